@@ -1,0 +1,151 @@
+"""TEST INFRASTRUCTURE -- CPU fp32 restatement (plain torch ops) of the encoder the reference calls.
+
+The encoder arithmetic is third-party: HuggingFace `transformers==3.0.0` `XLMRobertaModel`
+(requirements.txt:30), loaded at flair/embeddings.py:2951-2953 and called at
+flair/embeddings.py:3269.  That package is not vendored under /root/reference, so this file
+restates its published algorithm (modeling_bert.BertModel with modeling_roberta position ids):
+
+  position_ids = cumsum(ids != pad) * (ids != pad) + pad                (pad_token_id = 1)
+  x0 = LN(word[ids] + pos[position_ids] + type[0]), eps = 1e-5
+  per layer:  q,k,v = x W{q,k,v}^T + b ; P = softmax(q k^T / sqrt(d) + (1-mask) * -10000) ; c = P v
+              x  = LN(x + c Wo^T + bo) ; x = LN(x + gelu_erf(x W1^T + b1) W2^T + b2)
+
+Pinned against transformers 5.15 `XLMRobertaModel` (eager, fp32) run in the build container on
+random-init weights: tests/golden/encoder_tiny.npz (oracle/gen_golden.py).  The reference's own
+tests hold nothing for this boundary -> parity for the encoder is pinned only by
+those container-generated vectors.
+
+Only tests/, smoke() and bench.py's cpu_baseline leg may import this; product code never does.
+Weight names are HF state_dict names without the model prefix.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+class EncoderConfig:
+    def __init__(self, vocab_size=250002, hidden_size=1024, num_hidden_layers=24, num_attention_heads=16,
+                 intermediate_size=4096, max_position_embeddings=514, type_vocab_size=1, pad_token_id=1,
+                 layer_norm_eps=1e-5):
+        self.vocab_size = vocab_size
+        self.hidden_size = hidden_size
+        self.num_hidden_layers = num_hidden_layers
+        self.num_attention_heads = num_attention_heads
+        self.intermediate_size = intermediate_size
+        self.max_position_embeddings = max_position_embeddings
+        self.type_vocab_size = type_vocab_size
+        self.pad_token_id = pad_token_id
+        self.layer_norm_eps = layer_norm_eps
+
+    @staticmethod
+    def large():
+        return EncoderConfig()
+
+    @staticmethod
+    def base():
+        return EncoderConfig(hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072)
+
+
+def param_shapes(cfg):
+    """HF state_dict names -> shapes (encoder only; the pooler is unused on this path because
+    sentence_feat is False, flair/embeddings.py:3270-3271)."""
+    H, F_, V, P, TV = cfg.hidden_size, cfg.intermediate_size, cfg.vocab_size, cfg.max_position_embeddings, cfg.type_vocab_size
+    shapes = {
+        "embeddings.word_embeddings.weight": (V, H),
+        "embeddings.position_embeddings.weight": (P, H),
+        "embeddings.token_type_embeddings.weight": (TV, H),
+        "embeddings.LayerNorm.weight": (H,),
+        "embeddings.LayerNorm.bias": (H,),
+    }
+    for i in range(cfg.num_hidden_layers):
+        p = "encoder.layer.%d." % i
+        shapes[p + "attention.self.query.weight"] = (H, H)
+        shapes[p + "attention.self.query.bias"] = (H,)
+        shapes[p + "attention.self.key.weight"] = (H, H)
+        shapes[p + "attention.self.key.bias"] = (H,)
+        shapes[p + "attention.self.value.weight"] = (H, H)
+        shapes[p + "attention.self.value.bias"] = (H,)
+        shapes[p + "attention.output.dense.weight"] = (H, H)
+        shapes[p + "attention.output.dense.bias"] = (H,)
+        shapes[p + "attention.output.LayerNorm.weight"] = (H,)
+        shapes[p + "attention.output.LayerNorm.bias"] = (H,)
+        shapes[p + "intermediate.dense.weight"] = (F_, H)
+        shapes[p + "intermediate.dense.bias"] = (F_,)
+        shapes[p + "output.dense.weight"] = (H, F_)
+        shapes[p + "output.dense.bias"] = (H,)
+        shapes[p + "output.LayerNorm.weight"] = (H,)
+        shapes[p + "output.LayerNorm.bias"] = (H,)
+    return shapes
+
+
+def init_params(cfg, seed=20220711, std=0.02, device="cpu"):
+    """Random-init weights of the architecture: N(0, 0.02) matrices / embeddings, zero biases,
+    unit LayerNorm gains (HF BertPreTrainedModel._init_weights), pad row of word/position
+    embeddings zero (nn.Embedding padding_idx)."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    out = {}
+    for name, shp in param_shapes(cfg).items():
+        if name.endswith("LayerNorm.weight"):
+            t = torch.ones(shp)
+        elif name.endswith(".bias"):
+            t = torch.zeros(shp)
+        else:
+            t = torch.empty(shp).normal_(0.0, std, generator=g)
+            if name in ("embeddings.word_embeddings.weight", "embeddings.position_embeddings.weight"):
+                t[cfg.pad_token_id].zero_()
+        out[name] = t.to(device)
+    return out
+
+
+def position_ids_from_input_ids(input_ids, pad_id):
+    m = (input_ids != pad_id).to(torch.int64)
+    return torch.cumsum(m, dim=1) * m + pad_id
+
+
+def encoder_forward(params, cfg, input_ids, attention_mask, return_all=False):
+    """input_ids int64[B,S], attention_mask {0,1}[B,S] -> last hidden state f32[B,S,H]
+    (== hidden_states[-1], the only layer the path uses: `layers: '-1'`)."""
+    H, A = cfg.hidden_size, cfg.num_attention_heads
+    d = H // A
+    B, S = input_ids.shape
+    eps = cfg.layer_norm_eps
+    pos = position_ids_from_input_ids(input_ids, cfg.pad_token_id)
+    x = (params["embeddings.word_embeddings.weight"][input_ids]
+         + params["embeddings.position_embeddings.weight"][pos]
+         + params["embeddings.token_type_embeddings.weight"][0])
+    x = F.layer_norm(x, (H,), params["embeddings.LayerNorm.weight"], params["embeddings.LayerNorm.bias"], eps)
+    ext = (1.0 - attention_mask.to(x.dtype))[:, None, None, :] * -10000.0
+    hs = [x]
+    for i in range(cfg.num_hidden_layers):
+        p = "encoder.layer.%d." % i
+        q = F.linear(x, params[p + "attention.self.query.weight"], params[p + "attention.self.query.bias"])
+        k = F.linear(x, params[p + "attention.self.key.weight"], params[p + "attention.self.key.bias"])
+        v = F.linear(x, params[p + "attention.self.value.weight"], params[p + "attention.self.value.bias"])
+        q = q.view(B, S, A, d).transpose(1, 2)
+        k = k.view(B, S, A, d).transpose(1, 2)
+        v = v.view(B, S, A, d).transpose(1, 2)
+        sc = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(d) + ext
+        pr = torch.softmax(sc, dim=-1)
+        c = torch.matmul(pr, v).transpose(1, 2).reshape(B, S, H)
+        o = F.linear(c, params[p + "attention.output.dense.weight"], params[p + "attention.output.dense.bias"])
+        x = F.layer_norm(o + x, (H,), params[p + "attention.output.LayerNorm.weight"],
+                         params[p + "attention.output.LayerNorm.bias"], eps)
+        h = F.gelu(F.linear(x, params[p + "intermediate.dense.weight"], params[p + "intermediate.dense.bias"]))
+        o = F.linear(h, params[p + "output.dense.weight"], params[p + "output.dense.bias"])
+        x = F.layer_norm(o + x, (H,), params[p + "output.LayerNorm.weight"], params[p + "output.LayerNorm.bias"], eps)
+        hs.append(x)
+    if return_all:
+        return x, hs
+    return x
+
+
+def gather_first_subtoken(hidden, first_idx):
+    """first-subtoken pooling (flair/embeddings.py:3288-3345 with pooling_operation 'first') +
+    assign_batch_features zero padding (:108-124).  hidden f32[B,S,H]; first_idx int64[B,n] holds
+    the subtoken position of each word token's first piece, or -1 for padding / tokens with zero
+    subtokens (-> zero vector, :3306-3308).  Returns f32[B,n,H]."""
+    B, S, H = hidden.shape
+    idx = first_idx.clamp(min=0)
+    out = torch.gather(hidden, 1, idx[:, :, None].expand(-1, -1, H))
+    return out * (first_idx >= 0).to(hidden.dtype)[:, :, None]
