@@ -1,0 +1,201 @@
+#!/usr/bin/env python
+"""bench.py -- sentences/sec of XLM-R-large + CRF fine-tuning at seq_len 512 (BASELINE.json metric,
+configs[1]) on N GPUs of one node; one process per GPU, RCCL all-reduce of gradients per optimizer step.
+
+A "step" = one optimizer step = `accum` micro-batches of `micro_batch` synthetic 512-token sentences
+(encoder fwd + gather + head + CRF NLL + full backward) + [all-reduce] + grad-norm clip + fused AdamW.
+Inputs are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+
+  python bench.py --gpus 1 --steps 5 --warmup 2
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "kb-ner_amd"))
+
+MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16
+HBM_PEAK_GBS = 8000.0
+
+
+def encoder_flops_per_sentence(cfg, S):
+    """matmul FLOPs only, forward; fwd+bwd = 3x (no recompute counted)."""
+    H, L = cfg.hidden_size, cfg.num_hidden_layers
+    return L * (6 * S * H * H + 2 * S * H * H + 16 * S * H * H + 4 * S * S * H)
+
+
+def cpu_baseline(args, cfg_kw, T, tags):
+    """The oracle's fp32 torch-CPU restatement of the same step, timed on this box's host cores on a
+    bounded sample (kind 'port').  Only rank 0 at N=1."""
+    import numpy as np
+    import torch
+    from kbner import batch as kb
+    from oracle import encoder as oenc
+    from oracle import train_step as ots
+    start, stop, x_idx = tags
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    ocfg = oenc.EncoderConfig(**cfg_kw)
+    Bc = args.cpu_sentences
+    t0 = time.time()
+    params = oenc.init_params(ocfg, seed=kb.SEED)
+    g = torch.Generator().manual_seed(1)
+    params["linear.weight"] = torch.empty(T, ocfg.hidden_size).uniform_(-0.03, 0.03, generator=g)
+    params["linear.bias"] = torch.zeros(T)
+    tr = torch.randn(T, T, generator=g)
+    tr[start, :] = -1e12
+    tr[:, stop] = -1e12
+    params["transitions"] = tr
+    trainer = ots.OracleTrainer(params, ocfg, start, stop, x_idx, accum=1, t_total=1000)
+    del params
+    b = kb.synthetic_batch(Bc, args.seq_len, vocab=ocfg.vocab_size, T=T, x_idx=x_idx, start=start, stop=stop)
+    ob = dict(input_ids=torch.from_numpy(b["input_ids"]), attention_mask=torch.from_numpy(b["attention_mask"]),
+              first_idx=torch.from_numpy(b["first_idx"]), tags=torch.from_numpy(b["tags"].astype(np.int64)),
+              lengths=torch.from_numpy(b["lengths"].astype(np.int64)))
+    setup = time.time() - t0
+    t1 = time.time()
+    trainer.micro_batch(ob)
+    trainer.optimizer_step()
+    dt = time.time() - t1
+    return {"value": Bc / dt, "unit": "sentences/sec", "cores": ncores, "kind": "port",
+            "sample": "1 optimizer step of %d synthetic 512-token sentences (fwd+bwd+clip+AdamW, fp32 torch-CPU oracle, "
+                      "%d threads; %.1fs timed, %.1fs setup)" % (Bc, ncores, dt, setup)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--micro-batch", type=int, default=32)
+    ap.add_argument("--accum", type=int, default=4)
+    ap.add_argument("--seq-len", type=int, default=512)
+    ap.add_argument("--model", default="large", choices=["large", "base"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sentences", type=int, default=2)
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from kbner import batch as kb
+    from kbner import engine, ops
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    T, start, stop, x_idx = 29, 27, 28, 9  # resources/taggers/EN-English_x.pkl layout
+    cfg_kw = dict(vocab_size=250002, max_position_embeddings=514)
+    if args.model == "base":
+        cfg_kw.update(hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072)
+    cfg = engine.EncoderConfig(**cfg_kw)
+    tg = engine.Tagger(cfg, T, start, stop, device=dev)
+    tg.init_random(seed=kb.SEED)  # identical replicas on every rank
+    B, S, accum = args.micro_batch, args.seq_len, args.accum
+    # each rank gets its own shard of synthetic sentences (weak scaling: per-GPU work fixed)
+    micro = [kb.to_device(kb.synthetic_batch(B, S, vocab=cfg.vocab_size, T=T, x_idx=x_idx, start=start, stop=stop,
+                                              seed=kb.SEED + 1000 * rank + i), dev) for i in range(accum)]
+    total_steps = args.steps + args.warmup + 1
+    opt = engine.FusedAdamW(tg.arena, lr=5e-6, lr_rate=10000.0, t_total=max(total_steps, 100))
+    losses = []
+
+    def one_step():
+        for mb in micro:
+            losses.append(tg.forward_loss(mb, loss_scale=1.0 / accum, backward=True))
+        if world > 1:
+            dist.all_reduce(tg.arena.g)  # sum over ranks; AdamW applies 1/world (mean gradient)
+        opt.step(grad_scale=1.0 / world)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax)
+    sentences = world * B * accum * args.steps
+    value = sentences / dt
+    loss_first, loss_last = float(losses[0]), float(losses[-1])
+
+    roofline = None
+    if not args.no_roofline:
+        # live per-launch timing of the dominant kernel family (gemm_kernel<*>): HIP events on the launch
+        # stream around every GEMM launch of ONE extra step; algorithmic FLOPs = 2*M*N*K per launch.
+        recs = []
+        ops.GEMM_HOOK = recs
+        one_step()
+        torch.cuda.synchronize()
+        ops.GEMM_HOOK = None
+        tot_fl = sum(r[2] for r in recs)
+        tot_ms = sum(r[0].elapsed_time(r[1]) for r in recs)
+        by = {}
+        for s_ev, e_ev, fl, layout in recs:
+            d = by.setdefault(layout, [0.0, 0.0, 0])
+            d[0] += fl
+            d[1] += s_ev.elapsed_time(e_ev)
+            d[2] += 1
+        ach = tot_fl / (tot_ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": "gemm_kernel<A_KS,B_KS> (bf16 MFMA 16x16x32, all 3 layouts)",
+                    "achieved": round(ach, 2), "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": len(recs), "gemm_ms_per_step": round(tot_ms, 3),
+                    "by_layout": {("NT_fwd", "NN_dgrad", "TN_wgrad")[k]: {"tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 2),
+                                                                              "ms": round(v[1], 3), "launches": v[2]}
+                                  for k, v in sorted(by.items())}}
+
+    if rank == 0:
+        fl_sent = 3 * encoder_flops_per_sentence(cfg, S)
+        out = {
+            "metric": "sentences/sec XLM-R-%s+CRF fine-tune seq512" % args.model,
+            "value": round(value, 2), "unit": "sentences/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "configs[1]: xlm-roberta-%s (random-init, L%d/H%d/A%d/F%d, V=250002) + linear head + CRF (T=29), "
+                                   "seq_len=%d, bf16 MFMA GEMMs/attention, fp32 master weights + AdamW(HF) + clip 5.0, "
+                                   "dropout 0 (BASELINE.md workload spec)" % (args.model, cfg.num_hidden_layers, cfg.hidden_size,
+                                                                              cfg.num_attention_heads, cfg.intermediate_size, S),
+                       "micro_batch": B, "accumulate": accum, "global_batch": world * B * accum, "seq_len": S,
+                       "parallelism": "dp%d" % world},
+            "encoder_tflops_fwd_bwd_per_sentence": round(fl_sent / 1e12, 4),
+            "mfma_fraction_end_to_end": round(value / world * fl_sent / (MFMA_BF16_DENSE_PEAK_TFLOPS * 1e12), 4),
+            "loss_first": round(loss_first, 4), "loss_last": round(loss_last, 4),
+        }
+        if roofline is not None:
+            out["roofline"] = roofline
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args, cfg_kw if args.model == "base" else dict(cfg_kw), T, (start, stop, x_idx))
+            except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
+                out["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

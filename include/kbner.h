@@ -1,0 +1,110 @@
+/* kbner.h -- C ABI of libkbner_hip.so: the MI355X (gfx950) kernels behind KB-NER's token-classification
+ * hot path (XLM-R encoder fwd/bwd + emission head + linear-chain CRF + AdamW).
+ *
+ * The reference (Alibaba-NLP/KB-NER) is pure Python and has NO FFI for this path: the "interface" each
+ * entry point replaces is the torch / transformers op call site listed next to it (file:line under the
+ * reference tree).  The binding a maintainer adds is a ctypes stub; the build's own
+ * binding is kb-ner_amd/kbner/lib.py.
+ *
+ * Conventions (all functions):
+ *   - return 0 on success, -22 (EINVAL) on a bad argument, -(hipError_t) on a launch failure; never throw/exit
+ *   - every pointer is a DEVICE pointer owned by the caller (torch) and kept alive until the stream drains
+ *   - `stream` is a hipStream_t (NULL = default stream); work is enqueued asynchronously on it
+ *   - no global mutable state, no device allocation: callers pass workspaces
+ *   - bf16 tensors are raw uint16_t storage, row-major; fp32 statistics / optimizer state / CRF
+ */
+#ifndef KBNER_H
+#define KBNER_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef uint16_t kbner_bf16;
+
+int kbner_abi_version(void);
+int kbner_device_count(void);
+
+/* ---------------- linear-chain CRF (transitions[to,from], START/STOP are tag ids) ---------------- */
+/* SequenceTagger._viterbi_decode, flair/models/sequence_tagger_model.py:1248-1327 (called per sentence
+ * from _obtain_labels :1193-1210).  emit f32[B,n,T], lens i32[B] -> tags i32[B,n] (-1 past lens),
+ * conf f32[B,n] (max of softmax of the Viterbi scores, :1295-1300), popped i32[B] (nullable; the start tag
+ * the reference asserts == START at :1302-1303).  Bit-exact tag indices. */
+size_t kbner_crf_viterbi_lds_bytes(int n, int T);
+int kbner_crf_viterbi(const float* emit, const float* trans, const int* lens, int B, int n, int T, int start, int stop,
+                      int* tags, float* conf, int* popped, void* stream);
+/* _forward_alg :1329-1394 + FastSequenceTagger._score_sentence :2544-2591 on compacted rows.
+ * -> logz f32[B], gold f32[B], alpha f32[B,n+1,T] (saved for backward). */
+int kbner_crf_nll_fwd(const float* emit, const float* trans, const int* tags, const int* lens, int B, int n, int T, int start,
+                      int stop, float* logz, float* gold, float* alpha, void* stream);
+/* autograd backward of the two above (loss.backward(), flair/trainers/finetune_trainer.py:957):
+ * demit f32[B,n,T] (overwritten), dtrans f32[T,T] (+=, atomics) for sum_b dloss[b]*(logz_b - gold_b). */
+int kbner_crf_nll_bwd(const float* emit, const float* trans, const int* tags, const int* lens, const float* alpha,
+                      const float* logz, const float* dloss, int B, int n, int T, int start, int stop, float* demit,
+                      float* dtrans, void* stream);
+
+/* ---------------- row moves: pooling, compaction, emission head ---------------- */
+/* first-subtoken pooling + assign_batch_features (flair/embeddings.py:3288-3345,108-124) and the remove_x
+ * compaction loop (sequence_tagger_model.py:2474-2488) as ONE gather: out[r] = idx[r] >= 0 ? src[idx[r]] : 0 */
+int kbner_gather_rows(const kbner_bf16* src, const int* idx, kbner_bf16* out, int R, int H, void* stream);
+/* its backward (unique indices; caller zero-fills dsrc) */
+int kbner_scatter_rows(const kbner_bf16* dout, const int* idx, kbner_bf16* dsrc, int R, int H, void* stream);
+/* self.linear, sequence_tagger_model.py:1027: out f32[R,T] = x bf16[R,H] . w f32[T,H]^T + bias */
+int kbner_head_fwd(const kbner_bf16* x, const float* w, const float* bias, float* out, int R, int H, int T, void* stream);
+int kbner_head_bwd_dx(const float* de, const float* w, kbner_bf16* dx, int R, int H, int T, void* stream);
+int kbner_head_bwd_dw(const float* de, const kbner_bf16* x, float* dw, float* db, int R, int H, int T, void* stream);
+/* bias gradients: out f32[N] += column sums of x bf16[M,N] (row stride ld) */
+int kbner_colsum(const kbner_bf16* x, float* out, int M, int N, int ld, void* stream);
+
+/* ---------------- LayerNorm / embeddings (transformers BertEmbeddings, BertSelfOutput, BertOutput) ---------------- */
+int kbner_ln_fwd(const kbner_bf16* h, const float* gamma, const float* beta, float eps, kbner_bf16* y, float* mean,
+                 float* rstd, int M, int H, void* stream);
+int kbner_ln_bwd(const kbner_bf16* dy, const kbner_bf16* h, const float* mean, const float* rstd, const float* gamma,
+                 kbner_bf16* dh, float* dgamma, float* dbeta, float* dbias, int M, int H, void* stream);
+/* word[ids] + pos[pos_ids] + type[0] -> h0 (saved) -> LayerNorm -> y */
+int kbner_embed_ln_fwd(const int* ids, const int* pos_ids, const float* word, const float* pos, const float* type0,
+                       const float* gamma, const float* beta, float eps, kbner_bf16* h0, kbner_bf16* y, float* mean,
+                       float* rstd, int M, int H, void* stream);
+int kbner_embed_ln_bwd(const kbner_bf16* dy, const kbner_bf16* h0, const float* mean, const float* rstd, const float* gamma,
+                       const int* ids, const int* pos_ids, float* dgamma, float* dbeta, float* dword, float* dpos,
+                       float* dtype0, int M, int H, void* stream);
+
+/* ---------------- bf16 MFMA GEMM (torch.nn.Linear fwd/bwd inside transformers' BertLayer) ---------------- */
+#define KBNER_GEMM_NT 0 /* C[M,N] = A[M,K] . B[N,K]^T        forward  */
+#define KBNER_GEMM_NN 1 /* C[M,N] = A[M,K] . Bmem[K,N]        dgrad    */
+#define KBNER_GEMM_TN 2 /* C[M,N] = Amem[K,M]^T . Bmem[K,N]   wgrad    */
+#define KBNER_EPI_BIAS 1
+#define KBNER_EPI_GELU 2
+#define KBNER_EPI_ADD 4
+#define KBNER_EPI_DGELU 8
+#define KBNER_EPI_ATOMIC32 16
+int kbner_gemm_bf16(int layout, const kbner_bf16* A, int lda, const kbner_bf16* B, int ldb, int M, int N, int K,
+                    kbner_bf16* C, int ldc, float* C32, int ldc32, const float* bias, const kbner_bf16* addend, int ldadd,
+                    const kbner_bf16* aux, int ldaux, kbner_bf16* out2, int ldout2, int epi, int splitk, float alpha,
+                    void* stream);
+
+/* ---------------- fused self-attention (transformers BertSelfAttention), head_dim 64, S<=512 ---------------- */
+int kbner_attn_fwd(const kbner_bf16* qkv, const float* maskbias, kbner_bf16* ctx, float* lse, int B, int S, int H, int A,
+                   void* stream);
+int kbner_attn_bwd(const kbner_bf16* qkv, const kbner_bf16* ctx, const kbner_bf16* dctx, const float* maskbias,
+                   const float* lse, float* Dws, kbner_bf16* dqkv, int B, int S, int H, int A, void* stream);
+
+/* ---------------- optimiser (transformers==3.0.0 AdamW + clip_grad_norm_, finetune_trainer.py:1010,1018) ------------- */
+int kbner_sqnorm_ws_floats(void);
+int kbner_grad_sqnorm(const float* g, size_t n, float* ws, float* out, int accumulate, void* stream);
+int kbner_adamw_hf(float* p, float* g, float* m, float* v, kbner_bf16* shadow, size_t n, size_t n_shadow, float step_size,
+                   float lr_wd, float b1, float b2, float eps, const float* gnorm_sq, float max_norm, float grad_scale,
+                   int zero_grad, void* stream);
+int kbner_f32_to_bf16(const float* x, kbner_bf16* y, size_t n, void* stream);
+int kbner_wdiff_sum(const float* a, const float* b, const float* w, int n, float* out, void* stream);
+
+/* ---------------- hardware-semantics probes (debug) ---------------- */
+int kbner_probe_tr(const uint16_t* in, uint16_t* out, void* stream);
+int kbner_probe_mfma(const kbner_bf16* a, const kbner_bf16* b, float* c, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KBNER_H */

@@ -1,0 +1,428 @@
+// Fused multi-head self-attention for gfx950 (CDNA4), head_dim 64, S <= 512 (XLM-R's window),
+// forward + backward, bf16 MFMA with fp32 softmax statistics.
+//
+//   P = softmax(Q K^T / sqrt(d) + maskbias[key]) ; O = P V            (maskbias = (1-mask) * -10000,
+//   transformers 3.0.0 BertSelfAttention, reached from flair/embeddings.py:3269)
+//
+// Design (MI355X-first, not a flash-attention port): XLM-R never exceeds 512 positions, so the two
+// [S,64] operand panels a workgroup needs (64 KiB each at S=512) fit the CU's 160 KiB LDS whole.
+// Every kernel keeps a 16-row "stationary" fragment set in registers per wave and streams the two
+// LDS-resident panels past it: no online-softmax rescaling, no K/V re-fetch per tile, one DMA
+// (global_load_lds, 16 B/lane, XOR-swizzled on the source address) of each panel per workgroup.
+// Products are computed transposed where that makes the softmax axis lane-local (S^T = K Q^T) so
+// the probabilities feed the next MFMA as a B operand straight from registers; k-strided operands
+// (V^T, K^T, Q^T, dO^T) come from the same row-major panels via ds_read_b64_tr_b16.
+//
+//   attn_fwd     grid (S/128, A, B): panels K,V ; stationary Q        -> O [M,H], lse [B,A,S]
+//   attn_bwd_dq  grid (S/128, A, B): panels K,V ; stationary Q,dO     -> dQ
+//   attn_bwd_dkv grid (S/128, A, B): panels Q,dO; stationary K,V      -> dK, dV
+// (backward recomputes S and dP once per kernel: 7 matmuls instead of 5, no atomics, no LDS
+// round trip of computed tiles.)  qkv / dqkv are token-major [M, 3H] (Q | K | V), head h at
+// column h*64, exactly what the fused QKV GEMM produces / consumes: no permute kernels.
+#include "common.h"
+
+#define AT_D 64
+#define AT_MAXS 512
+#define AT_QT 128  // rows (queries or keys) owned by one workgroup
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void glb_cvoid;
+
+static __device__ __forceinline__ void glds16(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((glb_cvoid*)g, (lds_void*)l, 16, 0, 0);
+}
+static __device__ __forceinline__ int kc_swz(int row) { return (row >> 1) & 7; }
+
+// DMA a [S rows][64] bf16 panel (row stride ld elements) into a swizzled LDS image (128-B rows)
+static __device__ __forceinline__ void stage_panel(const bf16_t* __restrict__ src, int ld, int S, unsigned char* s, int wid,
+                                                   int lane) {
+  const int ninstr = S / 8;  // 1 KiB = 8 rows per wave-instruction
+  for (int q = wid; q < ninstr; q += 4) {
+    const int row = q * 8 + (lane >> 3);
+    const int pos = lane & 7;
+    glds16(src + (size_t)row * ld + ((pos ^ kc_swz(row)) << 3), s + q * 1024);
+  }
+}
+
+// 16 rows (r0 + lane&15) x 32 k (ks): k-contiguous fragment, ds_read_b128
+static __device__ __forceinline__ bf16x8 kc_frag(const unsigned char* s, int r0, int ks, int lane) {
+  const int row = r0 + (lane & 15);
+  const int c = ks * 4 + (lane >> 4);
+  const s8v v = *reinterpret_cast<const s8v*>(s + row * 128 + ((c ^ kc_swz(row)) << 4));
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+// transposed fragment: 16 "rows" = panel columns db*16 + (lane&15); k = panel rows of the 32-row
+// chunk kc in the split order {g*4+j (j<4), 16+g*4+(j-4)} that matches two stacked 16x16 C tiles
+static __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* s, int kc, int db, int lane) {
+  const int p = lane & 15;
+  const int row = kc * 32 + (lane >> 4) * 4 + (p >> 2);
+  const int c = db * 2 + ((p & 3) >> 1);
+  const unsigned char* a = s + row * 128 + ((c ^ kc_swz(row)) << 4) + ((p & 1) << 3);
+  const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4v __attribute__((address_space(3)))*)(a));
+  const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4v __attribute__((address_space(3)))*)(a + 16 * 128));
+  s8v v;
+  v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+  v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+// stationary fragment straight from global: row (r0 + lane&15), 8 consecutive d at ks*32 + g*8
+static __device__ __forceinline__ bf16x8 glb_frag(const bf16_t* __restrict__ base, int ld, int r0, int ks, int lane) {
+  const s8v v = *reinterpret_cast<const s8v*>(base + (size_t)(r0 + (lane & 15)) * ld + ks * 32 + (lane >> 4) * 8);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+static __device__ __forceinline__ bf16x8 pack_b(const f4v lo, const f4v hi) {
+  union {
+    uint32_t u[4];
+    bf16x8 v;
+  } r;
+  r.u[0] = pack2bf(lo[0], lo[1]);
+  r.u[1] = pack2bf(lo[2], lo[3]);
+  r.u[2] = pack2bf(hi[0], hi[1]);
+  r.u[3] = pack2bf(hi[2], hi[3]);
+  return r.v;
+}
+
+static __device__ __forceinline__ float group4_sum(float v) {  // across the 4 lane groups g (same lane&15)
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+static __device__ __forceinline__ float group4_max(float v) {
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  v = fmaxf(v, __shfl_xor(v, 32, 64));
+  return v;
+}
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+
+// ------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 1) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ maskbias,
+                                                          bf16_t* __restrict__ ctx, float* __restrict__ lse, int S, int H,
+                                                          int A, float scale) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sK = smem;
+  unsigned char* sV = smem + AT_MAXS * 128;
+  float* sMask = reinterpret_cast<float*>(smem + 2 * AT_MAXS * 128);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int ld = 3 * H;
+  const bf16_t* base = qkv + (size_t)b * S * ld + h * AT_D;
+  stage_panel(base + H, ld, S, sK, wid, lane);
+  stage_panel(base + 2 * H, ld, S, sV, wid, lane);
+  for (int i = tid; i < S; i += 256) sMask[i] = maskbias[(size_t)b * S + i];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const int g = lane >> 4, li = lane & 15;
+  const int nkb = S / 16;
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+    const int q0 = qt * AT_QT + wid * 32 + pass * 16;
+    if (q0 >= S) break;
+    const bf16x8 qf0 = glb_frag(base, ld, q0, 0, lane);
+    const bf16x8 qf1 = glb_frag(base, ld, q0, 1, lane);
+    f4v st[AT_MAXS / 16];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int f = 0; f < AT_MAXS / 16; ++f) {
+      if (f < nkb) {
+        f4v a = (f4v){0.f, 0.f, 0.f, 0.f};
+        a = MFMA(kc_frag(sK, f * 16, 0, lane), qf0, a);
+        a = MFMA(kc_frag(sK, f * 16, 1, lane), qf1, a);
+        const float4 mb = *reinterpret_cast<const float4*>(sMask + f * 16 + g * 4);
+        a[0] = a[0] * scale + mb.x;
+        a[1] = a[1] * scale + mb.y;
+        a[2] = a[2] * scale + mb.z;
+        a[3] = a[3] * scale + mb.w;
+        mx = fmaxf(mx, fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])));
+        st[f] = a;
+      }
+    }
+    mx = group4_max(mx);
+    float sum = 0.0f;
+#pragma unroll
+    for (int f = 0; f < AT_MAXS / 16; ++f) {
+      if (f < nkb) {
+        f4v a = st[f];
+        a[0] = __expf(a[0] - mx);
+        a[1] = __expf(a[1] - mx);
+        a[2] = __expf(a[2] - mx);
+        a[3] = __expf(a[3] - mx);
+        sum += (a[0] + a[1]) + (a[2] + a[3]);
+        st[f] = a;
+      }
+    }
+    sum = group4_sum(sum);
+    const float inv = 1.0f / sum;
+    f4v o[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) o[db] = (f4v){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kc = 0; kc < AT_MAXS / 32; ++kc) {
+      if (kc * 2 < nkb) {
+        const bf16x8 pb = pack_b(st[2 * kc] * inv, st[2 * kc + 1] * inv);
+#pragma unroll
+        for (int db = 0; db < 4; ++db) o[db] = MFMA(tr_frag(sV, kc, db, lane), pb, o[db]);
+      }
+    }
+    // O^T fragment: lane holds O[q0+li][db*16 + g*4 .. +3]
+    bf16_t* orow = ctx + (size_t)(b * S + q0 + li) * H + h * AT_D;
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+      uint2 u;
+      u.x = pack2bf(o[db][0], o[db][1]);
+      u.y = pack2bf(o[db][2], o[db][3]);
+      *reinterpret_cast<uint2*>(orow + db * 16 + g * 4) = u;
+    }
+    if (g == 0) lse[((size_t)b * A + h) * S + q0 + li] = mx + __logf(sum);
+  }
+}
+
+// D[b,h,s] = sum_d dO[m, h*64+d] * O[m, h*64+d]
+__global__ __launch_bounds__(256) void attn_rowdot_kernel(const bf16_t* __restrict__ dctx, const bf16_t* __restrict__ ctx,
+                                                          float* __restrict__ D, int B, int S, int H, int A) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= B * S * A) return;
+  const int h = idx % A;
+  const int m = idx / A;
+  const bf16_t* a = dctx + (size_t)m * H + h * AT_D;
+  const bf16_t* c = ctx + (size_t)m * H + h * AT_D;
+  float acc = 0.0f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const uint4 ua = *reinterpret_cast<const uint4*>(a + j * 8);
+    const uint4 uc = *reinterpret_cast<const uint4*>(c + j * 8);
+    const uint32_t wa[4] = {ua.x, ua.y, ua.z, ua.w};
+    const uint32_t wc[4] = {uc.x, uc.y, uc.z, uc.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      acc += __uint_as_float(wa[k] << 16) * __uint_as_float(wc[k] << 16);
+      acc += __uint_as_float(wa[k] & 0xffff0000u) * __uint_as_float(wc[k] & 0xffff0000u);
+    }
+  }
+  const int b = m / S, s = m % S;
+  D[((size_t)b * A + h) * S + s] = acc;
+}
+
+// ------------------------------------------------------------------------------------------
+// backward: dQ   (owner = query rows; panels K, V)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dctx,
+                                                             const float* __restrict__ maskbias, const float* __restrict__ lse,
+                                                             const float* __restrict__ Dv, bf16_t* __restrict__ dqkv, int S,
+                                                             int H, int A, float scale) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sK = smem;
+  unsigned char* sV = smem + AT_MAXS * 128;
+  float* sMask = reinterpret_cast<float*>(smem + 2 * AT_MAXS * 128);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int ld = 3 * H;
+  const bf16_t* base = qkv + (size_t)b * S * ld + h * AT_D;
+  stage_panel(base + H, ld, S, sK, wid, lane);
+  stage_panel(base + 2 * H, ld, S, sV, wid, lane);
+  for (int i = tid; i < S; i += 256) sMask[i] = maskbias[(size_t)b * S + i];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const int g = lane >> 4, li = lane & 15;
+  const int nkc = S / 32;
+  const bf16_t* dob = dctx + (size_t)b * S * H + h * AT_D;
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+    const int q0 = qt * AT_QT + wid * 32 + pass * 16;
+    if (q0 >= S) break;
+    const bf16x8 qf0 = glb_frag(base, ld, q0, 0, lane);
+    const bf16x8 qf1 = glb_frag(base, ld, q0, 1, lane);
+    const bf16x8 do0 = glb_frag(dob, H, q0, 0, lane);
+    const bf16x8 do1 = glb_frag(dob, H, q0, 1, lane);
+    const size_t sidx = ((size_t)b * A + h) * S + q0 + li;
+    const float l_q = lse[sidx];
+    const float d_q = Dv[sidx];
+    f4v dq[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) dq[db] = (f4v){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+    for (int kc = 0; kc < nkc; ++kc) {
+      f4v s0 = (f4v){0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
+      s0 = MFMA(kc_frag(sK, kc * 32, 0, lane), qf0, s0);
+      s0 = MFMA(kc_frag(sK, kc * 32, 1, lane), qf1, s0);
+      s1 = MFMA(kc_frag(sK, kc * 32 + 16, 0, lane), qf0, s1);
+      s1 = MFMA(kc_frag(sK, kc * 32 + 16, 1, lane), qf1, s1);
+      p0 = MFMA(kc_frag(sV, kc * 32, 0, lane), do0, p0);
+      p0 = MFMA(kc_frag(sV, kc * 32, 1, lane), do1, p0);
+      p1 = MFMA(kc_frag(sV, kc * 32 + 16, 0, lane), do0, p1);
+      p1 = MFMA(kc_frag(sV, kc * 32 + 16, 1, lane), do1, p1);
+      const float4 m0 = *reinterpret_cast<const float4*>(sMask + kc * 32 + g * 4);
+      const float4 m1 = *reinterpret_cast<const float4*>(sMask + kc * 32 + 16 + g * 4);
+      const float mb0[4] = {m0.x, m0.y, m0.z, m0.w};
+      const float mb1[4] = {m1.x, m1.y, m1.z, m1.w};
+      f4v ds0, ds1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pr0 = __expf(s0[r] * scale + mb0[r] - l_q);
+        const float pr1 = __expf(s1[r] * scale + mb1[r] - l_q);
+        ds0[r] = pr0 * (p0[r] - d_q);
+        ds1[r] = pr1 * (p1[r] - d_q);
+      }
+      const bf16x8 dsb = pack_b(ds0, ds1);
+#pragma unroll
+      for (int db = 0; db < 4; ++db) dq[db] = MFMA(tr_frag(sK, kc, db, lane), dsb, dq[db]);
+    }
+    bf16_t* orow = dqkv + (size_t)(b * S + q0 + li) * ld + h * AT_D;
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+      uint2 u;
+      u.x = pack2bf(dq[db][0] * scale, dq[db][1] * scale);
+      u.y = pack2bf(dq[db][2] * scale, dq[db][3] * scale);
+      *reinterpret_cast<uint2*>(orow + db * 16 + g * 4) = u;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward: dK, dV   (owner = key rows; panels Q, dO)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dctx,
+                                                              const float* __restrict__ maskbias, const float* __restrict__ lse,
+                                                              const float* __restrict__ Dv, bf16_t* __restrict__ dqkv, int S,
+                                                              int H, int A, float scale) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sQ = smem;
+  unsigned char* sO = smem + AT_MAXS * 128;
+  float* sL = reinterpret_cast<float*>(smem + 2 * AT_MAXS * 128);
+  float* sD = sL + AT_MAXS;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int ld = 3 * H;
+  const bf16_t* base = qkv + (size_t)b * S * ld + h * AT_D;
+  const bf16_t* dob = dctx + (size_t)b * S * H + h * AT_D;
+  stage_panel(base, ld, S, sQ, wid, lane);
+  stage_panel(dob, H, S, sO, wid, lane);
+  const size_t sbase = ((size_t)b * A + h) * S;
+  for (int i = tid; i < S; i += 256) {
+    sL[i] = lse[sbase + i];
+    sD[i] = Dv[sbase + i];
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const int g = lane >> 4, li = lane & 15;
+  const int nqc = S / 32;
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+    const int k0 = kt * AT_QT + wid * 32 + pass * 16;
+    if (k0 >= S) break;
+    const bf16x8 kf0 = glb_frag(base + H, ld, k0, 0, lane);
+    const bf16x8 kf1 = glb_frag(base + H, ld, k0, 1, lane);
+    const bf16x8 vf0 = glb_frag(base + 2 * H, ld, k0, 0, lane);
+    const bf16x8 vf1 = glb_frag(base + 2 * H, ld, k0, 1, lane);
+    const float mb = maskbias[(size_t)b * S + k0 + li];
+    f4v dk[4], dv[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+      dk[db] = (f4v){0.f, 0.f, 0.f, 0.f};
+      dv[db] = (f4v){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll 2
+    for (int qc = 0; qc < nqc; ++qc) {
+      // S and dP in [q rows, key cols] orientation: lane holds q = qc*32 + f*16 + g*4 + r, key = k0 + li
+      f4v s0 = (f4v){0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
+      s0 = MFMA(kc_frag(sQ, qc * 32, 0, lane), kf0, s0);
+      s0 = MFMA(kc_frag(sQ, qc * 32, 1, lane), kf1, s0);
+      s1 = MFMA(kc_frag(sQ, qc * 32 + 16, 0, lane), kf0, s1);
+      s1 = MFMA(kc_frag(sQ, qc * 32 + 16, 1, lane), kf1, s1);
+      p0 = MFMA(kc_frag(sO, qc * 32, 0, lane), vf0, p0);
+      p0 = MFMA(kc_frag(sO, qc * 32, 1, lane), vf1, p0);
+      p1 = MFMA(kc_frag(sO, qc * 32 + 16, 0, lane), vf0, p1);
+      p1 = MFMA(kc_frag(sO, qc * 32 + 16, 1, lane), vf1, p1);
+      const float4 l0 = *reinterpret_cast<const float4*>(sL + qc * 32 + g * 4);
+      const float4 l1 = *reinterpret_cast<const float4*>(sL + qc * 32 + 16 + g * 4);
+      const float4 d0 = *reinterpret_cast<const float4*>(sD + qc * 32 + g * 4);
+      const float4 d1 = *reinterpret_cast<const float4*>(sD + qc * 32 + 16 + g * 4);
+      const float la[4] = {l0.x, l0.y, l0.z, l0.w}, lb[4] = {l1.x, l1.y, l1.z, l1.w};
+      const float da[4] = {d0.x, d0.y, d0.z, d0.w}, dbv[4] = {d1.x, d1.y, d1.z, d1.w};
+      f4v pr0, pr1, ds0, ds1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        pr0[r] = __expf(s0[r] * scale + mb - la[r]);
+        pr1[r] = __expf(s1[r] * scale + mb - lb[r]);
+        ds0[r] = pr0[r] * (p0[r] - da[r]);
+        ds1[r] = pr1[r] * (p1[r] - dbv[r]);
+      }
+      const bf16x8 pb = pack_b(pr0, pr1);
+      const bf16x8 dsb = pack_b(ds0, ds1);
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        dv[db] = MFMA(tr_frag(sO, qc, db, lane), pb, dv[db]);
+        dk[db] = MFMA(tr_frag(sQ, qc, db, lane), dsb, dk[db]);
+      }
+    }
+    bf16_t* krow = dqkv + (size_t)(b * S + k0 + li) * ld + H + h * AT_D;
+    bf16_t* vrow = krow + H;
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+      uint2 u;
+      u.x = pack2bf(dk[db][0] * scale, dk[db][1] * scale);
+      u.y = pack2bf(dk[db][2] * scale, dk[db][3] * scale);
+      *reinterpret_cast<uint2*>(krow + db * 16 + g * 4) = u;
+      uint2 w;
+      w.x = pack2bf(dv[db][0], dv[db][1]);
+      w.y = pack2bf(dv[db][2], dv[db][3]);
+      *reinterpret_cast<uint2*>(vrow + db * 16 + g * 4) = w;
+    }
+  }
+}
+
+static int set_lds(const void* f, int bytes) {
+  hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+#define AT_LDS_BYTES (2 * AT_MAXS * 128 + 2 * AT_MAXS * 4)
+
+extern "C" {
+
+// qkv bf16 [B*S, 3H] ; maskbias f32 [B,S] ; ctx bf16 [B*S, H] ; lse f32 [B, A, S]
+// constraints: H = A * 64, S % 64 == 0, 64 <= S <= 512
+int kbner_attn_fwd(const bf16_t* qkv, const float* maskbias, bf16_t* ctx, float* lse, int B, int S, int H, int A, void* stream) {
+  KBNER_CHECK_ARG(B > 0 && A > 0 && H == A * AT_D && S % 64 == 0 && S >= 64 && S <= AT_MAXS);
+  static bool once = false;
+  if (!once) {
+    int r = set_lds(reinterpret_cast<const void*>(attn_fwd_kernel), AT_LDS_BYTES);
+    if (r) return r;
+    once = true;
+  }
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3((S + AT_QT - 1) / AT_QT, A, B), dim3(256), AT_LDS_BYTES, (hipStream_t)stream, qkv,
+                     maskbias, ctx, lse, S, H, A, 0.125f);
+  KBNER_LAUNCH_RET();
+}
+
+// dctx bf16 [B*S,H] (dO) ; ctx (O) ; lse ; Dws f32 [B,A,S] workspace ; dqkv bf16 [B*S,3H] out
+int kbner_attn_bwd(const bf16_t* qkv, const bf16_t* ctx, const bf16_t* dctx, const float* maskbias, const float* lse,
+                   float* Dws, bf16_t* dqkv, int B, int S, int H, int A, void* stream) {
+  KBNER_CHECK_ARG(B > 0 && A > 0 && H == A * AT_D && S % 64 == 0 && S >= 64 && S <= AT_MAXS);
+  static bool once = false;
+  if (!once) {
+    int r = set_lds(reinterpret_cast<const void*>(attn_bwd_dq_kernel), AT_LDS_BYTES);
+    if (r) return r;
+    r = set_lds(reinterpret_cast<const void*>(attn_bwd_dkv_kernel), AT_LDS_BYTES);
+    if (r) return r;
+    once = true;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const int n = B * S * A;
+  hipLaunchKernelGGL(attn_rowdot_kernel, dim3((n + 255) / 256), dim3(256), 0, s, dctx, ctx, Dws, B, S, H, A);
+  const dim3 grid((S + AT_QT - 1) / AT_QT, A, B);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), AT_LDS_BYTES, s, qkv, dctx, maskbias, lse, Dws, dqkv, S, H, A, 0.125f);
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), AT_LDS_BYTES, s, qkv, dctx, maskbias, lse, Dws, dqkv, S, H, A,
+                     0.125f);
+  KBNER_LAUNCH_RET();
+}
+
+}  // extern "C"

@@ -1,0 +1,330 @@
+// LayerNorm(+embedding) kernels for gfx950.  HBM-bound: one 64-lane wavefront owns a token row and
+// reduces it with DPP/shuffle butterflies; every global access is a 16-byte vector of 8 bf16
+// (or 2 x float4 for fp32 tables).  fp32 statistics, bf16 storage.
+//
+// Replaces the torch ops reached through transformers' BertEmbeddings / BertSelfOutput /
+// BertOutput LayerNorm (called from flair/embeddings.py:3269) and their autograd backward.
+//   fwd : y = (h - mean) * rstd * gamma + beta           (eps inside the sqrt, eps = 1e-5)
+//   bwd : dh = rstd * (g - mean_H(g) - xhat * mean_H(g * xhat)),  g = dy * gamma
+//         dgamma += sum_rows dy * xhat ; dbeta += sum_rows dy ; dbias += sum_rows dh (optional:
+//         the bias gradient of the GEMM whose output fed this LayerNorm's input)
+// H must be a multiple of 8 and <= 1024 (XLM-R base 768 / large 1024).
+#include "common.h"
+
+#define LN_MAXCH 2  // 16-byte chunks per lane: H <= 64 * 8 * 2
+
+template <int NCH>
+struct RowF {
+  float v[NCH][8];
+};
+
+template <int NCH>
+static __device__ __forceinline__ void load_row_bf16(const bf16_t* __restrict__ p, int H, int lane, RowF<NCH>& r) {
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int h0 = (lane + 64 * c) * 8;
+    if (h0 < H) {
+      const uint4 u = *reinterpret_cast<const uint4*>(p + h0);
+      const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        r.v[c][2 * j] = __uint_as_float(w[j] << 16);
+        r.v[c][2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r.v[c][j] = 0.0f;
+    }
+  }
+}
+
+template <int NCH>
+static __device__ __forceinline__ void store_row_bf16(bf16_t* __restrict__ p, int H, int lane, const RowF<NCH>& r) {
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int h0 = (lane + 64 * c) * 8;
+    if (h0 < H) {
+      uint4 u;
+      u.x = pack2bf(r.v[c][0], r.v[c][1]);
+      u.y = pack2bf(r.v[c][2], r.v[c][3]);
+      u.z = pack2bf(r.v[c][4], r.v[c][5]);
+      u.w = pack2bf(r.v[c][6], r.v[c][7]);
+      *reinterpret_cast<uint4*>(p + h0) = u;
+    }
+  }
+}
+
+template <int NCH>
+static __device__ __forceinline__ void load_row_f32(const float* __restrict__ p, int H, int lane, RowF<NCH>& r) {
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int h0 = (lane + 64 * c) * 8;
+    if (h0 < H) {
+      const float4 a = *reinterpret_cast<const float4*>(p + h0);
+      const float4 b = *reinterpret_cast<const float4*>(p + h0 + 4);
+      r.v[c][0] = a.x; r.v[c][1] = a.y; r.v[c][2] = a.z; r.v[c][3] = a.w;
+      r.v[c][4] = b.x; r.v[c][5] = b.y; r.v[c][6] = b.z; r.v[c][7] = b.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r.v[c][j] = 0.0f;
+    }
+  }
+}
+
+// round a row through bf16 (what is stored is what is normalised: fwd/bwd stay consistent)
+template <int NCH>
+static __device__ __forceinline__ void round_row(RowF<NCH>& r) {
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r.v[c][j] = bf2f(f2bf(r.v[c][j]));
+}
+
+template <int NCH>
+static __device__ __forceinline__ void row_stats(const RowF<NCH>& x, int H, float eps, float& mean, float& rstd) {
+  float s = 0.0f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += x.v[c][j];
+  mean = wave_sum(s) / (float)H;
+  float q = 0.0f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int h0 = (threadIdx.x % 64 + 64 * c) * 8;
+    if (h0 < H) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float d = x.v[c][j] - mean;
+        q += d * d;
+      }
+    }
+  }
+  rstd = rsqrtf(wave_sum(q) / (float)H + eps);
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ h, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float eps, bf16_t* __restrict__ y,
+                                                     float* __restrict__ mean_o, float* __restrict__ rstd_o, int M, int H) {
+  const int lane = threadIdx.x % 64;
+  const int wave = blockIdx.x * 4 + threadIdx.x / 64;
+  const int nwave = gridDim.x * 4;
+  RowF<NCH> g, b;
+  load_row_f32<NCH>(gamma, H, lane, g);
+  load_row_f32<NCH>(beta, H, lane, b);
+  for (int r = wave; r < M; r += nwave) {
+    RowF<NCH> x;
+    load_row_bf16<NCH>(h + (size_t)r * H, H, lane, x);
+    float mean, rstd;
+    row_stats<NCH>(x, H, eps, mean, rstd);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x.v[c][j] = (x.v[c][j] - mean) * rstd * g.v[c][j] + b.v[c][j];
+    store_row_bf16<NCH>(y + (size_t)r * H, H, lane, x);
+    if (lane == 0) {
+      mean_o[r] = mean;
+      rstd_o[r] = rstd;
+    }
+  }
+}
+
+// word[ids] + pos[pos_ids] + type[0] -> h0 (bf16, saved) -> LayerNorm -> y
+template <int NCH>
+__global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int* __restrict__ ids, const int* __restrict__ pos_ids,
+                                                           const float* __restrict__ word, const float* __restrict__ pos,
+                                                           const float* __restrict__ type0, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps, bf16_t* __restrict__ h0,
+                                                           bf16_t* __restrict__ y, float* __restrict__ mean_o,
+                                                           float* __restrict__ rstd_o, int M, int H) {
+  const int lane = threadIdx.x % 64;
+  const int wave = blockIdx.x * 4 + threadIdx.x / 64;
+  const int nwave = gridDim.x * 4;
+  RowF<NCH> g, b, ty;
+  load_row_f32<NCH>(gamma, H, lane, g);
+  load_row_f32<NCH>(beta, H, lane, b);
+  load_row_f32<NCH>(type0, H, lane, ty);
+  for (int r = wave; r < M; r += nwave) {
+    RowF<NCH> x, p;
+    load_row_f32<NCH>(word + (size_t)ids[r] * H, H, lane, x);
+    load_row_f32<NCH>(pos + (size_t)pos_ids[r] * H, H, lane, p);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x.v[c][j] = (x.v[c][j] + p.v[c][j]) + ty.v[c][j];
+    round_row<NCH>(x);
+    store_row_bf16<NCH>(h0 + (size_t)r * H, H, lane, x);
+    float mean, rstd;
+    row_stats<NCH>(x, H, eps, mean, rstd);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x.v[c][j] = (x.v[c][j] - mean) * rstd * g.v[c][j] + b.v[c][j];
+    store_row_bf16<NCH>(y + (size_t)r * H, H, lane, x);
+    if (lane == 0) {
+      mean_o[r] = mean;
+      rstd_o[r] = rstd;
+    }
+  }
+}
+
+// Backward.  EMBED: additionally scatter-add dh into the embedding-table gradients (fp32 atomics:
+// token ids repeat) and accumulate sum_rows dh into dtype0 through the dbias path.
+template <int NCH, bool EMBED>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ h,
+                                                     const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
+                                                     const float* __restrict__ gamma, bf16_t* __restrict__ dh,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                     float* __restrict__ dbias, const int* __restrict__ ids,
+                                                     const int* __restrict__ pos_ids, float* __restrict__ dword,
+                                                     float* __restrict__ dpos, int M, int H) {
+  __shared__ float red[3][4][64 * 8 * NCH];
+  const int lane = threadIdx.x % 64;
+  const int wid = threadIdx.x / 64;
+  const int wave = blockIdx.x * 4 + wid;
+  const int nwave = gridDim.x * 4;
+  RowF<NCH> g, ag, ab, ah;
+  load_row_f32<NCH>(gamma, H, lane, g);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ag.v[c][j] = ab.v[c][j] = ah.v[c][j] = 0.0f;
+  const float invH = 1.0f / (float)H;
+  for (int r = wave; r < M; r += nwave) {
+    RowF<NCH> x, d;
+    load_row_bf16<NCH>(h + (size_t)r * H, H, lane, x);
+    load_row_bf16<NCH>(dy + (size_t)r * H, H, lane, d);
+    const float mean = mean_i[r], rstd = rstd_i[r];
+    float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int h0 = (lane + 64 * c) * 8;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float xh = (h0 < H) ? (x.v[c][j] - mean) * rstd : 0.0f;
+        const float gd = d.v[c][j] * g.v[c][j];
+        x.v[c][j] = xh;
+        ag.v[c][j] += d.v[c][j] * xh;
+        ab.v[c][j] += d.v[c][j];
+        s1 += gd;
+        s2 += gd * xh;
+      }
+    }
+    s1 = wave_sum(s1) * invH;
+    s2 = wave_sum(s2) * invH;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float v = rstd * (d.v[c][j] * g.v[c][j] - s1 - x.v[c][j] * s2);
+        d.v[c][j] = v;
+        ah.v[c][j] += v;
+      }
+    if (dh) store_row_bf16<NCH>(dh + (size_t)r * H, H, lane, d);
+    if (EMBED) {
+      float* dw = dword + (size_t)ids[r] * H;
+      float* dp = dpos + (size_t)pos_ids[r] * H;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int h0 = (lane + 64 * c) * 8;
+        if (h0 < H) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            atomicAdd(dw + h0 + j, d.v[c][j]);
+            atomicAdd(dp + h0 + j, d.v[c][j]);
+          }
+        }
+      }
+    }
+  }
+  // block reduction of the per-column accumulators, then one atomic per column per block
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int col = (lane + 64 * c) * 8 + j;  // < 64*8*NCH
+      red[0][wid][col] = ag.v[c][j];
+      red[1][wid][col] = ab.v[c][j];
+      red[2][wid][col] = ah.v[c][j];
+    }
+  __syncthreads();
+  for (int col = threadIdx.x; col < H; col += 256) {
+    const float a = red[0][0][col] + red[0][1][col] + red[0][2][col] + red[0][3][col];
+    const float b = red[1][0][col] + red[1][1][col] + red[1][2][col] + red[1][3][col];
+    atomicAdd(dgamma + col, a);
+    atomicAdd(dbeta + col, b);
+    if (dbias) {
+      const float cc = red[2][0][col] + red[2][1][col] + red[2][2][col] + red[2][3][col];
+      atomicAdd(dbias + col, cc);
+    }
+  }
+}
+
+static inline int ln_grid(int M) {
+  int g = (M + 3) / 4;
+  if (g > 1024) g = 1024;
+  if (g < 1) g = 1;
+  return g;
+}
+
+extern "C" {
+
+int kbner_ln_fwd(const bf16_t* h, const float* gamma, const float* beta, float eps, bf16_t* y, float* mean, float* rstd,
+                 int M, int H, void* stream) {
+  KBNER_CHECK_ARG(M >= 0 && H > 0 && H % 8 == 0 && H <= 64 * 8 * LN_MAXCH);
+  if (M == 0) return 0;
+  if (H <= 512)
+    hipLaunchKernelGGL(ln_fwd_kernel<1>, dim3(ln_grid(M)), dim3(256), 0, (hipStream_t)stream, h, gamma, beta, eps, y, mean, rstd, M, H);
+  else
+    hipLaunchKernelGGL(ln_fwd_kernel<2>, dim3(ln_grid(M)), dim3(256), 0, (hipStream_t)stream, h, gamma, beta, eps, y, mean, rstd, M, H);
+  KBNER_LAUNCH_RET();
+}
+
+int kbner_embed_ln_fwd(const int* ids, const int* pos_ids, const float* word, const float* pos, const float* type0,
+                       const float* gamma, const float* beta, float eps, bf16_t* h0, bf16_t* y, float* mean, float* rstd,
+                       int M, int H, void* stream) {
+  KBNER_CHECK_ARG(M >= 0 && H > 0 && H % 8 == 0 && H <= 64 * 8 * LN_MAXCH);
+  if (M == 0) return 0;
+  if (H <= 512)
+    hipLaunchKernelGGL(embed_ln_fwd_kernel<1>, dim3(ln_grid(M)), dim3(256), 0, (hipStream_t)stream, ids, pos_ids, word, pos,
+                       type0, gamma, beta, eps, h0, y, mean, rstd, M, H);
+  else
+    hipLaunchKernelGGL(embed_ln_fwd_kernel<2>, dim3(ln_grid(M)), dim3(256), 0, (hipStream_t)stream, ids, pos_ids, word, pos,
+                       type0, gamma, beta, eps, h0, y, mean, rstd, M, H);
+  KBNER_LAUNCH_RET();
+}
+
+// dh may be NULL (embedding LayerNorm: nothing upstream).  dbias may be NULL.
+int kbner_ln_bwd(const bf16_t* dy, const bf16_t* h, const float* mean, const float* rstd, const float* gamma, bf16_t* dh,
+                 float* dgamma, float* dbeta, float* dbias, int M, int H, void* stream) {
+  KBNER_CHECK_ARG(M >= 0 && H > 0 && H % 8 == 0 && H <= 64 * 8 * LN_MAXCH);
+  if (M == 0) return 0;
+  int grid = ln_grid(M);
+  if (grid > 256) grid = 256;
+  if (H <= 512)
+    hipLaunchKernelGGL((ln_bwd_kernel<1, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, h, mean, rstd, gamma, dh,
+                       dgamma, dbeta, dbias, nullptr, nullptr, nullptr, nullptr, M, H);
+  else
+    hipLaunchKernelGGL((ln_bwd_kernel<2, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, h, mean, rstd, gamma, dh,
+                       dgamma, dbeta, dbias, nullptr, nullptr, nullptr, nullptr, M, H);
+  KBNER_LAUNCH_RET();
+}
+
+int kbner_embed_ln_bwd(const bf16_t* dy, const bf16_t* h0, const float* mean, const float* rstd, const float* gamma,
+                       const int* ids, const int* pos_ids, float* dgamma, float* dbeta, float* dword, float* dpos,
+                       float* dtype0, int M, int H, void* stream) {
+  KBNER_CHECK_ARG(M >= 0 && H > 0 && H % 8 == 0 && H <= 64 * 8 * LN_MAXCH);
+  if (M == 0) return 0;
+  int grid = ln_grid(M);
+  if (grid > 256) grid = 256;
+  if (H <= 512)
+    hipLaunchKernelGGL((ln_bwd_kernel<1, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, h0, mean, rstd, gamma,
+                       (bf16_t*)nullptr, dgamma, dbeta, dtype0, ids, pos_ids, dword, dpos, M, H);
+  else
+    hipLaunchKernelGGL((ln_bwd_kernel<2, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, h0, mean, rstd, gamma,
+                       (bf16_t*)nullptr, dgamma, dbeta, dtype0, ids, pos_ids, dword, dpos, M, H);
+  KBNER_LAUNCH_RET();
+}
+
+}  // extern "C"

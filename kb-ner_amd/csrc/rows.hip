@@ -1,0 +1,233 @@
+// Row-indexed helper kernels for gfx950: first-subtoken gather (+scatter backward), the T-wide
+// emission head (fwd / dX / dW,db) and bf16 column sums (bias gradients).  All HBM/L2-bound
+// integer-indexed row moves with 16-byte vector accesses; none of this is GEMM-shaped enough
+// (N = T = 29) to belong on MFMA.
+//
+// Replaces: the per-token pooling loop + assign_batch_features + .cpu()/.to(device) bounce
+// (flair/embeddings.py:3288-3345,108-124; sequence_tagger_model.py:909), the remove_x compaction
+// loop (sequence_tagger_model.py:2474-2488: the host passes row indices of the kept tokens so
+// gather and compaction are ONE gather), and self.linear (sequence_tagger_model.py:1027).
+#include "common.h"
+
+#define HEAD_MAXT 64
+
+// out[r,:] = idx[r] >= 0 ? src[idx[r],:] : 0        (bf16 rows, H % 8 == 0)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const bf16_t* __restrict__ src, const int* __restrict__ idx,
+                                                          bf16_t* __restrict__ out, int R, int H) {
+  const int lane = threadIdx.x % 64;
+  const int wave = blockIdx.x * 4 + threadIdx.x / 64;
+  const int nwave = gridDim.x * 4;
+  for (int r = wave; r < R; r += nwave) {
+    const int s = idx[r];
+    for (int h0 = lane * 8; h0 < H; h0 += 512) {
+      uint4 u = make_uint4(0, 0, 0, 0);
+      if (s >= 0) u = *reinterpret_cast<const uint4*>(src + (size_t)s * H + h0);
+      *reinterpret_cast<uint4*>(out + (size_t)r * H + h0) = u;
+    }
+  }
+}
+
+// dsrc[idx[r],:] = dout[r,:] for idx[r] >= 0 (indices are unique by construction: one first
+// subtoken per word token); the caller zero-fills dsrc beforehand.
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const bf16_t* __restrict__ dout, const int* __restrict__ idx,
+                                                           bf16_t* __restrict__ dsrc, int R, int H) {
+  const int lane = threadIdx.x % 64;
+  const int wave = blockIdx.x * 4 + threadIdx.x / 64;
+  const int nwave = gridDim.x * 4;
+  for (int r = wave; r < R; r += nwave) {
+    const int s = idx[r];
+    if (s < 0) continue;
+    for (int h0 = lane * 8; h0 < H; h0 += 512)
+      *reinterpret_cast<uint4*>(dsrc + (size_t)s * H + h0) = *reinterpret_cast<const uint4*>(dout + (size_t)r * H + h0);
+  }
+}
+
+static __device__ __forceinline__ void unpack8(const uint4 u, float* f) {
+  const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    f[2 * j] = __uint_as_float(w[j] << 16);
+    f[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u);
+  }
+}
+
+// emissions: out[r,t] = sum_h x[r,h] * w[t,h] + b[t]    (x bf16, w/b/out fp32; one wave per row)
+__global__ __launch_bounds__(256) void head_fwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, float* __restrict__ out, int R, int H,
+                                                       int T) {
+  const int lane = threadIdx.x % 64;
+  const int wave = blockIdx.x * 4 + threadIdx.x / 64;
+  const int nwave = gridDim.x * 4;
+  for (int r = wave; r < R; r += nwave) {
+    float xv[2][8];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int h0 = (lane + 64 * c) * 8;
+      if (h0 < H) {
+        unpack8(*reinterpret_cast<const uint4*>(x + (size_t)r * H + h0), xv[c]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xv[c][j] = 0.0f;
+      }
+    }
+    for (int t = 0; t < T; ++t) {
+      float acc = 0.0f;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int h0 = (lane + 64 * c) * 8;
+        if (h0 < H) {
+          const float4 a = *reinterpret_cast<const float4*>(w + (size_t)t * H + h0);
+          const float4 b = *reinterpret_cast<const float4*>(w + (size_t)t * H + h0 + 4);
+          acc += xv[c][0] * a.x + xv[c][1] * a.y + xv[c][2] * a.z + xv[c][3] * a.w + xv[c][4] * b.x + xv[c][5] * b.y +
+                 xv[c][6] * b.z + xv[c][7] * b.w;
+        }
+      }
+      acc = wave_sum(acc);
+      if (lane == 0) out[(size_t)r * T + t] = acc + bias[t];
+    }
+  }
+}
+
+// dx[r,h] = sum_t de[r,t] * w[t,h]        (one wave per row; bf16 out)
+__global__ __launch_bounds__(256) void head_bwd_dx_kernel(const float* __restrict__ de, const float* __restrict__ w,
+                                                          bf16_t* __restrict__ dx, int R, int H, int T) {
+  const int lane = threadIdx.x % 64;
+  const int wave = blockIdx.x * 4 + threadIdx.x / 64;
+  const int nwave = gridDim.x * 4;
+  for (int r = wave; r < R; r += nwave) {
+    float acc[2][8];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[c][j] = 0.0f;
+    for (int t = 0; t < T; ++t) {
+      const float d = de[(size_t)r * T + t];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int h0 = (lane + 64 * c) * 8;
+        if (h0 < H) {
+          const float4 a = *reinterpret_cast<const float4*>(w + (size_t)t * H + h0);
+          const float4 b = *reinterpret_cast<const float4*>(w + (size_t)t * H + h0 + 4);
+          acc[c][0] += d * a.x; acc[c][1] += d * a.y; acc[c][2] += d * a.z; acc[c][3] += d * a.w;
+          acc[c][4] += d * b.x; acc[c][5] += d * b.y; acc[c][6] += d * b.z; acc[c][7] += d * b.w;
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int h0 = (lane + 64 * c) * 8;
+      if (h0 < H) {
+        uint4 u;
+        u.x = pack2bf(acc[c][0], acc[c][1]);
+        u.y = pack2bf(acc[c][2], acc[c][3]);
+        u.z = pack2bf(acc[c][4], acc[c][5]);
+        u.w = pack2bf(acc[c][6], acc[c][7]);
+        *reinterpret_cast<uint4*>(dx + (size_t)r * H + h0) = u;
+      }
+    }
+  }
+}
+
+// dw[t,h] += sum_r de[r,t] * x[r,h] ; db[t] += sum_r de[r,t]
+// grid = (ceil(H/256), ceil(R/64)); thread owns column h; 64 rows of de staged in LDS.
+__global__ __launch_bounds__(256) void head_bwd_dw_kernel(const float* __restrict__ de, const bf16_t* __restrict__ x,
+                                                          float* __restrict__ dw, float* __restrict__ db, int R, int H, int T) {
+  __shared__ float sde[64 * HEAD_MAXT];
+  const int h = blockIdx.x * 256 + threadIdx.x;
+  const int r0 = blockIdx.y * 64;
+  const int nr = min(64, R - r0);
+  for (int i = threadIdx.x; i < nr * T; i += 256) sde[i] = de[(size_t)r0 * T + i];
+  __syncthreads();
+  float acc[HEAD_MAXT];
+#pragma unroll
+  for (int t = 0; t < HEAD_MAXT; ++t) acc[t] = 0.0f;
+  if (h < H) {
+    for (int r = 0; r < nr; ++r) {
+      const float xv = bf2f(x[(size_t)(r0 + r) * H + h]);
+#pragma unroll
+      for (int t = 0; t < HEAD_MAXT; ++t)
+        if (t < T) acc[t] += sde[r * T + t] * xv;
+    }
+#pragma unroll
+    for (int t = 0; t < HEAD_MAXT; ++t)
+      if (t < T) atomicAdd(dw + (size_t)t * H + h, acc[t]);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < T) {
+    float s = 0.0f;
+    for (int r = 0; r < nr; ++r) s += sde[r * T + threadIdx.x];
+    atomicAdd(db + threadIdx.x, s);
+  }
+}
+
+// out[n] += sum_m x[m,n]   (bf16 in, fp32 atomics out).  grid = (ceil(N/512), row chunks)
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ x, float* __restrict__ out, int M, int N,
+                                                     int ld, int rows_per_block) {
+  const int n0 = (blockIdx.x * 256 + threadIdx.x) * 2;
+  if (n0 >= N) return;
+  const int r0 = blockIdx.y * rows_per_block;
+  const int r1 = min(M, r0 + rows_per_block);
+  float a = 0.0f, b = 0.0f;
+  for (int r = r0; r < r1; ++r) {
+    const uint32_t u = *reinterpret_cast<const uint32_t*>(x + (size_t)r * ld + n0);
+    a += __uint_as_float(u << 16);
+    b += __uint_as_float(u & 0xffff0000u);
+  }
+  atomicAdd(out + n0, a);
+  atomicAdd(out + n0 + 1, b);
+}
+
+static inline int rows_grid(int R) {
+  int g = (R + 3) / 4;
+  if (g > 2048) g = 2048;
+  if (g < 1) g = 1;
+  return g;
+}
+
+extern "C" {
+
+int kbner_gather_rows(const bf16_t* src, const int* idx, bf16_t* out, int R, int H, void* stream) {
+  KBNER_CHECK_ARG(R >= 0 && H > 0 && H % 8 == 0);
+  if (R == 0) return 0;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(rows_grid(R)), dim3(256), 0, (hipStream_t)stream, src, idx, out, R, H);
+  KBNER_LAUNCH_RET();
+}
+
+int kbner_scatter_rows(const bf16_t* dout, const int* idx, bf16_t* dsrc, int R, int H, void* stream) {
+  KBNER_CHECK_ARG(R >= 0 && H > 0 && H % 8 == 0);
+  if (R == 0) return 0;
+  hipLaunchKernelGGL(scatter_rows_kernel, dim3(rows_grid(R)), dim3(256), 0, (hipStream_t)stream, dout, idx, dsrc, R, H);
+  KBNER_LAUNCH_RET();
+}
+
+int kbner_head_fwd(const bf16_t* x, const float* w, const float* bias, float* out, int R, int H, int T, void* stream) {
+  KBNER_CHECK_ARG(R >= 0 && H > 0 && H % 8 == 0 && H <= 1024 && T > 0 && T <= HEAD_MAXT);
+  if (R == 0) return 0;
+  hipLaunchKernelGGL(head_fwd_kernel, dim3(rows_grid(R)), dim3(256), 0, (hipStream_t)stream, x, w, bias, out, R, H, T);
+  KBNER_LAUNCH_RET();
+}
+
+int kbner_head_bwd_dx(const float* de, const float* w, bf16_t* dx, int R, int H, int T, void* stream) {
+  KBNER_CHECK_ARG(R >= 0 && H > 0 && H % 8 == 0 && H <= 1024 && T > 0 && T <= HEAD_MAXT);
+  if (R == 0) return 0;
+  hipLaunchKernelGGL(head_bwd_dx_kernel, dim3(rows_grid(R)), dim3(256), 0, (hipStream_t)stream, de, w, dx, R, H, T);
+  KBNER_LAUNCH_RET();
+}
+
+int kbner_head_bwd_dw(const float* de, const bf16_t* x, float* dw, float* db, int R, int H, int T, void* stream) {
+  KBNER_CHECK_ARG(R >= 0 && H > 0 && T > 0 && T <= HEAD_MAXT);
+  if (R == 0) return 0;
+  hipLaunchKernelGGL(head_bwd_dw_kernel, dim3((H + 255) / 256, (R + 63) / 64), dim3(256), 0, (hipStream_t)stream, de, x, dw,
+                     db, R, H, T);
+  KBNER_LAUNCH_RET();
+}
+
+int kbner_colsum(const bf16_t* x, float* out, int M, int N, int ld, void* stream) {
+  KBNER_CHECK_ARG(M >= 0 && N > 0 && N % 2 == 0 && ld >= N && ld % 2 == 0);
+  if (M == 0) return 0;
+  int rpb = 128;
+  hipLaunchKernelGGL(colsum_kernel, dim3((N / 2 + 255) / 256, (M + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream, x, out,
+                     M, N, ld, rpb);
+  KBNER_LAUNCH_RET();
+}
+
+}  // extern "C"

@@ -1,0 +1,426 @@
+"""Host-side engine of the hot path: parameter arena, XLM-R encoder forward/backward, emission
+head + CRF loss, fused AdamW -- all arithmetic in libkbner_hip.so (kbner.ops); torch only owns
+device memory and the stream.  No autograd: backward is explicit, mirroring what
+loss.backward() does in flair/trainers/finetune_trainer.py:957.
+
+Data layout in HBM (sized for 288 GB: everything stays resident, nothing is recomputed):
+  * ONE flat fp32 arena for parameters with identically laid-out arenas for grads / Adam m / v,
+    so clip-norm and AdamW are single streaming launches.  GEMM weights come first and have a
+    bf16 "shadow" (what MFMA reads), rewritten by the AdamW kernel itself.
+  * activations are token-major bf16 [M_pad, width] (M = B*S padded to 128 rows); per layer the
+    engine keeps x, qkv, ctx, h1, x1, pre, act, h2 (+ fp32 LN stats, softmax lse) for backward.
+"""
+import math
+
+import torch
+
+from . import ops
+from .lib import EPI_ADD, EPI_ATOMIC32, EPI_BIAS, EPI_DGELU, EPI_GELU, GEMM_NN, GEMM_NT, GEMM_TN
+
+BF16, F32, I32 = torch.bfloat16, torch.float32, torch.int32
+
+
+class EncoderConfig:
+    """Same fields/meaning as the HF XLMRobertaConfig the reference loads (flair/embeddings.py:2952)."""
+
+    def __init__(self, vocab_size=250002, hidden_size=1024, num_hidden_layers=24, num_attention_heads=16,
+                 intermediate_size=4096, max_position_embeddings=514, type_vocab_size=1, pad_token_id=1,
+                 layer_norm_eps=1e-5):
+        self.vocab_size = vocab_size
+        self.hidden_size = hidden_size
+        self.num_hidden_layers = num_hidden_layers
+        self.num_attention_heads = num_attention_heads
+        self.intermediate_size = intermediate_size
+        self.max_position_embeddings = max_position_embeddings
+        self.type_vocab_size = type_vocab_size
+        self.pad_token_id = pad_token_id
+        self.layer_norm_eps = layer_norm_eps
+        if hidden_size != num_attention_heads * 64:
+            raise ValueError("kbner attention kernels need head_dim 64 (XLM-R base/large)")
+        if hidden_size % 128 or intermediate_size % 128:
+            raise ValueError("hidden/intermediate sizes must be multiples of 128")
+
+    @staticmethod
+    def large(**kw):
+        return EncoderConfig(**kw)
+
+    @staticmethod
+    def base(**kw):
+        return EncoderConfig(hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072, **kw)
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+class Arena:
+    """Flat fp32 parameter storage + grads + Adam state; tensors padded to 8 elements."""
+
+    def __init__(self, specs, device):
+        self.device = device
+        self.offsets = {}
+        self.shapes = {}
+        off = 0
+        self.n_shadow = 0
+        seen_plain = False
+        for name, shape, shadow in specs:
+            n = 1
+            for s in shape:
+                n *= s
+            if shadow:
+                assert not seen_plain, "shadowed (GEMM) tensors must come first"
+            else:
+                if not seen_plain:
+                    self.n_shadow = off
+                seen_plain = True
+            self.offsets[name] = off
+            self.shapes[name] = tuple(shape)
+            off += _round_up(n, 8)
+        if not seen_plain:
+            self.n_shadow = off
+        self.n = off
+        self.p = torch.zeros(self.n, dtype=F32, device=device)
+        self.g = torch.zeros(self.n, dtype=F32, device=device)
+        self.m = None
+        self.v = None
+        self.shadow = torch.zeros(max(self.n_shadow, 8), dtype=BF16, device=device)
+
+    def _view(self, buf, name):
+        off, shape = self.offsets[name], self.shapes[name]
+        n = 1
+        for s in shape:
+            n *= s
+        return buf[off:off + n].view(shape)
+
+    def param(self, name):
+        return self._view(self.p, name)
+
+    def grad(self, name):
+        return self._view(self.g, name)
+
+    def bf(self, name):
+        assert self.offsets[name] < self.n_shadow
+        return self._view(self.shadow, name)
+
+    def refresh_shadow(self):
+        if self.n_shadow:
+            ops.f32_to_bf16(self.p[:self.n_shadow], self.shadow[:self.n_shadow])
+
+    def ensure_state(self):
+        if self.m is None:
+            self.m = torch.zeros_like(self.p)
+            self.v = torch.zeros_like(self.p)
+
+
+def tagger_specs(cfg, T):
+    """Arena order: GEMM weights (bf16-shadowed) | embeddings, LN, biases, head | transitions (own lr group,
+    flair/trainers/finetune_trainer.py:552-571)."""
+    H, F_, V, P, TV = cfg.hidden_size, cfg.intermediate_size, cfg.vocab_size, cfg.max_position_embeddings, cfg.type_vocab_size
+    specs = []
+    for i in range(cfg.num_hidden_layers):
+        specs += [("l%d.qkv.weight" % i, (3 * H, H), True), ("l%d.o.weight" % i, (H, H), True),
+                  ("l%d.ffn1.weight" % i, (F_, H), True), ("l%d.ffn2.weight" % i, (H, F_), True)]
+    specs += [("emb.word", (V, H), False), ("emb.pos", (P, H), False), ("emb.type", (TV, H), False),
+              ("emb.ln.g", (H,), False), ("emb.ln.b", (H,), False)]
+    for i in range(cfg.num_hidden_layers):
+        specs += [("l%d.qkv.bias" % i, (3 * H,), False), ("l%d.o.bias" % i, (H,), False),
+                  ("l%d.ln1.g" % i, (H,), False), ("l%d.ln1.b" % i, (H,), False),
+                  ("l%d.ffn1.bias" % i, (F_,), False), ("l%d.ffn2.bias" % i, (H,), False),
+                  ("l%d.ln2.g" % i, (H,), False), ("l%d.ln2.b" % i, (H,), False)]
+    specs += [("linear.weight", (T, H), False), ("linear.bias", (T,), False), ("transitions", (T, T), False)]
+    return specs
+
+
+# HF state_dict name <-> arena name (+ row slice for the fused qkv)
+def hf_name_map(cfg):
+    H = cfg.hidden_size
+    m = {
+        "embeddings.word_embeddings.weight": ("emb.word", None),
+        "embeddings.position_embeddings.weight": ("emb.pos", None),
+        "embeddings.token_type_embeddings.weight": ("emb.type", None),
+        "embeddings.LayerNorm.weight": ("emb.ln.g", None),
+        "embeddings.LayerNorm.bias": ("emb.ln.b", None),
+    }
+    for i in range(cfg.num_hidden_layers):
+        p = "encoder.layer.%d." % i
+        for j, nm in enumerate(("query", "key", "value")):
+            m[p + "attention.self.%s.weight" % nm] = ("l%d.qkv.weight" % i, (j * H, (j + 1) * H))
+            m[p + "attention.self.%s.bias" % nm] = ("l%d.qkv.bias" % i, (j * H, (j + 1) * H))
+        m[p + "attention.output.dense.weight"] = ("l%d.o.weight" % i, None)
+        m[p + "attention.output.dense.bias"] = ("l%d.o.bias" % i, None)
+        m[p + "attention.output.LayerNorm.weight"] = ("l%d.ln1.g" % i, None)
+        m[p + "attention.output.LayerNorm.bias"] = ("l%d.ln1.b" % i, None)
+        m[p + "intermediate.dense.weight"] = ("l%d.ffn1.weight" % i, None)
+        m[p + "intermediate.dense.bias"] = ("l%d.ffn1.bias" % i, None)
+        m[p + "output.dense.weight"] = ("l%d.ffn2.weight" % i, None)
+        m[p + "output.dense.bias"] = ("l%d.ffn2.bias" % i, None)
+        m[p + "output.LayerNorm.weight"] = ("l%d.ln2.g" % i, None)
+        m[p + "output.LayerNorm.bias"] = ("l%d.ln2.b" % i, None)
+    return m
+
+
+class _Acts:
+    """Activation / workspace buffers for one (B, S) shape; zero-initialised so the 128-row padding
+    tail never feeds NaNs into a wgrad reduction."""
+
+    def __init__(self, cfg, B, S, device):
+        H, F_, A, L = cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads, cfg.num_hidden_layers
+        self.B, self.S, self.M = B, S, B * S
+        self.Mp = Mp = _round_up(B * S, 128)
+        z = lambda *shape, dt=BF16: torch.zeros(shape, dtype=dt, device=device)  # noqa: E731
+        self.h0 = z(Mp, H)
+        self.emb_mean, self.emb_rstd = z(Mp, dt=F32), z(Mp, dt=F32)
+        self.x = [z(Mp, H) for _ in range(L + 1)]
+        self.qkv = [z(Mp, 3 * H) for _ in range(L)]
+        self.ctx = [z(Mp, H) for _ in range(L)]
+        self.lse = [z(B, A, S, dt=F32) for _ in range(L)]
+        self.h1 = [z(Mp, H) for _ in range(L)]
+        self.x1 = [z(Mp, H) for _ in range(L)]
+        self.pre = [z(Mp, F_) for _ in range(L)]
+        self.act = [z(Mp, F_) for _ in range(L)]
+        self.h2 = [z(Mp, H) for _ in range(L)]
+        self.st1 = [(z(Mp, dt=F32), z(Mp, dt=F32)) for _ in range(L)]
+        self.st2 = [(z(Mp, dt=F32), z(Mp, dt=F32)) for _ in range(L)]
+        # backward workspaces (shared across layers)
+        self.dx = z(Mp, H)
+        self.dh = z(Mp, H)
+        self.dx1 = z(Mp, H)
+        self.dh1 = z(Mp, H)
+        self.dpre = z(Mp, F_)
+        self.dctx = z(Mp, H)
+        self.dqkv = z(Mp, 3 * H)
+        self.dws = z(B, A, S, dt=F32)
+
+
+def _splitk(tiles, Mp):
+    """split the token (reduction) dimension of a wgrad GEMM so the launch has >= ~768 workgroups"""
+    sk = 1
+    while tiles * sk < 768 and Mp % (64 * sk * 2) == 0 and sk < 64:
+        sk *= 2
+    return sk
+
+
+class Tagger:
+    """XLM-R encoder + linear emission head + CRF, parameters in one Arena.
+
+    Reference path: TransformerWordEmbeddings (flair/embeddings.py:2906) -> FastSequenceTagger.forward /
+    forward_loss / _calculate_loss (flair/models/sequence_tagger_model.py:844,1899,2426)."""
+
+    def __init__(self, cfg, num_tags, start_idx, stop_idx, device="cuda"):
+        self.cfg, self.T, self.start, self.stop = cfg, num_tags, start_idx, stop_idx
+        self.device = torch.device(device)
+        self.arena = Arena(tagger_specs(cfg, num_tags), self.device)
+        self._acts = {}
+        self._saved = None
+
+    # ---------------------------------------------------------------- parameters
+    def init_random(self, seed=20220711, std=0.02):
+        """HF-style random init (N(0,0.02) matrices/embeddings, zero biases, unit LN gains, zero pad rows);
+        linear head as torch.nn.Linear default; transitions as sequence_tagger_model.py:402-410."""
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        a, cfg = self.arena, self.cfg
+        for name, shape in a.shapes.items():
+            dst = a.param(name)
+            if name.endswith("ln.g") or name.endswith("ln1.g") or name.endswith("ln2.g"):
+                dst.fill_(1.0)
+            elif name.endswith(".bias") or name.endswith("ln.b") or name.endswith("ln1.b") or name.endswith("ln2.b"):
+                dst.zero_()
+            elif name == "transitions":
+                t = torch.randn(shape, generator=g)
+                t[self.start, :] = -1e12
+                t[:, self.stop] = -1e12
+                dst.copy_(t)
+            elif name == "linear.weight":
+                bound = 1.0 / math.sqrt(shape[1])
+                dst.copy_((torch.rand(shape, generator=g) * 2 - 1) * bound)
+            else:
+                # generate in chunks to bound host memory for the 250k x 1024 table
+                rows = shape[0]
+                step = max(1, (1 << 24) // max(1, shape[1] if len(shape) > 1 else 1))
+                for r0 in range(0, rows, step):
+                    r1 = min(rows, r0 + step)
+                    blk = torch.empty((r1 - r0,) + tuple(shape[1:])).normal_(0.0, std, generator=g)
+                    dst[r0:r1].copy_(blk)
+        a.param("emb.word")[cfg.pad_token_id].zero_()
+        a.param("emb.pos")[cfg.pad_token_id].zero_()
+        a.refresh_shadow()
+
+    def load_hf_state_dict(self, sd, prefix=""):
+        """Load encoder weights given under HF names (e.g. from XLMRobertaModel.state_dict())."""
+        nm = hf_name_map(self.cfg)
+        for hf, (mine, sl) in nm.items():
+            t = sd[prefix + hf].to(device=self.device, dtype=F32)
+            dst = self.arena.param(mine)
+            if sl is not None:
+                dst = dst[sl[0]:sl[1]]
+            dst.copy_(t)
+        self.arena.refresh_shadow()
+
+    def hf_state_dict(self):
+        out = {}
+        for hf, (mine, sl) in hf_name_map(self.cfg).items():
+            t = self.arena.param(mine)
+            out[hf] = (t[sl[0]:sl[1]] if sl is not None else t).detach().clone()
+        return out
+
+    def set_param(self, name, value):
+        self.arena.param(name).copy_(torch.as_tensor(value).to(device=self.device, dtype=F32))
+        if self.arena.offsets[name] < self.arena.n_shadow:
+            self.arena.refresh_shadow()
+
+    def acts(self, B, S):
+        key = (B, S)
+        if key not in self._acts:
+            if len(self._acts) >= 2:  # bound resident activation sets
+                self._acts.pop(next(iter(self._acts)))
+            self._acts[key] = _Acts(self.cfg, B, S, self.device)
+        return self._acts[key]
+
+    # ---------------------------------------------------------------- encoder
+    def encoder_forward(self, ids, pos_ids, maskbias, B, S):
+        """ids/pos_ids i32[Mp], maskbias f32[B,S] -> last hidden state bf16 [Mp,H] (rows >= B*S are padding)."""
+        cfg, a = self.cfg, self.arena
+        H, F_, A, L = cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads, cfg.num_hidden_layers
+        ac = self.acts(B, S)
+        Mp = ac.Mp
+        eps = cfg.layer_norm_eps
+        ops.embed_ln_fwd(ids, pos_ids, a.param("emb.word"), a.param("emb.pos"), a.param("emb.type")[0], a.param("emb.ln.g"),
+                         a.param("emb.ln.b"), eps, ac.h0, ac.x[0], ac.emb_mean, ac.emb_rstd)
+        for l in range(L):
+            p = "l%d." % l
+            x = ac.x[l]
+            ops.gemm(GEMM_NT, x, a.bf(p + "qkv.weight"), Mp, 3 * H, H, C=ac.qkv[l], bias=a.param(p + "qkv.bias"), epi=EPI_BIAS)
+            ops.attn_fwd(ac.qkv[l], maskbias, ac.ctx[l], ac.lse[l], B, S, H, A)
+            ops.gemm(GEMM_NT, ac.ctx[l], a.bf(p + "o.weight"), Mp, H, H, C=ac.h1[l], bias=a.param(p + "o.bias"), addend=x,
+                     epi=EPI_BIAS | EPI_ADD)
+            ops.ln_fwd(ac.h1[l], a.param(p + "ln1.g"), a.param(p + "ln1.b"), eps, ac.x1[l], ac.st1[l][0], ac.st1[l][1])
+            ops.gemm(GEMM_NT, ac.x1[l], a.bf(p + "ffn1.weight"), Mp, F_, H, C=ac.act[l], out2=ac.pre[l],
+                     bias=a.param(p + "ffn1.bias"), epi=EPI_BIAS | EPI_GELU)
+            ops.gemm(GEMM_NT, ac.act[l], a.bf(p + "ffn2.weight"), Mp, H, F_, C=ac.h2[l], bias=a.param(p + "ffn2.bias"),
+                     addend=ac.x1[l], epi=EPI_BIAS | EPI_ADD)
+            ops.ln_fwd(ac.h2[l], a.param(p + "ln2.g"), a.param(p + "ln2.b"), eps, ac.x[l + 1], ac.st2[l][0], ac.st2[l][1])
+        self._enc_saved = (ids, pos_ids, maskbias, B, S)
+        return ac.x[L]
+
+    def encoder_backward(self, dx_top):
+        """dx_top bf16 [Mp,H] = d loss / d last hidden state; accumulates into arena.g."""
+        cfg, a = self.cfg, self.arena
+        H, F_, A, L = cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads, cfg.num_hidden_layers
+        ids, pos_ids, maskbias, B, S = self._enc_saved
+        ac = self.acts(B, S)
+        Mp = ac.Mp
+        dx = dx_top
+        for l in range(L - 1, -1, -1):
+            p = "l%d." % l
+            # LN2 backward; fused: d ffn2.bias = column sums of dh
+            ops.ln_bwd(dx, ac.h2[l], ac.st2[l][0], ac.st2[l][1], a.param(p + "ln2.g"), ac.dh, a.grad(p + "ln2.g"),
+                       a.grad(p + "ln2.b"), a.grad(p + "ffn2.bias"))
+            # FFN down: wgrad dW2[H,F] += dh^T act ; dgrad dpre = (dh W2) * gelu'(pre)
+            ops.gemm(GEMM_TN, ac.dh, ac.act[l], H, F_, Mp, C32=a.grad(p + "ffn2.weight"), epi=EPI_ATOMIC32,
+                     splitk=_splitk((H // 128) * (F_ // 128), Mp))
+            ops.gemm(GEMM_NN, ac.dh, a.bf(p + "ffn2.weight"), Mp, F_, H, C=ac.dpre, aux=ac.pre[l], epi=EPI_DGELU)
+            # FFN up
+            ops.colsum(ac.dpre, a.grad(p + "ffn1.bias"))
+            ops.gemm(GEMM_TN, ac.dpre, ac.x1[l], F_, H, Mp, C32=a.grad(p + "ffn1.weight"), epi=EPI_ATOMIC32,
+                     splitk=_splitk((F_ // 128) * (H // 128), Mp))
+            ops.gemm(GEMM_NN, ac.dpre, a.bf(p + "ffn1.weight"), Mp, H, F_, C=ac.dx1, addend=ac.dh, epi=EPI_ADD)
+            # LN1 backward; fused: d o.bias
+            ops.ln_bwd(ac.dx1, ac.h1[l], ac.st1[l][0], ac.st1[l][1], a.param(p + "ln1.g"), ac.dh1, a.grad(p + "ln1.g"),
+                       a.grad(p + "ln1.b"), a.grad(p + "o.bias"))
+            # attention output projection
+            ops.gemm(GEMM_TN, ac.dh1, ac.ctx[l], H, H, Mp, C32=a.grad(p + "o.weight"), epi=EPI_ATOMIC32,
+                     splitk=_splitk((H // 128) * (H // 128), Mp))
+            ops.gemm(GEMM_NN, ac.dh1, a.bf(p + "o.weight"), Mp, H, H, C=ac.dctx)
+            # attention core
+            ops.attn_bwd(ac.qkv[l], ac.ctx[l], ac.dctx, maskbias, ac.lse[l], ac.dws, ac.dqkv, B, S, H, A)
+            # QKV projection
+            ops.colsum(ac.dqkv, a.grad(p + "qkv.bias"))
+            ops.gemm(GEMM_TN, ac.dqkv, ac.x[l], 3 * H, H, Mp, C32=a.grad(p + "qkv.weight"), epi=EPI_ATOMIC32,
+                     splitk=_splitk((3 * H // 128) * (H // 128), Mp))
+            ops.gemm(GEMM_NN, ac.dqkv, a.bf(p + "qkv.weight"), Mp, H, 3 * H, C=ac.dx, addend=ac.dh1, epi=EPI_ADD)
+            dx = ac.dx
+        ops.embed_ln_bwd(dx, ac.h0, ac.emb_mean, ac.emb_rstd, a.param("emb.ln.g"), ids, pos_ids, a.grad("emb.ln.g"),
+                         a.grad("emb.ln.b"), a.grad("emb.word"), a.grad("emb.pos"), a.grad("emb.type")[0])
+
+    # ---------------------------------------------------------------- tagger head
+    def emissions(self, hidden, row_idx, B, n):
+        """gather rows (first sub-token of each word token, -1 -> zeros) then the linear head.
+        -> (features f32 [B,n,T], pooled bf16 [B*n,H])"""
+        pooled = ops.gather_rows(hidden, row_idx)
+        em = ops.head_fwd(pooled, self.arena.param("linear.weight"), self.arena.param("linear.bias"))
+        return em.view(B, n, self.T), pooled
+
+    def forward_loss(self, batch, loss_scale=1.0, backward=True):
+        """One micro-batch: encoder -> kept-token gather -> head -> CRF NLL (mean over sentences,
+        sequence_tagger_model.py:2499-2506) and, if `backward`, the full backward pass accumulating
+        loss_scale * d loss into arena.g.  Returns the loss as a 0-d device tensor (no host sync)."""
+        B, S = batch["B"], batch["S"]
+        hidden = self.encoder_forward(batch["ids"], batch["pos_ids"], batch["maskbias"], B, S)
+        nc = batch["ctags"].shape[1]
+        em, pooled = self.emissions(hidden, batch["crow_idx"], B, nc)
+        a = self.arena
+        trans = a.param("transitions")
+        logz, gold, alpha = ops.crf_nll_fwd(em, trans, batch["ctags"], batch["clens"], self.start, self.stop)
+        w = torch.full((B,), 1.0 / B, dtype=F32, device=self.device)
+        loss = torch.empty((1,), dtype=F32, device=self.device)
+        ops.wdiff_sum(logz, gold, w, loss)
+        if backward:
+            dl = w * loss_scale
+            demit = ops.crf_nll_bwd(em, trans, batch["ctags"], batch["clens"], alpha, logz, dl, self.start, self.stop,
+                                    a.grad("transitions"))
+            dpooled = ops.head_bwd(demit.view(B * nc, self.T), pooled, a.param("linear.weight"), a.grad("linear.weight"),
+                                   a.grad("linear.bias"))
+            ac = self.acts(B, S)
+            ac.dx.zero_()
+            ops.scatter_rows(dpooled, batch["crow_idx"], ac.dx)
+            self.encoder_backward(ac.dx)
+        return loss[0]
+
+    def forward_features(self, batch):
+        """FastSequenceTagger.forward (sequence_tagger_model.py:844): emissions for ALL word tokens."""
+        B, S = batch["B"], batch["S"]
+        hidden = self.encoder_forward(batch["ids"], batch["pos_ids"], batch["maskbias"], B, S)
+        n = batch["row_idx"].numel() // B
+        em, _ = self.emissions(hidden, batch["row_idx"], B, n)
+        return em
+
+    def viterbi(self, emissions, lens):
+        return ops.crf_viterbi(emissions.contiguous(), self.arena.param("transitions"), lens, self.start, self.stop)
+
+
+class FusedAdamW:
+    """HF AdamW (eps 1e-6, wd 0, correct_bias) + clip_grad_norm_(5.0) + linear decay, two lr groups
+    (transitions at lr * lr_rate) -- flair/trainers/finetune_trainer.py:552-571,686-688,1010-1023."""
+
+    def __init__(self, arena, lr=5e-6, lr_rate=10000.0, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, max_norm=5.0,
+                 t_total=None, warmup=0):
+        self.arena = arena
+        self.lr, self.lr_rate, self.betas, self.eps, self.wd = lr, lr_rate, betas, eps, weight_decay
+        self.max_norm, self.t_total, self.warmup = max_norm, t_total, warmup
+        self.t = 0
+        arena.ensure_state()
+        from . import lib as L
+        self.ws = torch.zeros(L.load().kbner_sqnorm_ws_floats(), dtype=F32, device=arena.device)
+        self.norm_sq = torch.zeros(1, dtype=F32, device=arena.device)
+        self.split = arena.offsets["transitions"]
+
+    def lr_lambda(self):
+        if self.t_total is None:
+            return 1.0
+        if self.t < self.warmup:
+            return float(self.t) / float(max(1, self.warmup))
+        return max(0.0, float(self.t_total - self.t) / float(max(1, self.t_total - self.warmup)))
+
+    def step(self, grad_scale=1.0):
+        a = self.arena
+        lam = self.lr_lambda()
+        self.t += 1
+        b1, b2 = self.betas
+        bc = math.sqrt(1.0 - b2 ** self.t) / (1.0 - b1 ** self.t)
+        ops.grad_sqnorm(a.g, self.ws, self.norm_sq)
+        s = self.split
+        for lo, hi, lr in ((0, s, self.lr * lam), (s, a.n, self.lr * self.lr_rate * lam)):
+            nsh = min(a.n_shadow, hi) - lo if lo < a.n_shadow else 0
+            ops.adamw(a.p[lo:hi], a.g[lo:hi], a.m[lo:hi], a.v[lo:hi], a.shadow[lo:] if nsh > 0 else None, max(nsh, 0),
+                      lr * bc, lr * self.wd, b1, b2, self.eps, self.norm_sq, self.max_norm, grad_scale, True)
+        return self.norm_sq

@@ -1,0 +1,95 @@
+"""ctypes binding of libkbner_hip.so (the C ABI declared in include/kbner.h).
+
+There is NO fallback: if the shared library is missing or a symbol is absent this module raises.
+torch is used only for device memory and streams (tensor.data_ptr(), current_stream().cuda_stream).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libkbner_hip.so")
+
+c_int, c_float, c_void_p, c_size_t = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
+P = c_void_p
+
+# name -> (restype, argtypes) ; must list EVERY symbol include/kbner.h declares
+SIGNATURES = {
+    "kbner_abi_version": (c_int, []),
+    "kbner_device_count": (c_int, []),
+    "kbner_crf_viterbi_lds_bytes": (c_size_t, [c_int, c_int]),
+    "kbner_crf_viterbi": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, P]),
+    "kbner_crf_nll_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, P]),
+    "kbner_crf_nll_bwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P]),
+    "kbner_gather_rows": (c_int, [P, P, P, c_int, c_int, P]),
+    "kbner_scatter_rows": (c_int, [P, P, P, c_int, c_int, P]),
+    "kbner_head_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
+    "kbner_head_bwd_dx": (c_int, [P, P, P, c_int, c_int, c_int, P]),
+    "kbner_head_bwd_dw": (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
+    "kbner_colsum": (c_int, [P, P, c_int, c_int, c_int, P]),
+    "kbner_ln_fwd": (c_int, [P, P, P, c_float, P, P, P, c_int, c_int, P]),
+    "kbner_ln_bwd": (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, P]),
+    "kbner_embed_ln_fwd": (c_int, [P, P, P, P, P, P, P, c_float, P, P, P, P, c_int, c_int, P]),
+    "kbner_embed_ln_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, P]),
+    "kbner_gemm_bf16": (c_int, [c_int, P, c_int, P, c_int, c_int, c_int, c_int, P, c_int, P, c_int, P, P, c_int, P, c_int,
+                                P, c_int, c_int, c_int, c_float, P]),
+    "kbner_attn_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "kbner_attn_bwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "kbner_sqnorm_ws_floats": (c_int, []),
+    "kbner_grad_sqnorm": (c_int, [P, c_size_t, P, P, c_int, P]),
+    "kbner_adamw_hf": (c_int, [P, P, P, P, P, c_size_t, c_size_t, c_float, c_float, c_float, c_float, c_float, P, c_float,
+                               c_float, c_int, P]),
+    "kbner_f32_to_bf16": (c_int, [P, P, c_size_t, P]),
+    "kbner_wdiff_sum": (c_int, [P, P, P, c_int, P, P]),
+    "kbner_probe_tr": (c_int, [P, P, P]),
+    "kbner_probe_mfma": (c_int, [P, P, P, P]),
+}
+
+GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
+EPI_BIAS, EPI_GELU, EPI_ADD, EPI_DGELU, EPI_ATOMIC32 = 1, 2, 4, 8, 16
+
+_lib = None
+
+
+class KbnerError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the library and bind every symbol; raises if the .so or a symbol is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise KbnerError("libkbner_hip.so not built: run `python __graft_entry__.py` (hipcc --offload-arch=gfx950). "
+                         "There is no CPU fallback for the product path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None -> NULL)."""
+    if t is None:
+        return None
+    return c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def check(rc, what):
+    if rc != 0:
+        raise KbnerError("%s failed with code %d" % (what, rc))
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise KbnerError("%s failed with code %d" % (name, rc))

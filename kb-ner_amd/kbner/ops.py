@@ -1,0 +1,171 @@
+"""Typed Python wrappers over the C ABI: argument checking + pointer marshalling, nothing else.
+Every function enqueues on torch's current HIP stream and returns immediately."""
+import torch
+
+from . import lib as L
+from .lib import ptr, stream_ptr
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+I32 = torch.int32
+
+
+def _chk(t, dtype, name):
+    if t.dtype != dtype or not t.is_cuda or not t.is_contiguous():
+        raise L.KbnerError("%s must be a contiguous cuda %s tensor (got %s, cuda=%s, contiguous=%s)"
+                           % (name, dtype, t.dtype, t.is_cuda, t.is_contiguous()))
+
+
+# ---------------------------------------------------------------- CRF
+def crf_viterbi(emit, trans, lens, start, stop, want_popped=False):
+    """emit f32[B,n,T], trans f32[T,T], lens i32[B] -> tags i32[B,n], conf f32[B,n] (, popped i32[B])"""
+    _chk(emit, F32, "emit"); _chk(trans, F32, "trans"); _chk(lens, I32, "lens")
+    B, n, T = emit.shape
+    tags = torch.empty((B, n), dtype=I32, device=emit.device)
+    conf = torch.empty((B, n), dtype=F32, device=emit.device)
+    popped = torch.empty((B,), dtype=I32, device=emit.device) if want_popped else None
+    L.call("kbner_crf_viterbi", ptr(emit), ptr(trans), ptr(lens), B, n, T, start, stop, ptr(tags), ptr(conf), ptr(popped),
+           stream_ptr())
+    return (tags, conf, popped) if want_popped else (tags, conf)
+
+
+def crf_nll_fwd(emit, trans, tags, lens, start, stop):
+    _chk(emit, F32, "emit"); _chk(trans, F32, "trans"); _chk(tags, I32, "tags"); _chk(lens, I32, "lens")
+    B, n, T = emit.shape
+    logz = torch.empty((B,), dtype=F32, device=emit.device)
+    gold = torch.empty((B,), dtype=F32, device=emit.device)
+    alpha = torch.empty((B, n + 1, T), dtype=F32, device=emit.device)
+    L.call("kbner_crf_nll_fwd", ptr(emit), ptr(trans), ptr(tags), ptr(lens), B, n, T, start, stop, ptr(logz), ptr(gold),
+           ptr(alpha), stream_ptr())
+    return logz, gold, alpha
+
+
+def crf_nll_bwd(emit, trans, tags, lens, alpha, logz, dloss, start, stop, dtrans):
+    """-> demit f32[B,n,T]; dtrans f32[T,T] is accumulated into (+=)."""
+    _chk(dloss, F32, "dloss"); _chk(dtrans, F32, "dtrans")
+    B, n, T = emit.shape
+    demit = torch.empty_like(emit)
+    L.call("kbner_crf_nll_bwd", ptr(emit), ptr(trans), ptr(tags), ptr(lens), ptr(alpha), ptr(logz), ptr(dloss), B, n, T, start,
+           stop, ptr(demit), ptr(dtrans), stream_ptr())
+    return demit
+
+
+# ---------------------------------------------------------------- rows / head
+def gather_rows(src, idx, out=None):
+    _chk(src, BF16, "src"); _chk(idx, I32, "idx")
+    R, H = idx.numel(), src.shape[-1]
+    if out is None:
+        out = torch.empty((R, H), dtype=BF16, device=src.device)
+    L.call("kbner_gather_rows", ptr(src), ptr(idx), ptr(out), R, H, stream_ptr())
+    return out
+
+
+def scatter_rows(dout, idx, dsrc):
+    _chk(dout, BF16, "dout"); _chk(idx, I32, "idx"); _chk(dsrc, BF16, "dsrc")
+    L.call("kbner_scatter_rows", ptr(dout), ptr(idx), ptr(dsrc), idx.numel(), dout.shape[-1], stream_ptr())
+
+
+def head_fwd(x, w, bias):
+    _chk(x, BF16, "x"); _chk(w, F32, "w"); _chk(bias, F32, "bias")
+    R, H = x.shape
+    T = w.shape[0]
+    out = torch.empty((R, T), dtype=F32, device=x.device)
+    L.call("kbner_head_fwd", ptr(x), ptr(w), ptr(bias), ptr(out), R, H, T, stream_ptr())
+    return out
+
+
+def head_bwd(de, x, w, dw, db):
+    """de f32[R,T] -> dx bf16[R,H]; dw f32[T,H], db f32[T] accumulated into."""
+    _chk(de, F32, "de"); _chk(x, BF16, "x"); _chk(w, F32, "w"); _chk(dw, F32, "dw"); _chk(db, F32, "db")
+    R, H = x.shape
+    T = w.shape[0]
+    dx = torch.empty((R, H), dtype=BF16, device=x.device)
+    L.call("kbner_head_bwd_dx", ptr(de), ptr(w), ptr(dx), R, H, T, stream_ptr())
+    L.call("kbner_head_bwd_dw", ptr(de), ptr(x), ptr(dw), ptr(db), R, H, T, stream_ptr())
+    return dx
+
+
+def colsum(x, out, M=None):
+    _chk(x, BF16, "x"); _chk(out, F32, "out")
+    rows, N = x.shape
+    L.call("kbner_colsum", ptr(x), ptr(out), rows if M is None else M, N, N, stream_ptr())
+
+
+# ---------------------------------------------------------------- LayerNorm / embeddings
+def ln_fwd(h, gamma, beta, eps, y, mean, rstd):
+    M, H = h.shape
+    L.call("kbner_ln_fwd", ptr(h), ptr(gamma), ptr(beta), eps, ptr(y), ptr(mean), ptr(rstd), M, H, stream_ptr())
+
+
+def ln_bwd(dy, h, mean, rstd, gamma, dh, dgamma, dbeta, dbias=None):
+    M, H = h.shape
+    L.call("kbner_ln_bwd", ptr(dy), ptr(h), ptr(mean), ptr(rstd), ptr(gamma), ptr(dh), ptr(dgamma), ptr(dbeta), ptr(dbias),
+           M, H, stream_ptr())
+
+
+def embed_ln_fwd(ids, pos_ids, word, pos, type0, gamma, beta, eps, h0, y, mean, rstd):
+    _chk(ids, I32, "ids"); _chk(pos_ids, I32, "pos_ids"); _chk(word, F32, "word")
+    M, H = ids.numel(), word.shape[1]
+    L.call("kbner_embed_ln_fwd", ptr(ids), ptr(pos_ids), ptr(word), ptr(pos), ptr(type0), ptr(gamma), ptr(beta), eps, ptr(h0),
+           ptr(y), ptr(mean), ptr(rstd), M, H, stream_ptr())
+
+
+def embed_ln_bwd(dy, h0, mean, rstd, gamma, ids, pos_ids, dgamma, dbeta, dword, dpos, dtype0):
+    M, H = ids.numel(), dword.shape[1]
+    L.call("kbner_embed_ln_bwd", ptr(dy), ptr(h0), ptr(mean), ptr(rstd), ptr(gamma), ptr(ids), ptr(pos_ids), ptr(dgamma),
+           ptr(dbeta), ptr(dword), ptr(dpos), ptr(dtype0), M, H, stream_ptr())
+
+
+# ---------------------------------------------------------------- GEMM
+GEMM_HOOK = None  # bench.py sets this to a list to time every GEMM launch with HIP events on the launch stream
+
+
+def gemm(layout, A, B, M, N, K, C=None, C32=None, bias=None, addend=None, aux=None, out2=None, epi=0, splitk=1, alpha=1.0,
+         lda=None, ldb=None):
+    """C[M,N] (bf16) or C32[M,N] += (fp32 atomics).  A/B are 2-D bf16 tensors in their memory layouts."""
+    _chk(A, BF16, "A"); _chk(B, BF16, "B")
+    lda = A.shape[1] if lda is None else lda
+    ldb = B.shape[1] if ldb is None else ldb
+    hook = GEMM_HOOK
+    if hook is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    L.call("kbner_gemm_bf16", layout, ptr(A), lda, ptr(B), ldb, M, N, K,
+           ptr(C), C.shape[1] if C is not None else 0,
+           ptr(C32), C32.shape[1] if C32 is not None else 0,
+           ptr(bias), ptr(addend), addend.shape[1] if addend is not None else 0,
+           ptr(aux), aux.shape[1] if aux is not None else 0,
+           ptr(out2), out2.shape[1] if out2 is not None else 0,
+           epi, splitk, alpha, stream_ptr())
+    if hook is not None:
+        ev1.record()
+        hook.append((ev0, ev1, 2.0 * M * N * K, layout))
+
+
+# ---------------------------------------------------------------- attention
+def attn_fwd(qkv, maskbias, ctx, lse, B, S, H, A):
+    L.call("kbner_attn_fwd", ptr(qkv), ptr(maskbias), ptr(ctx), ptr(lse), B, S, H, A, stream_ptr())
+
+
+def attn_bwd(qkv, ctx, dctx, maskbias, lse, dws, dqkv, B, S, H, A):
+    L.call("kbner_attn_bwd", ptr(qkv), ptr(ctx), ptr(dctx), ptr(maskbias), ptr(lse), ptr(dws), ptr(dqkv), B, S, H, A,
+           stream_ptr())
+
+
+# ---------------------------------------------------------------- optimiser
+def grad_sqnorm(g, ws, out, accumulate=False):
+    _chk(g, F32, "g")
+    L.call("kbner_grad_sqnorm", ptr(g), g.numel(), ptr(ws), ptr(out), 1 if accumulate else 0, stream_ptr())
+
+
+def adamw(p, g, m, v, shadow, n_shadow, step_size, lr_wd, b1, b2, eps, gnorm_sq, max_norm, grad_scale, zero_grad=True):
+    L.call("kbner_adamw_hf", ptr(p), ptr(g), ptr(m), ptr(v), ptr(shadow), p.numel(), n_shadow, step_size, lr_wd, b1, b2, eps,
+           ptr(gnorm_sq), max_norm, grad_scale, 1 if zero_grad else 0, stream_ptr())
+
+
+def f32_to_bf16(x, y):
+    L.call("kbner_f32_to_bf16", ptr(x), ptr(y), x.numel(), stream_ptr())
+
+
+def wdiff_sum(a, b, w, out):
+    L.call("kbner_wdiff_sum", ptr(a), ptr(b), ptr(w), a.numel(), ptr(out), stream_ptr())

@@ -1,0 +1,345 @@
+"""GPU self-checks of the HIP path against the oracle (oracle/ is imported HERE only as the checker:
+this module is used by tests/, __graft_entry__.smoke() and tools/gpu_diag.py -- never by the product path)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+from . import batch as kb
+from . import engine, ops
+from .lib import EPI_ADD, EPI_ATOMIC32, EPI_BIAS, EPI_DGELU, EPI_GELU, GEMM_NN, GEMM_NT, GEMM_TN
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+BF16, F32, I32 = torch.bfloat16, torch.float32, torch.int32
+DEV = "cuda"
+
+
+def rel_l2(a, b):
+    a = a.double().flatten()
+    b = b.double().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def cosine(a, b):
+    a = a.double().flatten()
+    b = b.double().flatten()
+    return float((a @ b) / (a.norm() * b.norm() + 1e-30))
+
+
+# ------------------------------------------------------------------ probes
+def probe_tr():
+    from . import lib as L
+    inp = torch.arange(2048, dtype=torch.int16, device=DEV)
+    out = torch.zeros(256, dtype=torch.int16, device=DEV)
+    L.call("kbner_probe_tr", L.ptr(inp), L.ptr(out), L.stream_ptr())
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().reshape(64, 4)
+    exp = np.zeros((64, 4), np.int16)
+    for lane in range(64):
+        g, i = lane >> 4, lane & 15
+        for j in range(4):
+            exp[lane, j] = (4 * g + j) * 64 + i
+    return got, exp
+
+
+def probe_mfma():
+    from . import lib as L
+    g = torch.Generator(device="cpu").manual_seed(3)
+    a = torch.randn(16, 32, generator=g).to(BF16)
+    b = torch.randn(16, 32, generator=g).to(BF16)
+    c = torch.zeros(16, 16, dtype=F32, device=DEV)
+    ad, bd = a.to(DEV), b.to(DEV)
+    L.call("kbner_probe_mfma", L.ptr(ad), L.ptr(bd), L.ptr(c), L.stream_ptr())
+    torch.cuda.synchronize()
+    ref = a.float() @ b.float().t()
+    return c.cpu(), ref
+
+
+# ------------------------------------------------------------------ GEMM
+def check_gemm(layout, M, N, K, epi=0, splitk=1, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    A = (torch.randn(M, K, generator=g) * 0.5).to(BF16)
+    Bm = (torch.randn(N, K, generator=g) * 0.5).to(BF16)
+    ref = A.double() @ Bm.double().t()
+    bias = torch.randn(N, generator=g)
+    add = (torch.randn(M, N, generator=g)).to(BF16)
+    aux = (torch.randn(M, N, generator=g)).to(BF16)
+    Ad = A.to(DEV) if layout != GEMM_TN else A.t().contiguous().to(DEV)
+    Bd = Bm.to(DEV) if layout == GEMM_NT else Bm.t().contiguous().to(DEV)
+    kw = {}
+    if epi & EPI_BIAS:
+        ref = ref + bias.double()[None, :]
+        kw["bias"] = bias.to(DEV)
+    if epi & EPI_ADD:
+        ref = ref + add.double()
+        kw["addend"] = add.to(DEV)
+    if epi & EPI_DGELU:
+        x = aux.double()
+        cdf = 0.5 * (1 + torch.erf(x / np.sqrt(2.0)))
+        pdf = torch.exp(-0.5 * x * x) / np.sqrt(2 * np.pi)
+        ref = ref * (cdf + x * pdf)
+        kw["aux"] = aux.to(DEV)
+    out2 = None
+    if epi & EPI_GELU:
+        out2 = torch.zeros(M, N, dtype=BF16, device=DEV)
+        kw["out2"] = out2
+        pre = ref.float().to(BF16).double()
+        ref_pre = ref
+        ref = torch.nn.functional.gelu(pre)
+    if epi & EPI_ATOMIC32:
+        C32 = torch.full((M, N), 1.0, dtype=F32, device=DEV)
+        ops.gemm(layout, Ad, Bd, M, N, K, C32=C32, epi=epi, splitk=splitk, **kw)
+        torch.cuda.synchronize()
+        return rel_l2(C32.cpu() - 1.0, ref)
+    C = torch.zeros(M, N, dtype=BF16, device=DEV)
+    ops.gemm(layout, Ad, Bd, M, N, K, C=C, epi=epi, splitk=splitk, **kw)
+    torch.cuda.synchronize()
+    err = rel_l2(C.cpu().float(), ref)
+    if out2 is not None:
+        err = max(err, rel_l2(out2.cpu().float(), ref_pre))
+    return err
+
+
+# ------------------------------------------------------------------ attention
+def attn_reference(qkv, maskbias, B, S, H, A, dctx=None):
+    d = H // A
+    x = qkv.detach().double().clone().requires_grad_(dctx is not None)
+    q, k, v = x[:, :H], x[:, H:2 * H], x[:, 2 * H:]
+    sp = lambda t: t.reshape(B, S, A, d).transpose(1, 2)  # noqa: E731
+    sc = sp(q) @ sp(k).transpose(-1, -2) / np.sqrt(d) + maskbias.double()[:, None, None, :]
+    pr = torch.softmax(sc, dim=-1)
+    ctx = (pr @ sp(v)).transpose(1, 2).reshape(B * S, H)
+    lse = torch.logsumexp(sc, dim=-1)
+    if dctx is None:
+        return ctx, lse, None
+    ctx.backward(dctx.double())
+    return ctx.detach(), lse.detach(), x.grad
+
+
+def check_attention(B, S, A, seed=0, ragged=True):
+    H = A * 64
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    qkv = (torch.randn(B * S, 3 * H, generator=g)).to(BF16)
+    dctx = (torch.randn(B * S, H, generator=g)).to(BF16)
+    am = torch.ones(B, S)
+    if ragged:
+        for b in range(B):
+            am[b, S - 7 * b - (5 if b else 0):] = 0 if b else 1
+    mb = ((1 - am) * -10000.0).float()
+    ctx_ref, lse_ref, dqkv_ref = attn_reference(qkv.float(), mb, B, S, H, A, dctx.float())
+    qd, dd, mbd = qkv.to(DEV), dctx.to(DEV), mb.to(DEV)
+    ctx = torch.zeros(B * S, H, dtype=BF16, device=DEV)
+    lse = torch.zeros(B, A, S, dtype=F32, device=DEV)
+    ops.attn_fwd(qd, mbd, ctx, lse, B, S, H, A)
+    dws = torch.zeros(B, A, S, dtype=F32, device=DEV)
+    dqkv = torch.zeros(B * S, 3 * H, dtype=BF16, device=DEV)
+    ops.attn_bwd(qd, ctx, dd, mbd, lse, dws, dqkv, B, S, H, A)
+    torch.cuda.synchronize()
+    dq = dqkv.cpu().float()
+    return {
+        "ctx": rel_l2(ctx.cpu().float(), ctx_ref),
+        "lse": float((lse.cpu().double() - lse_ref).abs().max()),
+        "dq": rel_l2(dq[:, :H], dqkv_ref[:, :H]),
+        "dk": rel_l2(dq[:, H:2 * H], dqkv_ref[:, H:2 * H]),
+        "dv": rel_l2(dq[:, 2 * H:], dqkv_ref[:, 2 * H:]),
+    }
+
+
+# ------------------------------------------------------------------ LayerNorm
+def check_layernorm(M, H, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    h = (torch.randn(M, H, generator=g) * 2 + 0.3).to(BF16)
+    dy = torch.randn(M, H, generator=g).to(BF16)
+    gamma = torch.randn(H, generator=g) * 0.2 + 1.0
+    beta = torch.randn(H, generator=g) * 0.1
+    hr = h.double().clone().requires_grad_(True)
+    gr = gamma.double().clone().requires_grad_(True)
+    br = beta.double().clone().requires_grad_(True)
+    y_ref = torch.nn.functional.layer_norm(hr, (H,), gr, br, 1e-5)
+    y_ref.backward(dy.double())
+    hd, dyd = h.to(DEV), dy.to(DEV)
+    gd, bd = gamma.to(DEV), beta.to(DEV)
+    y = torch.zeros(M, H, dtype=BF16, device=DEV)
+    mean = torch.zeros(M, dtype=F32, device=DEV)
+    rstd = torch.zeros(M, dtype=F32, device=DEV)
+    ops.ln_fwd(hd, gd, bd, 1e-5, y, mean, rstd)
+    dh = torch.zeros(M, H, dtype=BF16, device=DEV)
+    dg = torch.zeros(H, dtype=F32, device=DEV)
+    db = torch.zeros(H, dtype=F32, device=DEV)
+    dbias = torch.zeros(H, dtype=F32, device=DEV)
+    ops.ln_bwd(dyd, hd, mean, rstd, gd, dh, dg, db, dbias)
+    torch.cuda.synchronize()
+    return {
+        "y": rel_l2(y.cpu().float(), y_ref.detach()),
+        "dh": rel_l2(dh.cpu().float(), hr.grad),
+        "dgamma": rel_l2(dg.cpu(), gr.grad),
+        "dbeta": rel_l2(db.cpu(), br.grad),
+        "dbias": rel_l2(dbias.cpu(), hr.grad.sum(0)),
+    }
+
+
+# ------------------------------------------------------------------ CRF
+def check_crf(B, n, T=29, start=27, stop=28, seed=0):
+    from oracle import crf as ocrf
+    rng = np.random.default_rng(seed)
+    trans = ocrf.init_transitions(T, start, stop, rng)
+    feats = (rng.standard_normal((B, n, T)) * 2).astype(np.float32)
+    lens = rng.integers(0 if B > 2 else 1, n + 1, size=B).astype(np.int32)
+    lens[0] = n
+    valid = [t for t in range(T) if t not in (start, stop)]
+    tags = rng.choice(valid, size=(B, n)).astype(np.int32)
+    fd, td = torch.from_numpy(feats).to(DEV), torch.from_numpy(trans).to(DEV)
+    ld, tgd = torch.from_numpy(lens).to(DEV), torch.from_numpy(tags).to(DEV)
+    vt, vc, popped = ops.crf_viterbi(fd, td, ld, start, stop, want_popped=True)
+    logz, gold, alpha = ops.crf_nll_fwd(fd, td, tgd, ld, start, stop)
+    dl = torch.full((B,), 1.0 / B, dtype=F32, device=DEV)
+    dtr = torch.zeros(T, T, dtype=F32, device=DEV)
+    demit = ops.crf_nll_bwd(fd, td, tgd, ld, alpha, logz, dl, start, stop, dtr)
+    torch.cuda.synchronize()
+    rt, rc = ocrf.viterbi_batch(feats, lens, trans, start, stop)
+    rz = ocrf.forward_alg(feats, lens, trans, start, stop)
+    rg = ocrf.score_sentence(feats, tags, lens, trans, start, stop)
+    dfe, dtrr = ocrf.crf_nll_grads(feats, tags, lens, trans, start, stop, dloss=np.full(B, 1.0 / B))
+    for b in range(B):
+        dfe[b, lens[b]:] = 0
+    return {
+        "tags_equal": bool(np.array_equal(vt.cpu().numpy(), rt)),
+        "popped_ok": bool(np.all(popped.cpu().numpy() == start)),
+        "conf": float(np.abs(vc.cpu().numpy() - rc).max()),
+        "logz": float(np.abs(logz.cpu().numpy() - rz).max() / (np.abs(rz).max() + 1e-9)),
+        "gold": float(np.abs(gold.cpu().numpy() - rg).max() / (np.abs(rg).max() + 1e-9)),
+        "demit": float(np.abs(demit.cpu().numpy() - dfe).max()),
+        "dtrans": float(np.abs(dtr.cpu().numpy() - dtrr).max()),
+    }
+
+
+# ------------------------------------------------------------------ end-to-end tiny tagger step
+def tiny_setup(B=2, S=64, L=2, H=128, A=2, F_=256, V=512, T=29, seed=5):
+    cfg = engine.EncoderConfig(vocab_size=V, hidden_size=H, num_hidden_layers=L, num_attention_heads=A,
+                               intermediate_size=F_, max_position_embeddings=S + 2)
+    start, stop, x_idx = 27, 28, 9
+    tg = engine.Tagger(cfg, T, start, stop, device=DEV)
+    tg.init_random(seed=seed, std=0.08)
+    b = kb.synthetic_batch(B, S, vocab=V, T=T, x_idx=x_idx, start=start, stop=stop, n_real=6, seed=seed)
+    # make it ragged: second sentence shorter
+    if B > 1:
+        ids, am = b["input_ids"].copy(), b["attention_mask"].copy()
+        cut = S - 9
+        ids[1, cut - 1] = 2
+        ids[1, cut:] = 0
+        am[1, cut:] = 0
+        fi = b["first_idx"].copy()
+        fi[1][fi[1] >= cut - 1] = -1
+        lengths = np.asarray([int((fi[r] >= 0).sum()) for r in range(B)])
+        tags = b["tags"].copy()
+        b = kb.assemble(ids, am, fi, tags, lengths, x_idx)
+    return cfg, tg, b, (start, stop, x_idx)
+
+
+def oracle_params(tg, round_gemm=True):
+    """fp32 copies of the tagger's parameters under HF names (+ head), GEMM weights rounded through bf16
+    so the comparison isolates kernel error from the (intended) bf16 weight quantisation."""
+    sd = {k: v.cpu() for k, v in tg.hf_state_dict().items()}
+    if round_gemm:
+        for k in list(sd):
+            if k.endswith("dense.weight") or k.endswith("query.weight") or k.endswith("key.weight") or k.endswith("value.weight"):
+                sd[k] = sd[k].to(BF16).float()
+    for k in ("linear.weight", "linear.bias", "transitions"):
+        sd[k] = tg.arena.param(k).detach().cpu().clone()
+    return sd
+
+
+def check_step():
+    """One micro-batch fwd+bwd on the HIP path vs the oracle's autograd (fp32 CPU)."""
+    from oracle import encoder as oenc
+    from oracle import train_step as ots
+    cfg, tg, b, (start, stop, x_idx) = tiny_setup()
+    bd = kb.to_device(b, DEV)
+    loss = tg.forward_loss(bd, loss_scale=1.0, backward=True)
+    torch.cuda.synchronize()
+    ocfg = oenc.EncoderConfig(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers,
+                              num_attention_heads=cfg.num_attention_heads, intermediate_size=cfg.intermediate_size,
+                              max_position_embeddings=cfg.max_position_embeddings)
+    params = {k: v.clone().requires_grad_(True) for k, v in oracle_params(tg).items()}
+    ob = dict(input_ids=torch.from_numpy(b["input_ids"]), attention_mask=torch.from_numpy(b["attention_mask"]),
+              first_idx=torch.from_numpy(b["first_idx"]), tags=torch.from_numpy(b["tags"].astype(np.int64)),
+              lengths=torch.from_numpy(b["lengths"].astype(np.int64)))
+    oloss, oem = ots.tagger_forward_loss(params, ocfg, ob, start, stop, x_idx)
+    oloss.backward()
+    res = {"loss_hip": float(loss), "loss_oracle": float(oloss), "loss_rel": abs(float(loss) - float(oloss)) / abs(float(oloss))}
+    # hidden / emissions parity (forward only, all tokens)
+    em = tg.forward_features(bd)
+    torch.cuda.synchronize()
+    n = b["first_idx"].shape[1]
+    valid = torch.from_numpy(b["first_idx"] >= 0)
+    res["emissions_rel"] = rel_l2(em.cpu()[valid], oem.detach()[valid])
+    # gradients
+    nm = engine.hf_name_map(cfg)
+    worst, worst_name, coss = 0.0, "", 1.0
+    for hf, (mine, sl) in nm.items():
+        gh = tg.arena.grad(mine)
+        gh = (gh[sl[0]:sl[1]] if sl is not None else gh).cpu()
+        go = params[hf].grad
+        if go is None or float(go.abs().max()) == 0.0:
+            continue
+        e = rel_l2(gh, go)
+        c = cosine(gh, go)
+        coss = min(coss, c)
+        if e > worst:
+            worst, worst_name = e, hf
+    res["grad_worst_rel"], res["grad_worst_name"], res["grad_min_cos"] = worst, worst_name, coss
+    for k in ("linear.weight", "linear.bias", "transitions"):
+        res["grad_" + k] = rel_l2(tg.arena.grad(k).cpu(), params[k].grad)
+    # Viterbi on the HIP emissions == oracle Viterbi on the SAME emissions (bit-exact indices)
+    from oracle import crf as ocrf
+    lens = torch.from_numpy(b["lengths"]).to(DEV)
+    vt, vc = tg.viterbi(em, lens)
+    torch.cuda.synchronize()
+    rt, rc = ocrf.viterbi_batch(em.cpu().numpy(), b["lengths"], tg.arena.param("transitions").cpu().numpy(), start, stop)
+    res["viterbi_equal"] = bool(np.array_equal(vt.cpu().numpy(), rt))
+    return res
+
+
+def check_adamw(n=4096 + 64, seed=0):
+    from oracle import optim as oopt
+    rng = np.random.default_rng(seed)
+    p = rng.standard_normal(n).astype(np.float32)
+    m = np.zeros(n, np.float32)
+    v = np.zeros(n, np.float32)
+    pd = torch.from_numpy(p.copy()).to(DEV)
+    md = torch.zeros(n, dtype=F32, device=DEV)
+    vd = torch.zeros(n, dtype=F32, device=DEV)
+    sh = torch.zeros(n, dtype=BF16, device=DEV)
+    from . import lib as L
+    ws = torch.zeros(L.load().kbner_sqnorm_ws_floats(), dtype=F32, device=DEV)
+    nsq = torch.zeros(1, dtype=F32, device=DEV)
+    worst = 0.0
+    for step in range(1, 4):
+        g = (rng.standard_normal(n) * (3.0 if step == 2 else 0.01)).astype(np.float32)
+        gd = torch.from_numpy(g.copy()).to(DEV)
+        ops.grad_sqnorm(gd, ws, nsq)
+        lr = 1e-3
+        import math
+        bc = math.sqrt(1 - 0.999 ** step) / (1 - 0.9 ** step)
+        ops.adamw(pd, gd, md, vd, sh, n, lr * bc, 0.0, 0.9, 0.999, 1e-6, nsq, 5.0, 1.0, True)
+        torch.cuda.synchronize()
+        norm = float(np.sqrt((g.astype(np.float64) ** 2).sum()))
+        coef = oopt.clip_coef(norm, 5.0)
+        oopt.adamw_hf_step(p, g * np.float32(coef), m, v, step, lr)
+        worst = max(worst, float(np.abs(pd.cpu().numpy() - p).max()))
+        assert float(gd.abs().max()) == 0.0
+        worst = max(worst, float(np.abs(float(nsq) - norm * norm) / (norm * norm)))
+    shadow_err = float((sh.float().cpu() - torch.from_numpy(p)).abs().max())
+    return {"p_abs": worst, "shadow_abs": shadow_err}
+
+
+def smoke():
+    r = check_step()
+    print("smoke:", r)
+    assert r["loss_rel"] < 3e-2, r
+    assert r["grad_min_cos"] > 0.98, r
+    assert r["viterbi_equal"], r

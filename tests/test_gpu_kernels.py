@@ -1,0 +1,154 @@
+"""GPU parity tests: every HIP kernel, through the C ABI, against the oracle / golden vectors."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def st():
+    from kbner import selftest
+    return selftest
+
+
+def test_probe_tr_read_semantics(st):
+    got, exp = st.probe_tr()
+    np.testing.assert_array_equal(got, exp)
+
+
+def test_probe_mfma_layout(st):
+    c, ref = st.probe_mfma()
+    assert float((c - ref).abs().max()) < 1e-3
+
+
+@pytest.mark.parametrize("layout,M,N,K,epi,sk", [
+    (0, 128, 128, 64, 0, 1), (0, 256, 384, 192, 0, 1), (0, 256, 256, 128, 1 | 4, 1), (0, 256, 256, 128, 1 | 2, 1),
+    (1, 128, 128, 64, 0, 1), (1, 256, 384, 192, 8, 1), (1, 384, 128, 256, 4, 1),
+    (2, 128, 128, 64, 16, 1), (2, 256, 384, 512, 16, 4), (0, 2048, 1024, 1024, 0, 1), (2, 1024, 1024, 4096, 16, 8),
+])
+def test_gemm(st, layout, M, N, K, epi, sk):
+    # tolerance: bf16 output rounding (2^-9 relative per element) on fp32-accumulated products
+    assert st.check_gemm(layout, M, N, K, epi, sk) < 6e-3
+
+
+@pytest.mark.parametrize("B,S,A,ragged", [(1, 64, 1, False), (2, 128, 2, True), (2, 512, 2, True), (3, 320, 1, True)])
+def test_attention(st, B, S, A, ragged):
+    r = st.check_attention(B, S, A, ragged=ragged)
+    # bf16 probabilities / outputs: ~1e-2 relative in L2
+    assert r["ctx"] < 1.5e-2 and r["lse"] < 2e-2, r
+    assert r["dq"] < 3e-2 and r["dk"] < 3e-2 and r["dv"] < 3e-2, r
+
+
+@pytest.mark.parametrize("M,H", [(256, 128), (300, 768), (512, 1024)])
+def test_layernorm(st, M, H):
+    r = st.check_layernorm(M, H)
+    assert r["y"] < 6e-3 and r["dh"] < 1e-2, r
+    assert r["dgamma"] < 2e-3 and r["dbeta"] < 2e-3 and r["dbias"] < 2e-2, r
+
+
+@pytest.mark.parametrize("B,n", [(3, 7), (32, 64), (256, 32), (32, 16), (8, 512), (1, 1)])
+def test_crf_vs_oracle(st, B, n):
+    r = st.check_crf(B, n)
+    assert r["tags_equal"] and r["popped_ok"], r       # Viterbi: bit-exact tag indices
+    assert r["conf"] < 2e-6 and r["logz"] < 2e-6 and r["gold"] < 2e-6, r
+    assert r["demit"] < 2e-5 and r["dtrans"] < 2e-4, r
+
+
+def test_crf_golden_vectors(golden_dir):
+    """The HIP CRF kernels against vectors captured from the reference itself."""
+    from kbner import ops
+    dev = "cuda"
+    g = np.load(os.path.join(golden_dir, "viterbi.npz"))
+    start, stop = int(g["start"]), int(g["stop"])
+    for c in range(int(g["n_cases"])):
+        feats = torch.from_numpy(g["c%d_feats" % c]).to(dev)[None].contiguous()
+        trans = torch.from_numpy(g["c%d_trans" % c]).to(dev)
+        lens = torch.tensor([feats.shape[1]], dtype=torch.int32, device=dev)
+        tags, conf = ops.crf_viterbi(feats, trans, lens, start, stop)
+        np.testing.assert_array_equal(tags.cpu().numpy()[0], g["c%d_path" % c])
+        np.testing.assert_allclose(conf.cpu().numpy()[0], g["c%d_conf" % c], rtol=2e-6, atol=1e-7)
+    g = np.load(os.path.join(golden_dir, "crf_forward_score.npz"))
+    for c in range(int(g["n_cases"])):
+        feats = torch.from_numpy(g["c%d_feats" % c]).to(dev)
+        trans = torch.from_numpy(g["c%d_trans" % c]).to(dev)
+        lens = torch.from_numpy(g["c%d_lens" % c].astype(np.int32)).to(dev)
+        tags = torch.from_numpy(g["c%d_tags" % c].astype(np.int32)).to(dev)
+        logz, gold, _ = ops.crf_nll_fwd(feats, trans, tags, lens, start, stop)
+        np.testing.assert_allclose(logz.cpu().numpy(), g["c%d_alpha" % c], rtol=3e-6, atol=3e-5)
+        np.testing.assert_allclose(gold.cpu().numpy(), g["c%d_gold" % c], rtol=3e-6, atol=3e-5)
+
+
+def test_crf_loss_grad_golden(golden_dir):
+    from kbner import batch as kb
+    from kbner import ops
+    from oracle import crf as ocrf
+    dev = "cuda"
+    g = np.load(os.path.join(golden_dir, "crf_loss_grad.npz"))
+    start, stop, x_idx = int(g["start"]), int(g["stop"]), int(g["x_idx"])
+    for c in range(int(g["n_cases"])):
+        feats, lengths, tags, trans = (g["c%d_%s" % (c, k)] for k in ("feats", "lengths", "tags", "trans"))
+        B, n, T = feats.shape
+        cf, ct, lens, keep = ocrf.compact_remove_x(feats, tags, lengths, x_idx)  # host-side index work
+        fd = torch.from_numpy(cf).to(dev)
+        td = torch.from_numpy(trans).to(dev)
+        tg = torch.from_numpy(ct.astype(np.int32)).to(dev)
+        ld = torch.from_numpy(lens.astype(np.int32)).to(dev)
+        logz, gold, alpha = ops.crf_nll_fwd(fd, td, tg, ld, start, stop)
+        loss = float((logz - gold).mean())
+        np.testing.assert_allclose(loss, float(g["c%d_loss" % c]), rtol=1e-5)
+        dl = torch.full((B,), 1.0 / B, dtype=torch.float32, device=dev)
+        dtr = torch.zeros(T, T, dtype=torch.float32, device=dev)
+        de = ops.crf_nll_bwd(fd, td, tg, ld, alpha, logz, dl, start, stop, dtr).cpu().numpy()
+        full = np.zeros(feats.shape, np.float32)
+        for b in range(B):
+            idx = np.nonzero(keep[b])[0]
+            full[b, idx] = de[b, :len(idx)]
+        np.testing.assert_allclose(full, g["c%d_dfeats" % c], rtol=1e-4, atol=2e-6)
+        np.testing.assert_allclose(dtr.cpu().numpy(), g["c%d_dtrans" % c], rtol=1e-4, atol=2e-6)
+
+
+def test_adamw(st):
+    r = st.check_adamw()
+    assert r["p_abs"] < 2e-6 and r["shadow_abs"] < 2e-2, r
+
+
+def test_encoder_vs_hf_golden(golden_dir):
+    """Encoder forward (HIP, bf16) vs transformers XLMRobertaModel fp32 output captured in-container.
+    Stated tolerance: bf16 activations/weights => relative L2 error <= 2e-2 on unmasked positions."""
+    from kbner import batch as kb
+    from kbner import engine
+    g = np.load(os.path.join(golden_dir, "encoder_tiny.npz"))
+    tag = "wide"
+    V, H, L, A, F_, P = (int(x) for x in g[tag + "_cfg"])
+    cfg = engine.EncoderConfig(vocab_size=V, hidden_size=H, num_hidden_layers=L, num_attention_heads=A,
+                               intermediate_size=F_, max_position_embeddings=max(P, 66))
+    tg = engine.Tagger(cfg, 29, 27, 28)
+    sd = {k[len(tag) + 1:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(tag + "/")}
+    pe = torch.zeros(cfg.max_position_embeddings, H)
+    pe[:P] = sd["embeddings.position_embeddings.weight"]
+    sd["embeddings.position_embeddings.weight"] = pe
+    tg.load_hf_state_dict(sd)
+    ids, am = g[tag + "_ids"], g[tag + "_mask"]
+    B, S0 = ids.shape
+    fi = np.tile(np.arange(S0)[None], (B, 1))
+    b = kb.assemble(ids, am, fi, np.zeros((B, S0), np.int64), np.full(B, S0), None)
+    bd = kb.to_device(b)
+    hid = tg.encoder_forward(bd["ids"], bd["pos_ids"], bd["maskbias"], b["B"], b["S"])
+    torch.cuda.synchronize()
+    out = hid[:B * b["S"]].view(B, b["S"], H)[:, :S0].float().cpu().numpy()
+    valid = am.astype(bool)
+    ref = g[tag + "_last"]
+    err = np.linalg.norm(out[valid] - ref[valid]) / np.linalg.norm(ref[valid])
+    assert err < 2e-2, err
+
+
+def test_full_step_vs_oracle(st):
+    r = st.check_step()
+    assert r["loss_rel"] < 3e-2, r
+    assert r["emissions_rel"] < 3e-2, r
+    assert r["grad_min_cos"] > 0.98 and r["grad_worst_rel"] < 0.15, r
+    assert r["grad_linear.weight"] < 5e-2 and r["grad_transitions"] < 5e-2, r
+    assert r["viterbi_equal"], r
