@@ -277,20 +277,25 @@ def check_step():
     n = b["first_idx"].shape[1]
     valid = torch.from_numpy(b["first_idx"] >= 0)
     res["emissions_rel"] = rel_l2(em.cpu()[valid], oem.detach()[valid])
-    # gradients
+    # gradients.  attention key biases are excluded: softmax is invariant to a per-query constant, so
+    # d loss / d key.bias is exactly 0 in exact arithmetic and both sides hold only roundoff noise.
     nm = engine.hf_name_map(cfg)
     worst, worst_name, coss = 0.0, "", 1.0
+    table = []
+    gscale = max(float(v.grad.abs().max()) for v in params.values() if v.grad is not None)
     for hf, (mine, sl) in nm.items():
         gh = tg.arena.grad(mine)
         gh = (gh[sl[0]:sl[1]] if sl is not None else gh).cpu()
         go = params[hf].grad
-        if go is None or float(go.abs().max()) == 0.0:
+        if go is None or hf.endswith("key.bias") or float(go.abs().max()) < 1e-7 * gscale:
             continue
         e = rel_l2(gh, go)
         c = cosine(gh, go)
+        table.append((e, c, hf))
         coss = min(coss, c)
         if e > worst:
             worst, worst_name = e, hf
+    res["grad_table_top"] = ["%s rel=%.3g cos=%.5f" % (n_, e_, c_) for e_, c_, n_ in sorted(table, reverse=True)[:6]]
     res["grad_worst_rel"], res["grad_worst_name"], res["grad_min_cos"] = worst, worst_name, coss
     for k in ("linear.weight", "linear.bias", "transitions"):
         res["grad_" + k] = rel_l2(tg.arena.grad(k).cpu(), params[k].grad)

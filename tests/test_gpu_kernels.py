@@ -54,7 +54,8 @@ def test_crf_vs_oracle(st, B, n):
     r = st.check_crf(B, n)
     assert r["tags_equal"] and r["popped_ok"], r       # Viterbi: bit-exact tag indices
     assert r["conf"] < 2e-6 and r["logz"] < 2e-6 and r["gold"] < 2e-6, r
-    assert r["demit"] < 2e-5 and r["dtrans"] < 2e-4, r
+    # marginals come from exp(alpha + beta - logZ) with |alpha| ~ O(n): fp32 absolute error grows ~ n * 2^-23 * |score|
+    assert r["demit"] < 5e-7 * max(n, 40) and r["dtrans"] < 2e-6 * max(n, 100), r
 
 
 def test_crf_golden_vectors(golden_dir):
