@@ -85,6 +85,25 @@ int kbner_gemm_bf16(int layout, const kbner_bf16* A, int lda, const kbner_bf16* 
                     const kbner_bf16* aux, int ldaux, kbner_bf16* out2, int ldout2, int epi, int splitk, float alpha,
                     void* stream);
 
+/* Grouped GEMM on the 256x256x64 / 8-wave kernel: up to 8 problems of one layout per launch (the four weight-
+ * gradient GEMMs of an encoder layer fill the chip without split-K).  Per problem M,N % 256 == 0, K % 64 == 0. */
+#define KBNER_EPI_RMW32 32 /* C32 += result by non-atomic 16-byte read-modify-write */
+typedef struct kbner_gemm_problem {
+  const kbner_bf16* A;
+  const kbner_bf16* B;
+  kbner_bf16* C;
+  float* C32;
+  const float* bias;
+  const kbner_bf16* addend;
+  const kbner_bf16* aux;
+  kbner_bf16* out2;
+  int M, N, K;
+  int lda, ldb, ldc, ldc32, ldadd, ldaux, ldout2;
+  int epi;
+  float alpha;
+} kbner_gemm_problem;
+int kbner_gemm_bf16_grouped(int layout, int nprob, const kbner_gemm_problem* probs, void* stream);
+
 /* ---------------- fused self-attention (transformers BertSelfAttention), head_dim 64, S<=512 ---------------- */
 int kbner_attn_fwd(const kbner_bf16* qkv, const float* maskbias, kbner_bf16* ctx, float* lse, int B, int S, int H, int A,
                    void* stream);

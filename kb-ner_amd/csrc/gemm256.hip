@@ -1,0 +1,292 @@
+// bf16 MFMA GEMM, second structure: 256 x 256 x 64 block tile, 512 threads = 8 wavefronts (2 x 4),
+// each wave 128 x 64 (8 x 4 MFMA 16x16x32 fragments, 128 accumulator registers), one workgroup per CU,
+// two 64 KiB LDS stages filled by global_load_lds.  Versus the 128^2 kernel (gemm.hip) this halves
+// the L2->LDS bytes per flop (the 128^2 tile needs ~34 TB/s of L2 at MFMA peak, the whole chip's L2
+// bandwidth) and the LDS->register bytes per flop.  Grouped: one launch can carry up to 8 independent
+// problems (same layout) so the four weight-gradient GEMMs of a layer fill the chip WITHOUT split-K:
+// their fp32 accumulate-into-gradient epilogue is a plain 16-byte read-modify-write, no atomics.
+//
+// Operand images and fragment maps are those of gemm.hip; the k-strided (KS) image here carries a
+// 32-byte-block XOR swizzle so ds_read_b64_tr_b16 is bank-conflict free (8 k-rows x 32 B per half-wave
+// land on 64 distinct banks).
+#include "common.h"
+
+#define EPI_BIAS 1
+#define EPI_GELU 2
+#define EPI_ADD 4
+#define EPI_DGELU 8
+#define EPI_ATOMIC32 16
+#define EPI_RMW32 32  // C32[m,n] += result, non-atomic 16-byte RMW (each output element owned by one lane)
+
+#define G2_MAXP 8
+
+struct GemmProblem {
+  const bf16_t* A;
+  const bf16_t* B;
+  bf16_t* C;
+  float* C32;
+  const float* bias;
+  const bf16_t* addend;
+  const bf16_t* aux;
+  bf16_t* out2;
+  int M, N, K;
+  int lda, ldb, ldc, ldc32, ldadd, ldaux, ldout2;
+  int epi;
+  float alpha;
+  int tile_begin;
+  int pad_;
+};
+
+struct GroupArgs {
+  int nprob;
+  int total_tiles;
+  GemmProblem p[G2_MAXP];
+};
+
+#define T2 256
+#define BK2 64
+#define TILE2_BYTES 32768
+#define STAGE2_BYTES 65536
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void glb_cvoid;
+
+static __device__ __forceinline__ void glds16(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((glb_cvoid*)g, (lds_void*)l, 16, 0, 0);
+}
+static __device__ __forceinline__ int kc_swz(int row) { return (row >> 1) & 7; }
+static __device__ __forceinline__ int ks_swz(int krow) { return (krow & 3) | ((krow >> 1) & 4); }
+
+template <bool KS>
+static __device__ __forceinline__ void stage256(const bf16_t* __restrict__ P, int ld, int row0, int k0, unsigned char* s, int wid,
+                                                int lane) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int q = wid * 4 + j;  // 32 wave-instructions x 1 KiB = 32 KiB tile
+    const bf16_t* src;
+    if (!KS) {
+      const int row = q * 8 + (lane >> 3);
+      const int pos = lane & 7;
+      src = P + (size_t)(row0 + row) * ld + k0 + ((pos ^ kc_swz(row)) << 3);
+    } else {
+      const int kr = q * 2 + (lane >> 5);
+      const int pos = lane & 31;
+      src = P + (size_t)(k0 + kr) * ld + row0 + ((pos ^ (ks_swz(kr) << 1)) << 3);
+    }
+    glds16(src, s + q * 1024);
+  }
+}
+
+template <bool KS>
+static __device__ __forceinline__ bf16x8 frag256(const unsigned char* s, int r0, int ks, int lane) {
+  if (!KS) {
+    const int row = r0 + (lane & 15);
+    const int c = ks * 4 + (lane >> 4);
+    const s8v v = *reinterpret_cast<const s8v*>(s + row * 128 + ((c ^ kc_swz(row)) << 4));
+    return __builtin_bit_cast(bf16x8, v);
+  } else {
+    const int p = lane & 15;
+    const int r = ks * 32 + (lane >> 4) * 8 + (p >> 2);
+    const unsigned char* a = s + r * 512 + ((((r0 >> 4) ^ ks_swz(r))) << 5) + ((p & 3) << 3);
+    const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4v __attribute__((address_space(3)))*)(a));
+    const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4v __attribute__((address_space(3)))*)(a + 4 * 512));
+    s8v v;
+    v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+    v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+    return __builtin_bit_cast(bf16x8, v);
+  }
+}
+
+template <bool A_KS, bool B_KS>
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(const GroupArgs ga) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 2, wn = wid & 3;
+
+  // XCD-aware bijective remap (block b runs on XCD b % 8): contiguous tile run per XCD
+  const int nwg = gridDim.x;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7;
+  const int q8 = nwg >> 3, r8 = nwg & 7;
+  const int wg = ((xcd < r8) ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+
+  // pick this block's problem with static indices only (a runtime-indexed kernarg array would go to scratch)
+  GemmProblem g = ga.p[0];
+#pragma unroll
+  for (int i = 1; i < G2_MAXP; ++i)
+    if (i < ga.nprob && wg >= ga.p[i].tile_begin) g = ga.p[i];
+  const int tile = wg - g.tile_begin;
+  const int tiles_n = g.N / T2;
+  const int tm = tile / tiles_n, tn = tile % tiles_n;
+  const int m0 = tm * T2, n0 = tn * T2;
+  const int nt = g.K / BK2;
+  const bf16_t* __restrict__ Ap = g.A;
+  const bf16_t* __restrict__ Bp = g.B;
+  const int lda = g.lda, ldb = g.ldb;
+
+  f4v acc[8][4];
+#pragma unroll
+  for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
+
+  stage256<A_KS>(Ap, lda, m0, 0, smem, wid, lane);
+  stage256<B_KS>(Bp, ldb, n0, 0, smem + TILE2_BYTES, wid, lane);
+
+  for (int t = 0; t < nt; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    unsigned char* cur = smem + (t & 1) * STAGE2_BYTES;
+    if (t + 1 < nt) {
+      unsigned char* nxt = smem + ((t + 1) & 1) * STAGE2_BYTES;
+      stage256<A_KS>(Ap, lda, m0, (t + 1) * BK2, nxt, wid, lane);
+      stage256<B_KS>(Bp, ldb, n0, (t + 1) * BK2, nxt + TILE2_BYTES, wid, lane);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 bfr[4];
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) bfr[ni] = frag256<B_KS>(cur + TILE2_BYTES, wn * 64 + ni * 16, ks, lane);
+#pragma unroll
+      for (int mi = 0; mi < 8; ++mi) {
+        const bf16x8 af = frag256<A_KS>(cur, wm * 128 + mi * 16, ks, lane);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af, acc[mi][ni], 0, 0, 0);
+      }
+    }
+  }
+
+  const int epi = g.epi;
+  const float alpha = g.alpha;
+  const int gq = lane >> 4;
+#pragma unroll
+  for (int mi = 0; mi < 8; ++mi) {
+    const int m = m0 + wm * 128 + mi * 16 + (lane & 15);
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int n = n0 + wn * 64 + ni * 16 + gq * 4;
+      float v[4] = {acc[mi][ni][0] * alpha, acc[mi][ni][1] * alpha, acc[mi][ni][2] * alpha, acc[mi][ni][3] * alpha};
+      if (epi & EPI_RMW32) {
+        float4* c = reinterpret_cast<float4*>(g.C32 + (size_t)m * g.ldc32 + n);
+        float4 o = *c;
+        o.x += v[0]; o.y += v[1]; o.z += v[2]; o.w += v[3];
+        *c = o;
+        continue;
+      }
+      if (epi & EPI_ATOMIC32) {
+        float* c = g.C32 + (size_t)m * g.ldc32 + n;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) atomicAdd(c + r, v[r]);
+        continue;
+      }
+      if (epi & EPI_BIAS) {
+        const float4 b = *reinterpret_cast<const float4*>(g.bias + n);
+        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+      }
+      if (epi & EPI_ADD) {
+        const uint2 u = *reinterpret_cast<const uint2*>(g.addend + (size_t)m * g.ldadd + n);
+        v[0] += __uint_as_float(u.x << 16);
+        v[1] += __uint_as_float(u.x & 0xffff0000u);
+        v[2] += __uint_as_float(u.y << 16);
+        v[3] += __uint_as_float(u.y & 0xffff0000u);
+      }
+      if (epi & EPI_DGELU) {
+        const uint2 u = *reinterpret_cast<const uint2*>(g.aux + (size_t)m * g.ldaux + n);
+        v[0] *= gelu_grad_f(__uint_as_float(u.x << 16));
+        v[1] *= gelu_grad_f(__uint_as_float(u.x & 0xffff0000u));
+        v[2] *= gelu_grad_f(__uint_as_float(u.y << 16));
+        v[3] *= gelu_grad_f(__uint_as_float(u.y & 0xffff0000u));
+      }
+      if (epi & EPI_GELU) {
+        uint2 pu;
+        pu.x = pack2bf(v[0], v[1]);
+        pu.y = pack2bf(v[2], v[3]);
+        *reinterpret_cast<uint2*>(g.out2 + (size_t)m * g.ldout2 + n) = pu;
+        v[0] = gelu_f(__uint_as_float(pu.x << 16));
+        v[1] = gelu_f(__uint_as_float(pu.x & 0xffff0000u));
+        v[2] = gelu_f(__uint_as_float(pu.y << 16));
+        v[3] = gelu_f(__uint_as_float(pu.y & 0xffff0000u));
+      }
+      uint2 o;
+      o.x = pack2bf(v[0], v[1]);
+      o.y = pack2bf(v[2], v[3]);
+      *reinterpret_cast<uint2*>(g.C + (size_t)m * g.ldc + n) = o;
+    }
+  }
+}
+
+template <bool A_KS, bool B_KS>
+static int launch256(const GroupArgs& ga, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<A_KS, B_KS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE2_BYTES);
+    if (e != hipSuccess) return -(int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm256_kernel<A_KS, B_KS>), dim3(ga.total_tiles), dim3(512), 2 * STAGE2_BYTES, stream, ga);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+// public mirror of GemmProblem (include/kbner.h: kbner_gemm_problem)
+struct kbner_gemm_problem {
+  const bf16_t* A;
+  const bf16_t* B;
+  bf16_t* C;
+  float* C32;
+  const float* bias;
+  const bf16_t* addend;
+  const bf16_t* aux;
+  bf16_t* out2;
+  int M, N, K;
+  int lda, ldb, ldc, ldc32, ldadd, ldaux, ldout2;
+  int epi;
+  float alpha;
+};
+
+extern "C" {
+
+// Grouped GEMM: nprob (1..8) problems of the SAME layout in one launch.
+// Constraints per problem: M % 256 == 0, N % 256 == 0, K % 64 == 0, lda/ldb % 8 == 0.
+int kbner_gemm_bf16_grouped(int layout, int nprob, const kbner_gemm_problem* probs, void* stream) {
+  KBNER_CHECK_ARG(layout >= 0 && layout <= 2 && nprob >= 1 && nprob <= G2_MAXP && probs != nullptr);
+  GroupArgs ga;
+  ga.nprob = nprob;
+  int tiles = 0;
+  for (int i = 0; i < nprob; ++i) {
+    const kbner_gemm_problem& s = probs[i];
+    KBNER_CHECK_ARG(s.M > 0 && s.N > 0 && s.K > 0 && s.M % T2 == 0 && s.N % T2 == 0 && s.K % BK2 == 0);
+    KBNER_CHECK_ARG(s.A != nullptr && s.B != nullptr && s.lda % 8 == 0 && s.ldb % 8 == 0);
+    if (s.epi & (EPI_ATOMIC32 | EPI_RMW32)) {
+      KBNER_CHECK_ARG(s.C32 != nullptr && s.ldc32 >= s.N && s.ldc32 % 4 == 0);
+    } else {
+      KBNER_CHECK_ARG(s.C != nullptr && s.ldc >= s.N && s.ldc % 4 == 0);
+    }
+    if (s.epi & EPI_BIAS) KBNER_CHECK_ARG(s.bias != nullptr);
+    if (s.epi & EPI_ADD) KBNER_CHECK_ARG(s.addend != nullptr && s.ldadd % 4 == 0);
+    if (s.epi & EPI_DGELU) KBNER_CHECK_ARG(s.aux != nullptr && s.ldaux % 4 == 0);
+    if (s.epi & EPI_GELU) KBNER_CHECK_ARG(s.out2 != nullptr && s.ldout2 % 4 == 0);
+    GemmProblem& d = ga.p[i];
+    d.A = s.A; d.B = s.B; d.C = s.C; d.C32 = s.C32; d.bias = s.bias; d.addend = s.addend; d.aux = s.aux; d.out2 = s.out2;
+    d.M = s.M; d.N = s.N; d.K = s.K; d.lda = s.lda; d.ldb = s.ldb; d.ldc = s.ldc; d.ldc32 = s.ldc32; d.ldadd = s.ldadd;
+    d.ldaux = s.ldaux; d.ldout2 = s.ldout2; d.epi = s.epi; d.alpha = s.alpha; d.tile_begin = tiles; d.pad_ = 0;
+    tiles += (s.M / T2) * (s.N / T2);
+  }
+  for (int i = nprob; i < G2_MAXP; ++i) {
+    ga.p[i] = ga.p[0];
+    ga.p[i].tile_begin = 0x7fffffff;
+  }
+  ga.total_tiles = tiles;
+  hipStream_t st = (hipStream_t)stream;
+  switch (layout) {
+    case 0: return launch256<false, false>(ga, st);
+    case 1: return launch256<false, true>(ga, st);
+    default: return launch256<true, true>(ga, st);
+  }
+}
+
+}  // extern "C"

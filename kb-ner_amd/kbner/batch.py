@@ -35,7 +35,7 @@ def assemble(input_ids, attention_mask, first_idx, tags, lengths, x_idx, pad_id=
     nz = (ids != pad_id).astype(np.int64)       # RoBERTa position ids from ids != pad (transformers modeling_roberta)
     pos = np.cumsum(nz, axis=1) * nz + pad_id
     M = B * S
-    Mp = round_up(M, 128)
+    Mp = round_up(M, 256)
     ids_f = np.zeros(Mp, np.int32)
     pos_f = np.full(Mp, pad_id, np.int32)
     ids_f[:M] = ids.reshape(-1)

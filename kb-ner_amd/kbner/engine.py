@@ -15,7 +15,7 @@ import math
 import torch
 
 from . import ops
-from .lib import EPI_ADD, EPI_ATOMIC32, EPI_BIAS, EPI_DGELU, EPI_GELU, GEMM_NN, GEMM_NT, GEMM_TN
+from .lib import EPI_ADD, EPI_ATOMIC32, EPI_BIAS, EPI_DGELU, EPI_GELU, EPI_RMW32, GEMM_NN, GEMM_NT, GEMM_TN
 
 BF16, F32, I32 = torch.bfloat16, torch.float32, torch.int32
 
@@ -166,7 +166,7 @@ class _Acts:
     def __init__(self, cfg, B, S, device):
         H, F_, A, L = cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads, cfg.num_hidden_layers
         self.B, self.S, self.M = B, S, B * S
-        self.Mp = Mp = _round_up(B * S, 128)
+        self.Mp = Mp = _round_up(B * S, 256)
         z = lambda *shape, dt=BF16: torch.zeros(shape, dtype=dt, device=device)  # noqa: E731
         self.h0 = z(Mp, H)
         self.emb_mean, self.emb_rstd = z(Mp, dt=F32), z(Mp, dt=F32)
@@ -316,31 +316,40 @@ class Tagger:
             ops.ln_bwd(dx, ac.h2[l], ac.st2[l][0], ac.st2[l][1], a.param(p + "ln2.g"), ac.dh, a.grad(p + "ln2.g"),
                        a.grad(p + "ln2.b"), a.grad(p + "ffn2.bias"))
             # FFN down: wgrad dW2[H,F] += dh^T act ; dgrad dpre = (dh W2) * gelu'(pre)
-            ops.gemm(GEMM_TN, ac.dh, ac.act[l], H, F_, Mp, C32=a.grad(p + "ffn2.weight"), epi=EPI_ATOMIC32,
-                     splitk=_splitk((H // 128) * (F_ // 128), Mp))
             ops.gemm(GEMM_NN, ac.dh, a.bf(p + "ffn2.weight"), Mp, F_, H, C=ac.dpre, aux=ac.pre[l], epi=EPI_DGELU)
             # FFN up
             ops.colsum(ac.dpre, a.grad(p + "ffn1.bias"))
-            ops.gemm(GEMM_TN, ac.dpre, ac.x1[l], F_, H, Mp, C32=a.grad(p + "ffn1.weight"), epi=EPI_ATOMIC32,
-                     splitk=_splitk((F_ // 128) * (H // 128), Mp))
             ops.gemm(GEMM_NN, ac.dpre, a.bf(p + "ffn1.weight"), Mp, H, F_, C=ac.dx1, addend=ac.dh, epi=EPI_ADD)
             # LN1 backward; fused: d o.bias
             ops.ln_bwd(ac.dx1, ac.h1[l], ac.st1[l][0], ac.st1[l][1], a.param(p + "ln1.g"), ac.dh1, a.grad(p + "ln1.g"),
                        a.grad(p + "ln1.b"), a.grad(p + "o.bias"))
             # attention output projection
-            ops.gemm(GEMM_TN, ac.dh1, ac.ctx[l], H, H, Mp, C32=a.grad(p + "o.weight"), epi=EPI_ATOMIC32,
-                     splitk=_splitk((H // 128) * (H // 128), Mp))
             ops.gemm(GEMM_NN, ac.dh1, a.bf(p + "o.weight"), Mp, H, H, C=ac.dctx)
             # attention core
             ops.attn_bwd(ac.qkv[l], ac.ctx[l], ac.dctx, maskbias, ac.lse[l], ac.dws, ac.dqkv, B, S, H, A)
             # QKV projection
             ops.colsum(ac.dqkv, a.grad(p + "qkv.bias"))
-            ops.gemm(GEMM_TN, ac.dqkv, ac.x[l], 3 * H, H, Mp, C32=a.grad(p + "qkv.weight"), epi=EPI_ATOMIC32,
-                     splitk=_splitk((3 * H // 128) * (H // 128), Mp))
             ops.gemm(GEMM_NN, ac.dqkv, a.bf(p + "qkv.weight"), Mp, H, 3 * H, C=ac.dx, addend=ac.dh1, epi=EPI_ADD)
+            # the layer's four weight gradients dW += dY^T X in ONE grouped launch (no split-K, no atomics):
+            # every dY / X of this layer is still live here (the work buffers are only reused by layer l-1)
+            self._wgrads(l, ac)
             dx = ac.dx
         ops.embed_ln_bwd(dx, ac.h0, ac.emb_mean, ac.emb_rstd, a.param("emb.ln.g"), ids, pos_ids, a.grad("emb.ln.g"),
                          a.grad("emb.ln.b"), a.grad("emb.word"), a.grad("emb.pos"), a.grad("emb.type")[0])
+
+    def _wgrads(self, l, ac):
+        cfg, a = self.cfg, self.arena
+        H, F_, Mp = cfg.hidden_size, cfg.intermediate_size, ac.Mp
+        p = "l%d." % l
+        pairs = [(ac.dh, ac.act[l], H, F_, "ffn2.weight"), (ac.dpre, ac.x1[l], F_, H, "ffn1.weight"),
+                 (ac.dh1, ac.ctx[l], H, H, "o.weight"), (ac.dqkv, ac.x[l], 3 * H, H, "qkv.weight")]
+        if all(n_ % 256 == 0 and k_ % 256 == 0 for _, _, n_, k_, _ in pairs):
+            ops.gemm_grouped(GEMM_TN, [ops.make_problem(dy, x, n_, k_, Mp, C32=a.grad(p + nm), epi=EPI_RMW32)
+                                       for dy, x, n_, k_, nm in pairs])
+        else:
+            for dy, x, n_, k_, nm in pairs:
+                ops.gemm(GEMM_TN, dy, x, n_, k_, Mp, C32=a.grad(p + nm), epi=EPI_ATOMIC32,
+                         splitk=_splitk((n_ // 128) * (k_ // 128), Mp))
 
     # ---------------------------------------------------------------- tagger head
     def emissions(self, hidden, row_idx, B, n):

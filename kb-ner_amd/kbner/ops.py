@@ -1,5 +1,7 @@
 """Typed Python wrappers over the C ABI: argument checking + pointer marshalling, nothing else.
 Every function enqueues on torch's current HIP stream and returns immediately."""
+import ctypes
+
 import torch
 
 from . import lib as L
@@ -117,13 +119,43 @@ def embed_ln_bwd(dy, h0, mean, rstd, gamma, ids, pos_ids, dgamma, dbeta, dword, 
 
 
 # ---------------------------------------------------------------- GEMM
+FORCE_128 = False  # tests: force the 128^2 kernel
 GEMM_HOOK = None  # bench.py sets this to a list to time every GEMM launch with HIP events on the launch stream
+
+
+def _addr(t):
+    return t.data_ptr() if t is not None else None
+
+
+def make_problem(A, B, M, N, K, C=None, C32=None, bias=None, addend=None, aux=None, out2=None, epi=0, alpha=1.0):
+    _chk(A, BF16, "A"); _chk(B, BF16, "B")
+    return L.GemmProblem(_addr(A), _addr(B), _addr(C), _addr(C32), _addr(bias), _addr(addend), _addr(aux), _addr(out2),
+                         M, N, K, A.shape[1], B.shape[1], C.shape[1] if C is not None else 0,
+                         C32.shape[1] if C32 is not None else 0, addend.shape[1] if addend is not None else 0,
+                         aux.shape[1] if aux is not None else 0, out2.shape[1] if out2 is not None else 0, epi, alpha)
+
+
+def gemm_grouped(layout, problems):
+    """problems: list (<= 8) of L.GemmProblem (make_problem) of one layout; 256x256x64 8-wave kernel."""
+    n = len(problems)
+    arr = (L.GemmProblem * n)(*problems)
+    hook = GEMM_HOOK
+    if hook is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    L.call("kbner_gemm_bf16_grouped", layout, n, ctypes.cast(arr, ctypes.c_void_p), stream_ptr())
+    if hook is not None:
+        ev1.record()
+        hook.append((ev0, ev1, sum(2.0 * p.M * p.N * p.K for p in problems), layout))
 
 
 def gemm(layout, A, B, M, N, K, C=None, C32=None, bias=None, addend=None, aux=None, out2=None, epi=0, splitk=1, alpha=1.0,
          lda=None, ldb=None):
-    """C[M,N] (bf16) or C32[M,N] += (fp32 atomics).  A/B are 2-D bf16 tensors in their memory layouts."""
+    """C[M,N] (bf16) or C32[M,N] += (fp32).  A/B are 2-D bf16 tensors in their memory layouts.
+    Shapes divisible by 256 go to the 256^2 8-wave kernel, others to the 128^2 kernel."""
     _chk(A, BF16, "A"); _chk(B, BF16, "B")
+    if M % 256 == 0 and N % 256 == 0 and splitk == 1 and lda is None and ldb is None and not FORCE_128:
+        return gemm_grouped(layout, [make_problem(A, B, M, N, K, C, C32, bias, addend, aux, out2, epi, alpha)])
     lda = A.shape[1] if lda is None else lda
     ldb = B.shape[1] if ldb is None else ldb
     hook = GEMM_HOOK

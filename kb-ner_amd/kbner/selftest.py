@@ -8,7 +8,7 @@ import torch
 
 from . import batch as kb
 from . import engine, ops
-from .lib import EPI_ADD, EPI_ATOMIC32, EPI_BIAS, EPI_DGELU, EPI_GELU, GEMM_NN, GEMM_NT, GEMM_TN
+from .lib import EPI_ADD, EPI_ATOMIC32, EPI_BIAS, EPI_DGELU, EPI_GELU, EPI_RMW32, GEMM_NN, GEMM_NT, GEMM_TN
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if ROOT not in sys.path:
@@ -90,7 +90,7 @@ def check_gemm(layout, M, N, K, epi=0, splitk=1, seed=0):
         pre = ref.float().to(BF16).double()
         ref_pre = ref
         ref = torch.nn.functional.gelu(pre)
-    if epi & EPI_ATOMIC32:
+    if epi & (EPI_ATOMIC32 | EPI_RMW32):
         C32 = torch.full((M, N), 1.0, dtype=F32, device=DEV)
         ops.gemm(layout, Ad, Bd, M, N, K, C32=C32, epi=epi, splitk=splitk, **kw)
         torch.cuda.synchronize()
@@ -102,6 +102,25 @@ def check_gemm(layout, M, N, K, epi=0, splitk=1, seed=0):
     if out2 is not None:
         err = max(err, rel_l2(out2.cpu().float(), ref_pre))
     return err
+
+
+def check_gemm_grouped(seed=0):
+    """four TN (wgrad) problems of different shapes in one grouped launch, RMW32 epilogue."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    shapes = [(256, 512, 320), (512, 256, 320), (256, 256, 320), (768, 256, 320)]
+    probs, refs, outs, keep = [], [], [], []
+    for (N_, K_, M_) in shapes:
+        dy = (torch.randn(M_, N_, generator=g) * 0.5).to(BF16)
+        x = (torch.randn(M_, K_, generator=g) * 0.5).to(BF16)
+        refs.append(dy.double().t() @ x.double())
+        dyd, xd = dy.to(DEV), x.to(DEV)
+        c = torch.full((N_, K_), 2.0, dtype=F32, device=DEV)
+        keep += [dyd, xd]
+        outs.append(c)
+        probs.append(ops.make_problem(dyd, xd, N_, K_, M_, C32=c, epi=EPI_RMW32))
+    ops.gemm_grouped(GEMM_TN, probs)
+    torch.cuda.synchronize()
+    return max(rel_l2(o.cpu() - 2.0, r) for o, r in zip(outs, refs))
 
 
 # ------------------------------------------------------------------ attention

@@ -28,10 +28,28 @@ def test_probe_mfma_layout(st):
     (0, 128, 128, 64, 0, 1), (0, 256, 384, 192, 0, 1), (0, 256, 256, 128, 1 | 4, 1), (0, 256, 256, 128, 1 | 2, 1),
     (1, 128, 128, 64, 0, 1), (1, 256, 384, 192, 8, 1), (1, 384, 128, 256, 4, 1),
     (2, 128, 128, 64, 16, 1), (2, 256, 384, 512, 16, 4), (0, 2048, 1024, 1024, 0, 1), (2, 1024, 1024, 4096, 16, 8),
+    # 256x256x64 8-wave kernel (M, N % 256 == 0)
+    (0, 256, 256, 64, 0, 1), (0, 512, 768, 320, 1 | 4, 1), (0, 512, 256, 128, 1 | 2, 1), (1, 256, 256, 64, 0, 1),
+    (1, 512, 768, 320, 8, 1), (1, 768, 256, 256, 4, 1), (2, 256, 256, 64, 32, 1), (2, 512, 768, 1024, 32, 1),
+    (2, 256, 512, 320, 16, 1),
 ])
 def test_gemm(st, layout, M, N, K, epi, sk):
     # tolerance: bf16 output rounding (2^-9 relative per element) on fp32-accumulated products
     assert st.check_gemm(layout, M, N, K, epi, sk) < 6e-3
+
+
+def test_gemm_grouped_wgrad(st):
+    assert st.check_gemm_grouped() < 1e-5
+
+
+def test_gemm_128_kernel_still_correct(st):
+    from kbner import ops
+    ops.FORCE_128 = True
+    try:
+        for layout, epi in ((0, 1 | 2), (1, 8), (2, 16)):
+            assert st.check_gemm(layout, 256, 256, 128, epi, 1) < 6e-3
+    finally:
+        ops.FORCE_128 = False
 
 
 @pytest.mark.parametrize("B,S,A,ragged", [(1, 64, 1, False), (2, 128, 2, True), (2, 512, 2, True), (3, 320, 1, True)])
