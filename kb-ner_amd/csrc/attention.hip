@@ -23,13 +23,35 @@
 
 #define AT_D 64
 #define AT_MAXS 512
-#define AT_QT 128  // rows (queries or keys) owned by one workgroup
+#define AT_NW 8  // wavefronts per workgroup (2 per SIMD: one wave's softmax VALU overlaps the other's MFMAs)
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void glb_cvoid;
 
+// LDS-DMA from inline asm (hidden from hipcc's waitcnt bookkeeping, see gemm256.hip): completion is
+// ordered by hand with counted s_waitcnt vmcnt(N) + a barrier before the panel is read.
 static __device__ __forceinline__ void glds16(const void* g, void* l) {
-  __builtin_amdgcn_global_load_lds((glb_cvoid*)g, (lds_void*)l, 16, 0, 0);
+  const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void*)l);
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(g), "s"(dst)
+               : "memory");
+}
+// wait until at most n of this wave's DMA instructions are outstanding (n = S/64 per panel: every wave
+// issues exactly S/64 one-KiB pieces of each [S,64] panel)
+static __device__ __forceinline__ void wait_vm(int n) {
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+  }
 }
 static __device__ __forceinline__ int kc_swz(int row) { return (row >> 1) & 7; }
 
@@ -37,7 +59,7 @@ static __device__ __forceinline__ int kc_swz(int row) { return (row >> 1) & 7; }
 static __device__ __forceinline__ void stage_panel(const bf16_t* __restrict__ src, int ld, int S, unsigned char* s, int wid,
                                                    int lane) {
   const int ninstr = S / 8;  // 1 KiB = 8 rows per wave-instruction
-  for (int q = wid; q < ninstr; q += 4) {
+  for (int q = wid; q < ninstr; q += AT_NW) {
     const int row = q * 8 + (lane >> 3);
     const int pos = lane & 7;
     glds16(src + (size_t)row * ld + ((pos ^ kc_swz(row)) << 3), s + q * 1024);
@@ -101,9 +123,9 @@ static __device__ __forceinline__ float group4_max(float v) {
 // ------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 1) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ maskbias,
+__global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ maskbias,
                                                           bf16_t* __restrict__ ctx, float* __restrict__ lse, int S, int H,
-                                                          int A, float scale) {
+                                                          int A, float scale, int rpw) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sK = smem;
   unsigned char* sV = smem + AT_MAXS * 128;
@@ -115,14 +137,14 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel(const bf16_t* __restri
   const bf16_t* base = qkv + (size_t)b * S * ld + h * AT_D;
   stage_panel(base + H, ld, S, sK, wid, lane);
   stage_panel(base + 2 * H, ld, S, sV, wid, lane);
-  for (int i = tid; i < S; i += 256) sMask[i] = maskbias[(size_t)b * S + i];
+  for (int i = tid; i < S; i += 512) sMask[i] = maskbias[(size_t)b * S + i];
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   const int g = lane >> 4, li = lane & 15;
   const int nkb = S / 16;
 #pragma unroll 1
-  for (int pass = 0; pass < 2; ++pass) {
-    const int q0 = qt * AT_QT + wid * 32 + pass * 16;
+  for (int pass = 0; pass < rpw / 128; ++pass) {
+    const int q0 = qt * rpw + wid * (rpw / 8) + pass * 16;
     if (q0 >= S) break;
     const bf16x8 qf0 = glb_frag(base, ld, q0, 0, lane);
     const bf16x8 qf1 = glb_frag(base, ld, q0, 1, lane);
@@ -212,10 +234,10 @@ __global__ __launch_bounds__(256) void attn_rowdot_kernel(const bf16_t* __restri
 // ------------------------------------------------------------------------------------------
 // backward: dQ   (owner = query rows; panels K, V)
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dctx,
+__global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dctx,
                                                              const float* __restrict__ maskbias, const float* __restrict__ lse,
                                                              const float* __restrict__ Dv, bf16_t* __restrict__ dqkv, int S,
-                                                             int H, int A, float scale) {
+                                                             int H, int A, float scale, int rpw) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sK = smem;
   unsigned char* sV = smem + AT_MAXS * 128;
@@ -227,15 +249,15 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const bf16_t* __res
   const bf16_t* base = qkv + (size_t)b * S * ld + h * AT_D;
   stage_panel(base + H, ld, S, sK, wid, lane);
   stage_panel(base + 2 * H, ld, S, sV, wid, lane);
-  for (int i = tid; i < S; i += 256) sMask[i] = maskbias[(size_t)b * S + i];
+  for (int i = tid; i < S; i += 512) sMask[i] = maskbias[(size_t)b * S + i];
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   const int g = lane >> 4, li = lane & 15;
   const int nkc = S / 32;
   const bf16_t* dob = dctx + (size_t)b * S * H + h * AT_D;
 #pragma unroll 1
-  for (int pass = 0; pass < 2; ++pass) {
-    const int q0 = qt * AT_QT + wid * 32 + pass * 16;
+  for (int pass = 0; pass < rpw / 128; ++pass) {
+    const int q0 = qt * rpw + wid * (rpw / 8) + pass * 16;
     if (q0 >= S) break;
     const bf16x8 qf0 = glb_frag(base, ld, q0, 0, lane);
     const bf16x8 qf1 = glb_frag(base, ld, q0, 1, lane);
@@ -288,10 +310,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const bf16_t* __res
 // ------------------------------------------------------------------------------------------
 // backward: dK, dV   (owner = key rows; panels Q, dO)
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dctx,
+__global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dctx,
                                                               const float* __restrict__ maskbias, const float* __restrict__ lse,
                                                               const float* __restrict__ Dv, bf16_t* __restrict__ dqkv, int S,
-                                                              int H, int A, float scale) {
+                                                              int H, int A, float scale, int rpw) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sQ = smem;
   unsigned char* sO = smem + AT_MAXS * 128;
@@ -306,7 +328,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const bf16_t* __re
   stage_panel(base, ld, S, sQ, wid, lane);
   stage_panel(dob, H, S, sO, wid, lane);
   const size_t sbase = ((size_t)b * A + h) * S;
-  for (int i = tid; i < S; i += 256) {
+  for (int i = tid; i < S; i += 512) {
     sL[i] = lse[sbase + i];
     sD[i] = Dv[sbase + i];
   }
@@ -315,8 +337,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const bf16_t* __re
   const int g = lane >> 4, li = lane & 15;
   const int nqc = S / 32;
 #pragma unroll 1
-  for (int pass = 0; pass < 2; ++pass) {
-    const int k0 = kt * AT_QT + wid * 32 + pass * 16;
+  for (int pass = 0; pass < rpw / 128; ++pass) {
+    const int k0 = kt * rpw + wid * (rpw / 8) + pass * 16;
     if (k0 >= S) break;
     const bf16x8 kf0 = glb_frag(base + H, ld, k0, 0, lane);
     const bf16x8 kf1 = glb_frag(base + H, ld, k0, 1, lane);
@@ -386,6 +408,14 @@ static int set_lds(const void* f, int bytes) {
 
 #define AT_LDS_BYTES (2 * AT_MAXS * 128 + 2 * AT_MAXS * 4)
 
+// rows per workgroup: the whole head (one DMA of each panel per head) when the grid still covers the
+// chip several times over, otherwise smaller row tiles so small batches spread over more CUs
+static inline int pick_rpw(int B, int S, int A) {
+  int rpw = 512;
+  while (rpw > 128 && (rpw / 2 >= S || (long)B * A * ((S + rpw - 1) / rpw) < 512)) rpw /= 2;
+  return rpw;
+}
+
 extern "C" {
 
 // qkv bf16 [B*S, 3H] ; maskbias f32 [B,S] ; ctx bf16 [B*S, H] ; lse f32 [B, A, S]
@@ -398,8 +428,9 @@ int kbner_attn_fwd(const bf16_t* qkv, const float* maskbias, bf16_t* ctx, float*
     if (r) return r;
     once = true;
   }
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3((S + AT_QT - 1) / AT_QT, A, B), dim3(256), AT_LDS_BYTES, (hipStream_t)stream, qkv,
-                     maskbias, ctx, lse, S, H, A, 0.125f);
+  const int rpw = pick_rpw(B, S, A);
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3((S + rpw - 1) / rpw, A, B), dim3(512), AT_LDS_BYTES, (hipStream_t)stream, qkv,
+                     maskbias, ctx, lse, S, H, A, 0.125f, rpw);
   KBNER_LAUNCH_RET();
 }
 
@@ -418,10 +449,12 @@ int kbner_attn_bwd(const bf16_t* qkv, const bf16_t* ctx, const bf16_t* dctx, con
   hipStream_t s = (hipStream_t)stream;
   const int n = B * S * A;
   hipLaunchKernelGGL(attn_rowdot_kernel, dim3((n + 255) / 256), dim3(256), 0, s, dctx, ctx, Dws, B, S, H, A);
-  const dim3 grid((S + AT_QT - 1) / AT_QT, A, B);
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), AT_LDS_BYTES, s, qkv, dctx, maskbias, lse, Dws, dqkv, S, H, A, 0.125f);
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), AT_LDS_BYTES, s, qkv, dctx, maskbias, lse, Dws, dqkv, S, H, A,
-                     0.125f);
+  const int rpw = pick_rpw(B, S, A);
+  const dim3 grid((S + rpw - 1) / rpw, A, B);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(512), AT_LDS_BYTES, s, qkv, dctx, maskbias, lse, Dws, dqkv, S, H, A, 0.125f,
+                     rpw);
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(512), AT_LDS_BYTES, s, qkv, dctx, maskbias, lse, Dws, dqkv, S, H, A,
+                     0.125f, rpw);
   KBNER_LAUNCH_RET();
 }
 

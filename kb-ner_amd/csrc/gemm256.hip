@@ -51,8 +51,17 @@ struct GroupArgs {
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void glb_cvoid;
 
+// LDS-DMA issued from inline asm so the compiler does not see it: with a compiler-visible
+// global_load_lds in flight hipcc (ROCm 7.2) degrades every ds_read wait in the loop to lgkmcnt(0)
+// (mixed pending LGKM event types), which serialises the fragment stream behind full LDS latency.
+// The DMA's completion is ordered by hand: s_waitcnt vmcnt(0) + barrier before the stage is read.
 static __device__ __forceinline__ void glds16(const void* g, void* l) {
-  __builtin_amdgcn_global_load_lds((glb_cvoid*)g, (lds_void*)l, 16, 0, 0);
+  const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void*)l);
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(g), "s"(dst)
+               : "memory");
 }
 static __device__ __forceinline__ int kc_swz(int row) { return (row >> 1) & 7; }
 static __device__ __forceinline__ int ks_swz(int krow) { return (krow & 3) | ((krow >> 1) & 4); }
@@ -144,19 +153,31 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GroupArgs ga) {
       stage256<A_KS>(Ap, lda, m0, (t + 1) * BK2, nxt, wid, lane);
       stage256<B_KS>(Bp, ldb, n0, (t + 1) * BK2, nxt + TILE2_BYTES, wid, lane);
     }
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 bfr[4];
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) bfr[ni] = frag256<B_KS>(cur + TILE2_BYTES, wn * 64 + ni * 16, ks, lane);
-#pragma unroll
-      for (int mi = 0; mi < 8; ++mi) {
-        const bf16x8 af = frag256<A_KS>(cur, wm * 128 + mi * 16, ks, lane);
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af, acc[mi][ni], 0, 0, 0);
-      }
-    }
+    // Software-pipelined fragment stream: the ds_reads of step s+1 are issued BEFORE the 8 MFMAs of step s
+    // (8 steps per K tile = 2 k-steps x 4 row pairs), pinned with sched_barrier so the compiler's counted
+    // lgkmcnt waits only for the fragments the current MFMAs consume.
+#define G2_SB() __builtin_amdgcn_sched_barrier(0)
+#define G2_LOADB(dst, ks)                                                                                     \
+  _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) dst[ni] = frag256<B_KS>(cur + TILE2_BYTES, wn * 64 + ni * 16, ks, lane)
+#define G2_LOADA(dst, ks, pr)                                         \
+  dst[0] = frag256<A_KS>(cur, wm * 128 + (2 * (pr)) * 16, ks, lane);  \
+  dst[1] = frag256<A_KS>(cur, wm * 128 + (2 * (pr) + 1) * 16, ks, lane)
+#define G2_MM(a, b, pr)                                                                                              \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) acc[2 * (pr) + j][ni] = \
+      __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[ni], a[j], acc[2 * (pr) + j][ni], 0, 0, 0)
+    bf16x8 b0[4], b1[4], a0[2], a1[2];
+    G2_LOADB(b0, 0);
+    G2_LOADA(a0, 0, 0);
+    G2_SB();
+    G2_LOADA(a1, 0, 1); G2_SB(); G2_MM(a0, b0, 0); G2_SB();
+    G2_LOADA(a0, 0, 2); G2_SB(); G2_MM(a1, b0, 1); G2_SB();
+    G2_LOADA(a1, 0, 3); G2_SB(); G2_MM(a0, b0, 2); G2_SB();
+    G2_LOADB(b1, 1);
+    G2_LOADA(a0, 1, 0); G2_SB(); G2_MM(a1, b0, 3); G2_SB();
+    G2_LOADA(a1, 1, 1); G2_SB(); G2_MM(a0, b1, 0); G2_SB();
+    G2_LOADA(a0, 1, 2); G2_SB(); G2_MM(a1, b1, 1); G2_SB();
+    G2_LOADA(a1, 1, 3); G2_SB(); G2_MM(a0, b1, 2); G2_SB();
+    G2_MM(a1, b1, 3);
   }
 
   const int epi = g.epi;
