@@ -301,7 +301,7 @@ int kbner_ln_bwd(const bf16_t* dy, const bf16_t* h, const float* mean, const flo
   KBNER_CHECK_ARG(M >= 0 && H > 0 && H % 8 == 0 && H <= 64 * 8 * LN_MAXCH);
   if (M == 0) return 0;
   int grid = ln_grid(M);
-  if (grid > 256) grid = 256;
+  if (grid > 1024) grid = 1024;
   if (H <= 512)
     hipLaunchKernelGGL((ln_bwd_kernel<1, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, h, mean, rstd, gamma, dh,
                        dgamma, dbeta, dbias, nullptr, nullptr, nullptr, nullptr, M, H);
@@ -317,7 +317,7 @@ int kbner_embed_ln_bwd(const bf16_t* dy, const bf16_t* h0, const float* mean, co
   KBNER_CHECK_ARG(M >= 0 && H > 0 && H % 8 == 0 && H <= 64 * 8 * LN_MAXCH);
   if (M == 0) return 0;
   int grid = ln_grid(M);
-  if (grid > 256) grid = 256;
+  if (grid > 1024) grid = 1024;
   if (H <= 512)
     hipLaunchKernelGGL((ln_bwd_kernel<1, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, h0, mean, rstd, gamma,
                        (bf16_t*)nullptr, dgamma, dbeta, dtype0, ids, pos_ids, dword, dpos, M, H);

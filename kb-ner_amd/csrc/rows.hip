@@ -159,21 +159,26 @@ __global__ __launch_bounds__(256) void head_bwd_dw_kernel(const float* __restric
   }
 }
 
-// out[n] += sum_m x[m,n]   (bf16 in, fp32 atomics out).  grid = (ceil(N/512), row chunks)
+// out[n] += sum_m x[m,n]   (bf16 in, fp32 atomics out).  16-byte loads: a thread owns 8 columns and
+// `rows_per_block` rows; grid = (ceil(N/2048), ceil(M/rows_per_block))
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ x, float* __restrict__ out, int M, int N,
                                                      int ld, int rows_per_block) {
-  const int n0 = (blockIdx.x * 256 + threadIdx.x) * 2;
+  const int n0 = (blockIdx.x * 256 + threadIdx.x) * 8;
   if (n0 >= N) return;
   const int r0 = blockIdx.y * rows_per_block;
   const int r1 = min(M, r0 + rows_per_block);
-  float a = 0.0f, b = 0.0f;
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+#pragma unroll 4
   for (int r = r0; r < r1; ++r) {
-    const uint32_t u = *reinterpret_cast<const uint32_t*>(x + (size_t)r * ld + n0);
-    a += __uint_as_float(u << 16);
-    b += __uint_as_float(u & 0xffff0000u);
+    float f[8];
+    unpack8(*reinterpret_cast<const uint4*>(x + (size_t)r * ld + n0), f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] += f[j];
   }
-  atomicAdd(out + n0, a);
-  atomicAdd(out + n0 + 1, b);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) atomicAdd(out + n0 + j, acc[j]);
 }
 
 static inline int rows_grid(int R) {
@@ -222,10 +227,10 @@ int kbner_head_bwd_dw(const float* de, const bf16_t* x, float* dw, float* db, in
 }
 
 int kbner_colsum(const bf16_t* x, float* out, int M, int N, int ld, void* stream) {
-  KBNER_CHECK_ARG(M >= 0 && N > 0 && N % 2 == 0 && ld >= N && ld % 2 == 0);
+  KBNER_CHECK_ARG(M >= 0 && N > 0 && N % 8 == 0 && ld >= N && ld % 8 == 0);
   if (M == 0) return 0;
-  int rpb = 128;
-  hipLaunchKernelGGL(colsum_kernel, dim3((N / 2 + 255) / 256, (M + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream, x, out,
+  int rpb = 64;
+  hipLaunchKernelGGL(colsum_kernel, dim3((N / 8 + 255) / 256, (M + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream, x, out,
                      M, N, ld, rpb);
   KBNER_LAUNCH_RET();
 }
