@@ -85,8 +85,8 @@ int kbner_gemm_bf16(int layout, const kbner_bf16* A, int lda, const kbner_bf16* 
                     const kbner_bf16* aux, int ldaux, kbner_bf16* out2, int ldout2, int epi, int splitk, float alpha,
                     void* stream);
 
-/* Grouped GEMM on the 256x256x64 / 8-wave kernel: up to 8 problems of one layout per launch (the four weight-
- * gradient GEMMs of an encoder layer fill the chip without split-K).  Per problem M,N % 256 == 0, K % 64 == 0. */
+/* Grouped GEMM on the 256x256x64 / 8-wave kernel: up to 16 problems of one layout per launch (the weight-
+ * gradient GEMMs of four encoder layers = 768 tiles fill the chip without split-K).  Per problem M,N % 256 == 0, K % 64 == 0. */
 #define KBNER_EPI_RMW32 32 /* C32 += result by non-atomic 16-byte read-modify-write */
 typedef struct kbner_gemm_problem {
   const kbner_bf16* A;

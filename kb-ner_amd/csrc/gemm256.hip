@@ -18,7 +18,7 @@
 #define EPI_ATOMIC32 16
 #define EPI_RMW32 32  // C32[m,n] += result, non-atomic 16-byte RMW (each output element owned by one lane)
 
-#define G2_MAXP 8
+#define G2_MAXP 16
 
 struct GemmProblem {
   const bf16_t* A;
@@ -40,6 +40,9 @@ struct GemmProblem {
 struct GroupArgs {
   int nprob;
   int total_tiles;
+  int ncu;
+  int pad_;
+  int tile_begin[G2_MAXP];  // compact copy of p[i].tile_begin: one s_load_dwordx16 picks the problem
   GemmProblem p[G2_MAXP];
 };
 
@@ -55,34 +58,46 @@ typedef __attribute__((address_space(1))) const void glb_cvoid;
 // global_load_lds in flight hipcc (ROCm 7.2) degrades every ds_read wait in the loop to lgkmcnt(0)
 // (mixed pending LGKM event types), which serialises the fragment stream behind full LDS latency.
 // The DMA's completion is ordered by hand: s_waitcnt vmcnt(0) + barrier before the stage is read.
-static __device__ __forceinline__ void glds16(const void* g, void* l) {
+// Address form: wave-uniform 64-bit base in SGPRs + per-lane 32-bit byte offset.  The per-lane part is
+// loop-invariant, so only 8 VGPRs (not 8 x 64-bit pointers) stay live across the MFMA loop.
+static __device__ __forceinline__ void glds16(const void* sbase, unsigned voff, void* l) {
   const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void*)l);
   unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                : "=&s"(keep)
-               : "v"(g), "s"(dst)
+               : "v"(voff), "s"(sbase), "s"(dst)
                : "memory");
 }
 static __device__ __forceinline__ int kc_swz(int row) { return (row >> 1) & 7; }
 static __device__ __forceinline__ int ks_swz(int krow) { return (krow & 3) | ((krow >> 1) & 4); }
+// B operand, KC image: a fragment's 16 lanes read rows {8a + 4h + c : a,c in 0..3} of a 32-row block (the column
+// permutation below), so the conflict-free chunk swizzle keys on row bits 4,3 and 1
+static __device__ __forceinline__ int kcb_swz(int row) { return (((row >> 3) & 3) << 1) | ((row >> 1) & 1); }
 
-template <bool KS>
+// Output-column permutation: MFMA fragment ni (0..3) of a wave's 64 columns takes operand row j (= lane & 15) from
+// column (ni>>1)*32 + (j>>2)*8 + (ni&1)*4 + (j&3).  With the operand-swapped MFMA a lane then owns 8 CONTIGUOUS
+// output columns per fragment pair (g*8 .. g*8+7 of each 32-column block): every epilogue access is 16 bytes
+// (dwordx4) instead of 8 -- the row-per-lane store tail is issue-bound, halving the instruction count halves it.
+
+template <bool KS, bool ISB>
 static __device__ __forceinline__ void stage256(const bf16_t* __restrict__ P, int ld, int row0, int k0, unsigned char* s, int wid,
                                                 int lane) {
+  // uniform tile origin in SGPRs
+  const bf16_t* sbase = KS ? P + (size_t)k0 * ld + row0 : P + (size_t)row0 * ld + k0;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int q = wid * 4 + j;  // 32 wave-instructions x 1 KiB = 32 KiB tile
-    const bf16_t* src;
+    unsigned voff;
     if (!KS) {
       const int row = q * 8 + (lane >> 3);
       const int pos = lane & 7;
-      src = P + (size_t)(row0 + row) * ld + k0 + ((pos ^ kc_swz(row)) << 3);
+      voff = (unsigned)(row * ld + ((pos ^ (ISB ? kcb_swz(row) : kc_swz(row))) << 3)) * 2u;
     } else {
       const int kr = q * 2 + (lane >> 5);
       const int pos = lane & 31;
-      src = P + (size_t)(k0 + kr) * ld + row0 + ((pos ^ (ks_swz(kr) << 1)) << 3);
+      voff = (unsigned)(kr * ld + ((pos ^ (ks_swz(kr) << 1)) << 3)) * 2u;
     }
-    glds16(src, s + q * 1024);
+    glds16(sbase, voff, s + q * 1024);
   }
 }
 
@@ -106,6 +121,54 @@ static __device__ __forceinline__ bf16x8 frag256(const unsigned char* s, int r0,
   }
 }
 
+// B-operand fragment ni of the wave whose columns start at c0 (see the permutation note above)
+template <bool KS>
+static __device__ __forceinline__ bf16x8 fragB256(const unsigned char* s, int c0, int ni, int ks, int lane) {
+  if (!KS) {
+    const int j = lane & 15;
+    const int row = c0 + (ni >> 1) * 32 + (j >> 2) * 8 + (ni & 1) * 4 + (j & 3);
+    const int c = ks * 4 + (lane >> 4);
+    const s8v v = *reinterpret_cast<const s8v*>(s + row * 128 + ((c ^ kcb_swz(row)) << 4));
+    return __builtin_bit_cast(bf16x8, v);
+  } else {
+    const int p = lane & 15;
+    const int r = ks * 32 + (lane >> 4) * 8 + (p >> 2);
+    const int col = c0 + (ni >> 1) * 32 + (p & 3) * 8 + (ni & 1) * 4;  // this lane's 4-column piece
+    const unsigned char* a = s + r * 512 + ((((col >> 4) ^ ks_swz(r))) << 5) + ((col & 15) << 1);
+    const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4v __attribute__((address_space(3)))*)(a));
+    const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4v __attribute__((address_space(3)))*)(a + 4 * 512));
+    s8v v;
+    v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+    v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+    return __builtin_bit_cast(bf16x8, v);
+  }
+}
+
+// linear id -> (problem, tile origin).  XCD-aware bijective remap (block b runs on XCD b % 8; persistent ids keep
+// id % 8): each XCD's private L2 sees a contiguous run of tiles, n fastest, so neighbours share the A panel.
+// The problem is picked with static indices only (a runtime-indexed kernarg array would go to scratch).
+static __device__ __forceinline__ void pick_tile(const GroupArgs& ga, int id, int total, GemmProblem& g, int& m0, int& n0) {
+  const int xcd = id & 7;
+  const int q8 = total >> 3, r8 = total & 7;
+  const int wg = ((xcd < r8) ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3);
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < G2_MAXP; ++i)
+    if (wg >= ga.tile_begin[i]) pi = i;  // unused slots hold INT_MAX
+  // the descriptor itself is read from the kernarg segment with a RUNTIME index (scalar loads); selecting it
+  // from by-value kernargs makes hipcc preload all 16 descriptors into ~500 SGPRs and spill them
+#if defined(__HIP_DEVICE_COMPILE__)
+  const GroupArgs* kp = (const GroupArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+  g = kp->p[pi];
+#else
+  g = ga.p[pi];
+#endif
+  const int tile = wg - g.tile_begin;
+  const int tiles_n = g.N / T2;
+  m0 = (tile / tiles_n) * T2;
+  n0 = (tile % tiles_n) * T2;
+}
+
 template <bool A_KS, bool B_KS>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GroupArgs ga) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -114,26 +177,38 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GroupArgs ga) {
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid >> 2, wn = wid & 3;
 
-  // XCD-aware bijective remap (block b runs on XCD b % 8): contiguous tile run per XCD
-  const int nwg = gridDim.x;
-  const int bid = blockIdx.x;
-  const int xcd = bid & 7;
-  const int q8 = nwg >> 3, r8 = nwg & 7;
-  const int wg = ((xcd < r8) ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  // Persistent: this workgroup walks tiles id, id + gridDim.x, ... (grid = min(tiles, #CUs)).  The first K tile
+  // of the NEXT output tile is DMA'd during the last K iteration of the current one, so the epilogue's loads and
+  // stores run under that flight and the next main loop starts without a cold prologue.
+  const int total = ga.total_tiles;
+  int id = blockIdx.x;
+  int it = 0;    // running K-iteration counter: LDS stage parity
+  int pend = 0;  // epilogue stores issued after the DMA that is in flight at a tile boundary
+  {
+    GemmProblem g0;
+    int m00, n00;
+    pick_tile(ga, id, total, g0, m00, n00);
+    stage256<A_KS, false>(g0.A, g0.lda, m00, 0, smem, wid, lane);
+    stage256<B_KS, true>(g0.B, g0.ldb, n00, 0, smem + TILE2_BYTES, wid, lane);
+  }
 
-  // pick this block's problem with static indices only (a runtime-indexed kernarg array would go to scratch)
-  GemmProblem g = ga.p[0];
-#pragma unroll
-  for (int i = 1; i < G2_MAXP; ++i)
-    if (i < ga.nprob && wg >= ga.p[i].tile_begin) g = ga.p[i];
-  const int tile = wg - g.tile_begin;
-  const int tiles_n = g.N / T2;
-  const int tm = tile / tiles_n, tn = tile % tiles_n;
-  const int m0 = tm * T2, n0 = tn * T2;
-  const int nt = g.K / BK2;
-  const bf16_t* __restrict__ Ap = g.A;
-  const bf16_t* __restrict__ Bp = g.B;
-  const int lda = g.lda, ldb = g.ldb;
+  for (;;) {
+  // (the problem descriptor is re-read from kernarg where it is needed -- main loop, next-tile prefetch, epilogue --
+  // instead of being carried in ~30 SGPRs across the MFMA loop, which spilled)
+  int m0, n0, nt, lda, ldb;
+  const bf16_t* __restrict__ Ap;
+  const bf16_t* __restrict__ Bp;
+  {
+    GemmProblem gm;
+    pick_tile(ga, id, total, gm, m0, n0);
+    nt = gm.K / BK2;
+    Ap = gm.A;
+    Bp = gm.B;
+    lda = gm.lda;
+    ldb = gm.ldb;
+  }
+  const int id_next = id + (int)gridDim.x;
+  const bool has_next = id_next < total;
 
   f4v acc[8][4];
 #pragma unroll
@@ -141,24 +216,40 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GroupArgs ga) {
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
 
-  stage256<A_KS>(Ap, lda, m0, 0, smem, wid, lane);
-  stage256<B_KS>(Bp, ldb, n0, 0, smem + TILE2_BYTES, wid, lane);
-
   for (int t = 0; t < nt; ++t) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    unsigned char* cur = smem + (t & 1) * STAGE2_BYTES;
-    if (t + 1 < nt) {
-      unsigned char* nxt = smem + ((t + 1) & 1) * STAGE2_BYTES;
-      stage256<A_KS>(Ap, lda, m0, (t + 1) * BK2, nxt, wid, lane);
-      stage256<B_KS>(Bp, ldb, n0, (t + 1) * BK2, nxt + TILE2_BYTES, wid, lane);
+    // the DMA of this K tile has landed: every wave drains its own pieces (counted: the previous tile's epilogue
+    // stores, younger than that DMA, may still be in flight), then the barrier publishes all of them and fences
+    // the previous iteration's reads of the stage about to be refilled.  Raw s_barrier: __syncthreads() would add a
+    // vmcnt(0) release for the epilogue's global stores.
+    if (t == 0 && pend == 16) {
+      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    } else if (t == 0 && pend == 32) {
+      asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    unsigned char* cur = smem + (it & 1) * STAGE2_BYTES;
+    unsigned char* nxt = smem + ((it + 1) & 1) * STAGE2_BYTES;
+    if (t + 1 < nt) {
+      stage256<A_KS, false>(Ap, lda, m0, (t + 1) * BK2, nxt, wid, lane);
+      stage256<B_KS, true>(Bp, ldb, n0, (t + 1) * BK2, nxt + TILE2_BYTES, wid, lane);
+    } else if (has_next) {
+      GemmProblem gn;
+      int m0n, n0n;
+      pick_tile(ga, id_next, total, gn, m0n, n0n);
+      stage256<A_KS, false>(gn.A, gn.lda, m0n, 0, nxt, wid, lane);
+      stage256<B_KS, true>(gn.B, gn.ldb, n0n, 0, nxt + TILE2_BYTES, wid, lane);
+    }
+    ++it;
     // Software-pipelined fragment stream: the ds_reads of step s+1 are issued BEFORE the 8 MFMAs of step s
     // (8 steps per K tile = 2 k-steps x 4 row pairs), pinned with sched_barrier so the compiler's counted
     // lgkmcnt waits only for the fragments the current MFMAs consume.
 #define G2_SB() __builtin_amdgcn_sched_barrier(0)
 #define G2_LOADB(dst, ks)                                                                                     \
-  _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) dst[ni] = frag256<B_KS>(cur + TILE2_BYTES, wn * 64 + ni * 16, ks, lane)
+  _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) dst[ni] = fragB256<B_KS>(cur + TILE2_BYTES, wn * 64, ni, ks, lane)
 #define G2_LOADA(dst, ks, pr)                                         \
   dst[0] = frag256<A_KS>(cur, wm * 128 + (2 * (pr)) * 16, ks, lane);  \
   dst[1] = frag256<A_KS>(cur, wm * 128 + (2 * (pr) + 1) * 16, ks, lane)
@@ -180,6 +271,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GroupArgs ga) {
     G2_MM(a1, b1, 3);
   }
 
+  GemmProblem g;
+  {
+    int mm, nn;
+    pick_tile(ga, id, total, g, mm, nn);
+  }
   const int epi = g.epi;
   const float alpha = g.alpha;
   const int gq = lane >> 4;
@@ -187,56 +283,81 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GroupArgs ga) {
   for (int mi = 0; mi < 8; ++mi) {
     const int m = m0 + wm * 128 + mi * 16 + (lane & 15);
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-      const int n = n0 + wn * 64 + ni * 16 + gq * 4;
-      float v[4] = {acc[mi][ni][0] * alpha, acc[mi][ni][1] * alpha, acc[mi][ni][2] * alpha, acc[mi][ni][3] * alpha};
+    for (int q = 0; q < 2; ++q) {
+      const int n = n0 + wn * 64 + q * 32 + gq * 8;  // 8 contiguous columns owned by this lane
+      float v[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = acc[mi][2 * q][r] * alpha;
+        v[4 + r] = acc[mi][2 * q + 1][r] * alpha;
+      }
       if (epi & EPI_RMW32) {
         float4* c = reinterpret_cast<float4*>(g.C32 + (size_t)m * g.ldc32 + n);
-        float4 o = *c;
-        o.x += v[0]; o.y += v[1]; o.z += v[2]; o.w += v[3];
-        *c = o;
+        float4 o0 = c[0], o1 = c[1];
+        o0.x += v[0]; o0.y += v[1]; o0.z += v[2]; o0.w += v[3];
+        o1.x += v[4]; o1.y += v[5]; o1.z += v[6]; o1.w += v[7];
+        c[0] = o0;
+        c[1] = o1;
         continue;
       }
       if (epi & EPI_ATOMIC32) {
         float* c = g.C32 + (size_t)m * g.ldc32 + n;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) atomicAdd(c + r, v[r]);
+        for (int r = 0; r < 8; ++r) atomicAdd(c + r, v[r]);
         continue;
       }
       if (epi & EPI_BIAS) {
-        const float4 b = *reinterpret_cast<const float4*>(g.bias + n);
-        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+        const float4 b0 = *reinterpret_cast<const float4*>(g.bias + n);
+        const float4 b1 = *reinterpret_cast<const float4*>(g.bias + n + 4);
+        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+        v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
       }
       if (epi & EPI_ADD) {
-        const uint2 u = *reinterpret_cast<const uint2*>(g.addend + (size_t)m * g.ldadd + n);
-        v[0] += __uint_as_float(u.x << 16);
-        v[1] += __uint_as_float(u.x & 0xffff0000u);
-        v[2] += __uint_as_float(u.y << 16);
-        v[3] += __uint_as_float(u.y & 0xffff0000u);
+        const uint4 u = *reinterpret_cast<const uint4*>(g.addend + (size_t)m * g.ldadd + n);
+        const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[2 * r] += __uint_as_float(w[r] << 16);
+          v[2 * r + 1] += __uint_as_float(w[r] & 0xffff0000u);
+        }
       }
       if (epi & EPI_DGELU) {
-        const uint2 u = *reinterpret_cast<const uint2*>(g.aux + (size_t)m * g.ldaux + n);
-        v[0] *= gelu_grad_f(__uint_as_float(u.x << 16));
-        v[1] *= gelu_grad_f(__uint_as_float(u.x & 0xffff0000u));
-        v[2] *= gelu_grad_f(__uint_as_float(u.y << 16));
-        v[3] *= gelu_grad_f(__uint_as_float(u.y & 0xffff0000u));
+        const uint4 u = *reinterpret_cast<const uint4*>(g.aux + (size_t)m * g.ldaux + n);
+        const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[2 * r] *= gelu_grad_f(__uint_as_float(w[r] << 16));
+          v[2 * r + 1] *= gelu_grad_f(__uint_as_float(w[r] & 0xffff0000u));
+        }
       }
       if (epi & EPI_GELU) {
-        uint2 pu;
+        // the saved pre-activation is the bf16-rounded value; gelu is applied to that same value so
+        // backward's gelu'(pre) sees exactly what forward activated
+        uint4 pu;
         pu.x = pack2bf(v[0], v[1]);
         pu.y = pack2bf(v[2], v[3]);
-        *reinterpret_cast<uint2*>(g.out2 + (size_t)m * g.ldout2 + n) = pu;
-        v[0] = gelu_f(__uint_as_float(pu.x << 16));
-        v[1] = gelu_f(__uint_as_float(pu.x & 0xffff0000u));
-        v[2] = gelu_f(__uint_as_float(pu.y << 16));
-        v[3] = gelu_f(__uint_as_float(pu.y & 0xffff0000u));
+        pu.z = pack2bf(v[4], v[5]);
+        pu.w = pack2bf(v[6], v[7]);
+        *reinterpret_cast<uint4*>(g.out2 + (size_t)m * g.ldout2 + n) = pu;
+        const uint32_t w[4] = {pu.x, pu.y, pu.z, pu.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[2 * r] = gelu_f(__uint_as_float(w[r] << 16));
+          v[2 * r + 1] = gelu_f(__uint_as_float(w[r] & 0xffff0000u));
+        }
       }
-      uint2 o;
+      uint4 o;
       o.x = pack2bf(v[0], v[1]);
       o.y = pack2bf(v[2], v[3]);
-      *reinterpret_cast<uint2*>(g.C + (size_t)m * g.ldc + n) = o;
+      o.z = pack2bf(v[4], v[5]);
+      o.w = pack2bf(v[6], v[7]);
+      *reinterpret_cast<uint4*>(g.C + (size_t)m * g.ldc + n) = o;
     }
   }
+  if (!has_next) break;
+  pend = (epi & EPI_ATOMIC32) ? 0 : ((epi & (EPI_GELU | EPI_RMW32)) ? 32 : 16);
+  id = id_next;
+  }  // persistent tile loop
 }
 
 template <bool A_KS, bool B_KS>
@@ -248,9 +369,21 @@ static int launch256(const GroupArgs& ga, hipStream_t stream) {
     if (e != hipSuccess) return -(int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm256_kernel<A_KS, B_KS>), dim3(ga.total_tiles), dim3(512), 2 * STAGE2_BYTES, stream, ga);
+  const int grid = ga.total_tiles < ga.ncu ? ga.total_tiles : ga.ncu;
+  hipLaunchKernelGGL((gemm256_kernel<A_KS, B_KS>), dim3(grid), dim3(512), 2 * STAGE2_BYTES, stream, ga);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
+}
+
+static int device_cu_count() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
 }
 
 // public mirror of GemmProblem (include/kbner.h: kbner_gemm_problem)
@@ -271,7 +404,7 @@ struct kbner_gemm_problem {
 
 extern "C" {
 
-// Grouped GEMM: nprob (1..8) problems of the SAME layout in one launch.
+// Grouped GEMM: nprob (1..16) problems of the SAME layout in one launch.
 // Constraints per problem: M % 256 == 0, N % 256 == 0, K % 64 == 0, lda/ldb % 8 == 0.
 int kbner_gemm_bf16_grouped(int layout, int nprob, const kbner_gemm_problem* probs, void* stream) {
   KBNER_CHECK_ARG(layout >= 0 && layout <= 2 && nprob >= 1 && nprob <= G2_MAXP && probs != nullptr);
@@ -285,23 +418,27 @@ int kbner_gemm_bf16_grouped(int layout, int nprob, const kbner_gemm_problem* pro
     if (s.epi & (EPI_ATOMIC32 | EPI_RMW32)) {
       KBNER_CHECK_ARG(s.C32 != nullptr && s.ldc32 >= s.N && s.ldc32 % 4 == 0);
     } else {
-      KBNER_CHECK_ARG(s.C != nullptr && s.ldc >= s.N && s.ldc % 4 == 0);
+      KBNER_CHECK_ARG(s.C != nullptr && s.ldc >= s.N && s.ldc % 8 == 0);
     }
     if (s.epi & EPI_BIAS) KBNER_CHECK_ARG(s.bias != nullptr);
-    if (s.epi & EPI_ADD) KBNER_CHECK_ARG(s.addend != nullptr && s.ldadd % 4 == 0);
-    if (s.epi & EPI_DGELU) KBNER_CHECK_ARG(s.aux != nullptr && s.ldaux % 4 == 0);
-    if (s.epi & EPI_GELU) KBNER_CHECK_ARG(s.out2 != nullptr && s.ldout2 % 4 == 0);
+    if (s.epi & EPI_ADD) KBNER_CHECK_ARG(s.addend != nullptr && s.ldadd % 8 == 0);
+    if (s.epi & EPI_DGELU) KBNER_CHECK_ARG(s.aux != nullptr && s.ldaux % 8 == 0);
+    if (s.epi & EPI_GELU) KBNER_CHECK_ARG(s.out2 != nullptr && s.ldout2 % 8 == 0);
     GemmProblem& d = ga.p[i];
     d.A = s.A; d.B = s.B; d.C = s.C; d.C32 = s.C32; d.bias = s.bias; d.addend = s.addend; d.aux = s.aux; d.out2 = s.out2;
     d.M = s.M; d.N = s.N; d.K = s.K; d.lda = s.lda; d.ldb = s.ldb; d.ldc = s.ldc; d.ldc32 = s.ldc32; d.ldadd = s.ldadd;
     d.ldaux = s.ldaux; d.ldout2 = s.ldout2; d.epi = s.epi; d.alpha = s.alpha; d.tile_begin = tiles; d.pad_ = 0;
+    ga.tile_begin[i] = tiles;
     tiles += (s.M / T2) * (s.N / T2);
   }
   for (int i = nprob; i < G2_MAXP; ++i) {
     ga.p[i] = ga.p[0];
     ga.p[i].tile_begin = 0x7fffffff;
+    ga.tile_begin[i] = 0x7fffffff;
   }
   ga.total_tiles = tiles;
+  ga.ncu = device_cu_count();
+  ga.pad_ = 0;
   hipStream_t st = (hipStream_t)stream;
   switch (layout) {
     case 0: return launch256<false, false>(ga, st);

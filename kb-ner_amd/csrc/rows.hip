@@ -159,26 +159,35 @@ __global__ __launch_bounds__(256) void head_bwd_dw_kernel(const float* __restric
   }
 }
 
-// out[n] += sum_m x[m,n]   (bf16 in, fp32 atomics out).  16-byte loads: a thread owns 8 columns and
-// `rows_per_block` rows; grid = (ceil(N/2048), ceil(M/rows_per_block))
+// out[n] += sum_m x[m,n]   (bf16 in, fp32 atomics out).  Block = 64 column-threads (16-byte loads, 512 columns)
+// x 4 row-threads; the 4 row partials are combined in LDS so a block issues one atomic per column.
+// grid = (ceil(N/512), ceil(M/rows_per_block))
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ x, float* __restrict__ out, int M, int N,
                                                      int ld, int rows_per_block) {
-  const int n0 = (blockIdx.x * 256 + threadIdx.x) * 8;
-  if (n0 >= N) return;
+  __shared__ float red[4][512];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int n0 = (blockIdx.x * 64 + tx) * 8;
   const int r0 = blockIdx.y * rows_per_block;
   const int r1 = min(M, r0 + rows_per_block);
   float acc[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+  if (n0 < N) {
 #pragma unroll 4
-  for (int r = r0; r < r1; ++r) {
-    float f[8];
-    unpack8(*reinterpret_cast<const uint4*>(x + (size_t)r * ld + n0), f);
+    for (int r = r0 + ty; r < r1; r += 4) {
+      float f[8];
+      unpack8(*reinterpret_cast<const uint4*>(x + (size_t)r * ld + n0), f);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] += f[j];
+      for (int j = 0; j < 8; ++j) acc[j] += f[j];
+    }
   }
 #pragma unroll
-  for (int j = 0; j < 8; ++j) atomicAdd(out + n0 + j, acc[j]);
+  for (int j = 0; j < 8; ++j) red[ty][tx * 8 + j] = acc[j];
+  __syncthreads();
+  for (int c = threadIdx.x; c < 512; c += 256) {
+    const int n = blockIdx.x * 512 + c;
+    if (n < N) atomicAdd(out + n, (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]));
+  }
 }
 
 static inline int rows_grid(int R) {
@@ -229,8 +238,8 @@ int kbner_head_bwd_dw(const float* de, const bf16_t* x, float* dw, float* db, in
 int kbner_colsum(const bf16_t* x, float* out, int M, int N, int ld, void* stream) {
   KBNER_CHECK_ARG(M >= 0 && N > 0 && N % 8 == 0 && ld >= N && ld % 8 == 0);
   if (M == 0) return 0;
-  int rpb = 64;
-  hipLaunchKernelGGL(colsum_kernel, dim3((N / 8 + 255) / 256, (M + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream, x, out,
+  int rpb = 128;
+  hipLaunchKernelGGL(colsum_kernel, dim3((N + 511) / 512, (M + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream, x, out,
                      M, N, ld, rpb);
   KBNER_LAUNCH_RET();
 }

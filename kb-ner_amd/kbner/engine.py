@@ -182,14 +182,19 @@ class _Acts:
         self.st1 = [(z(Mp, dt=F32), z(Mp, dt=F32)) for _ in range(L)]
         self.st2 = [(z(Mp, dt=F32), z(Mp, dt=F32)) for _ in range(L)]
         # backward workspaces (shared across layers)
+        # dY buffers are kept for WGRAD_GROUP layers so their weight-gradient GEMMs can be launched
+        # together (4 layers x 4 GEMMs = 768 tiles of 256x256 = 3 full waves of the 256 CUs)
         self.dx = z(Mp, H)
-        self.dh = z(Mp, H)
         self.dx1 = z(Mp, H)
-        self.dh1 = z(Mp, H)
-        self.dpre = z(Mp, F_)
         self.dctx = z(Mp, H)
-        self.dqkv = z(Mp, 3 * H)
+        self.dh = [z(Mp, H) for _ in range(WGRAD_GROUP)]
+        self.dh1 = [z(Mp, H) for _ in range(WGRAD_GROUP)]
+        self.dpre = [z(Mp, F_) for _ in range(WGRAD_GROUP)]
+        self.dqkv = [z(Mp, 3 * H) for _ in range(WGRAD_GROUP)]
         self.dws = z(B, A, S, dt=F32)
+
+
+WGRAD_GROUP = 4
 
 
 def _splitk(tiles, Mp):
@@ -310,45 +315,48 @@ class Tagger:
         ac = self.acts(B, S)
         Mp = ac.Mp
         dx = dx_top
+        pending = []
         for l in range(L - 1, -1, -1):
             p = "l%d." % l
+            r = l % WGRAD_GROUP
+            dh, dh1, dpre, dqkv = ac.dh[r], ac.dh1[r], ac.dpre[r], ac.dqkv[r]
             # LN2 backward; fused: d ffn2.bias = column sums of dh
-            ops.ln_bwd(dx, ac.h2[l], ac.st2[l][0], ac.st2[l][1], a.param(p + "ln2.g"), ac.dh, a.grad(p + "ln2.g"),
+            ops.ln_bwd(dx, ac.h2[l], ac.st2[l][0], ac.st2[l][1], a.param(p + "ln2.g"), dh, a.grad(p + "ln2.g"),
                        a.grad(p + "ln2.b"), a.grad(p + "ffn2.bias"))
-            # FFN down: wgrad dW2[H,F] += dh^T act ; dgrad dpre = (dh W2) * gelu'(pre)
-            ops.gemm(GEMM_NN, ac.dh, a.bf(p + "ffn2.weight"), Mp, F_, H, C=ac.dpre, aux=ac.pre[l], epi=EPI_DGELU)
+            # FFN down dgrad: dpre = (dh W2) * gelu'(pre)
+            ops.gemm(GEMM_NN, dh, a.bf(p + "ffn2.weight"), Mp, F_, H, C=dpre, aux=ac.pre[l], epi=EPI_DGELU)
             # FFN up
-            ops.colsum(ac.dpre, a.grad(p + "ffn1.bias"))
-            ops.gemm(GEMM_NN, ac.dpre, a.bf(p + "ffn1.weight"), Mp, H, F_, C=ac.dx1, addend=ac.dh, epi=EPI_ADD)
+            ops.colsum(dpre, a.grad(p + "ffn1.bias"))
+            ops.gemm(GEMM_NN, dpre, a.bf(p + "ffn1.weight"), Mp, H, F_, C=ac.dx1, addend=dh, epi=EPI_ADD)
             # LN1 backward; fused: d o.bias
-            ops.ln_bwd(ac.dx1, ac.h1[l], ac.st1[l][0], ac.st1[l][1], a.param(p + "ln1.g"), ac.dh1, a.grad(p + "ln1.g"),
+            ops.ln_bwd(ac.dx1, ac.h1[l], ac.st1[l][0], ac.st1[l][1], a.param(p + "ln1.g"), dh1, a.grad(p + "ln1.g"),
                        a.grad(p + "ln1.b"), a.grad(p + "o.bias"))
             # attention output projection
-            ops.gemm(GEMM_NN, ac.dh1, a.bf(p + "o.weight"), Mp, H, H, C=ac.dctx)
+            ops.gemm(GEMM_NN, dh1, a.bf(p + "o.weight"), Mp, H, H, C=ac.dctx)
             # attention core
-            ops.attn_bwd(ac.qkv[l], ac.ctx[l], ac.dctx, maskbias, ac.lse[l], ac.dws, ac.dqkv, B, S, H, A)
+            ops.attn_bwd(ac.qkv[l], ac.ctx[l], ac.dctx, maskbias, ac.lse[l], ac.dws, dqkv, B, S, H, A)
             # QKV projection
-            ops.colsum(ac.dqkv, a.grad(p + "qkv.bias"))
-            ops.gemm(GEMM_NN, ac.dqkv, a.bf(p + "qkv.weight"), Mp, H, 3 * H, C=ac.dx, addend=ac.dh1, epi=EPI_ADD)
-            # the layer's four weight gradients dW += dY^T X in ONE grouped launch (no split-K, no atomics):
-            # every dY / X of this layer is still live here (the work buffers are only reused by layer l-1)
-            self._wgrads(l, ac)
+            ops.colsum(dqkv, a.grad(p + "qkv.bias"))
+            ops.gemm(GEMM_NN, dqkv, a.bf(p + "qkv.weight"), Mp, H, 3 * H, C=ac.dx, addend=dh1, epi=EPI_ADD)
+            # weight gradients dW += dY^T X are deferred and launched for WGRAD_GROUP layers at once
+            # (no split-K, no atomics; the dY buffers rotate so they stay live until the group is flushed)
+            pending += [(dh, ac.act[l], H, F_, p + "ffn2.weight"), (dpre, ac.x1[l], F_, H, p + "ffn1.weight"),
+                        (dh1, ac.ctx[l], H, H, p + "o.weight"), (dqkv, ac.x[l], 3 * H, H, p + "qkv.weight")]
+            if l % WGRAD_GROUP == 0:
+                self._wgrads(pending, Mp)
+                pending = []
             dx = ac.dx
         ops.embed_ln_bwd(dx, ac.h0, ac.emb_mean, ac.emb_rstd, a.param("emb.ln.g"), ids, pos_ids, a.grad("emb.ln.g"),
                          a.grad("emb.ln.b"), a.grad("emb.word"), a.grad("emb.pos"), a.grad("emb.type")[0])
 
-    def _wgrads(self, l, ac):
-        cfg, a = self.cfg, self.arena
-        H, F_, Mp = cfg.hidden_size, cfg.intermediate_size, ac.Mp
-        p = "l%d." % l
-        pairs = [(ac.dh, ac.act[l], H, F_, "ffn2.weight"), (ac.dpre, ac.x1[l], F_, H, "ffn1.weight"),
-                 (ac.dh1, ac.ctx[l], H, H, "o.weight"), (ac.dqkv, ac.x[l], 3 * H, H, "qkv.weight")]
+    def _wgrads(self, pairs, Mp):
+        a = self.arena
         if all(n_ % 256 == 0 and k_ % 256 == 0 for _, _, n_, k_, _ in pairs):
-            ops.gemm_grouped(GEMM_TN, [ops.make_problem(dy, x, n_, k_, Mp, C32=a.grad(p + nm), epi=EPI_RMW32)
+            ops.gemm_grouped(GEMM_TN, [ops.make_problem(dy, x, n_, k_, Mp, C32=a.grad(nm), epi=EPI_RMW32)
                                        for dy, x, n_, k_, nm in pairs])
         else:
             for dy, x, n_, k_, nm in pairs:
-                ops.gemm(GEMM_TN, dy, x, n_, k_, Mp, C32=a.grad(p + nm), epi=EPI_ATOMIC32,
+                ops.gemm(GEMM_TN, dy, x, n_, k_, Mp, C32=a.grad(nm), epi=EPI_ATOMIC32,
                          splitk=_splitk((n_ // 128) * (k_ // 128), Mp))
 
     # ---------------------------------------------------------------- tagger head

@@ -136,7 +136,7 @@ def make_problem(A, B, M, N, K, C=None, C32=None, bias=None, addend=None, aux=No
 
 
 def gemm_grouped(layout, problems):
-    """problems: list (<= 8) of L.GemmProblem (make_problem) of one layout; 256x256x64 8-wave kernel."""
+    """problems: list (<= 16) of L.GemmProblem (make_problem) of one layout; 256x256x64 8-wave kernel."""
     n = len(problems)
     arr = (L.GemmProblem * n)(*problems)
     hook = GEMM_HOOK

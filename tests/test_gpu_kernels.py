@@ -32,6 +32,9 @@ def test_probe_mfma_layout(st):
     (0, 256, 256, 64, 0, 1), (0, 512, 768, 320, 1 | 4, 1), (0, 512, 256, 128, 1 | 2, 1), (1, 256, 256, 64, 0, 1),
     (1, 512, 768, 320, 8, 1), (1, 768, 256, 256, 4, 1), (2, 256, 256, 64, 32, 1), (2, 512, 768, 1024, 32, 1),
     (2, 256, 512, 320, 16, 1),
+    # persistent path: more tiles than CUs (tile-boundary prefetch + counted vmcnt over the epilogue stores)
+    (0, 4096, 5120, 128, 1 | 2, 1), (0, 8192, 2560, 192, 1 | 4, 1), (1, 4096, 5120, 128, 8, 1), (1, 5120, 4096, 64, 4, 1),
+    (2, 5120, 4096, 128, 32, 1), (2, 4096, 5120, 64, 16, 1), (0, 16384, 4096, 64, 0, 1),
 ])
 def test_gemm(st, layout, M, N, K, epi, sk):
     # tolerance: bf16 output rounding (2^-9 relative per element) on fp32-accumulated products
