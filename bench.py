@@ -29,6 +29,20 @@ def encoder_flops_per_sentence(cfg, S):
     return L * (6 * S * H * H + 2 * S * H * H + 16 * S * H * H + 4 * S * S * H)
 
 
+def host_threads():
+    """Threads for the CPU leg: the container's CPU quota (cgroup v2 cpu.max) when there is one -- the GPU box
+    exposes 256 logical CPUs under a 16-CPU quota, where 256 threads run 100x slower than 32 -- else the affinity
+    mask; 2 threads per quota CPU measured best for torch's GEMMs (tools/cpu_probe.py)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(2 * int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 64))
+
+
 def cpu_baseline(args, cfg_kw, T, tags):
     """The oracle's fp32 torch-CPU restatement of the same step, timed on this box's host cores on a
     bounded sample (kind 'port').  Only rank 0 at N=1."""
@@ -38,7 +52,7 @@ def cpu_baseline(args, cfg_kw, T, tags):
     from oracle import encoder as oenc
     from oracle import train_step as ots
     start, stop, x_idx = tags
-    ncores = os.cpu_count() or 1
+    ncores = host_threads()
     torch.set_num_threads(ncores)
     ocfg = oenc.EncoderConfig(**cfg_kw)
     Bc = args.cpu_sentences
