@@ -49,6 +49,8 @@ int kbner_crf_nll_bwd(const float* emit, const float* trans, const int* tags, co
 /* first-subtoken pooling + assign_batch_features (flair/embeddings.py:3288-3345,108-124) and the remove_x
  * compaction loop (sequence_tagger_model.py:2474-2488) as ONE gather: out[r] = idx[r] >= 0 ? src[idx[r]] : 0 */
 int kbner_gather_rows(const kbner_bf16* src, const int* idx, kbner_bf16* out, int R, int H, void* stream);
+/* fp32 variant for the evaluation path: emissions [B*n,T] -> the rows _obtain_labels decodes (sequence_tagger_model.py:1198-1200) */
+int kbner_gather_rows_f32(const float* src, const int* idx, float* out, int R, int W, void* stream);
 /* its backward (unique indices; caller zero-fills dsrc) */
 int kbner_scatter_rows(const kbner_bf16* dout, const int* idx, kbner_bf16* dsrc, int R, int H, void* stream);
 /* self.linear, sequence_tagger_model.py:1027: out f32[R,T] = x bf16[R,H] . w f32[T,H]^T + bias */

@@ -245,3 +245,21 @@ int kbner_colsum(const bf16_t* x, float* out, int M, int N, int ld, void* stream
 }
 
 }  // extern "C"
+
+// fp32 row gather (evaluation path: compaction of the [B*n, T] emissions to the non-S-X rows before Viterbi / CRF loss):
+// out[r,:] = idx[r] >= 0 ? src[idx[r],:] : 0
+__global__ __launch_bounds__(256) void gather_rows_f32_kernel(const float* __restrict__ src, const int* __restrict__ idx,
+                                                              float* __restrict__ out, int R, int W) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= R * W) return;
+  const int r = i / W, c = i % W;
+  const int s = idx[r];
+  out[i] = s >= 0 ? src[(size_t)s * W + c] : 0.0f;
+}
+
+extern "C" int kbner_gather_rows_f32(const float* src, const int* idx, float* out, int R, int W, void* stream) {
+  KBNER_CHECK_ARG(R >= 0 && W > 0);
+  if (R == 0) return 0;
+  hipLaunchKernelGGL(gather_rows_f32_kernel, dim3((R * W + 255) / 256), dim3(256), 0, (hipStream_t)stream, src, idx, out, R, W);
+  KBNER_LAUNCH_RET();
+}

@@ -1,0 +1,292 @@
+"""Embeddings surface of the tagger path: Embeddings / TokenEmbeddings / StackedEmbeddings / TransformerWordEmbeddings.
+
+Behavioural reference (restated): flair/embeddings.py -- Embeddings.embed (:75-101), StackedEmbeddings (:155-211),
+TransformerWordEmbeddings (:2906-3907): tokenizer + encoder loaded from a directory, `<EOS>` word tokens replaced by the
+tokenizer's eos string before sub-tokenisation (:3139-3163), sub-token counts per word token recovered by re-assembling
+sub-token text (:3347-3408), counts clamped to `maximum_subtoken_length` (:3182-3195), `<s> ids </s>` framing with
+`begin_offset = 1` (:3202-3227), ids AND mask padded with 0 (:3247-3260), first-sub-token pooling of the LAST layer
+(:3288-3345) with zero vectors for word tokens that received no sub-token (:3306-3308).
+
+Difference by design: nothing numeric happens here.  The reference runs the HF encoder inside this class and bounces
+[B,n,H] features through the CPU; here the class only produces the INTEGER batch (ids, mask, first-sub-token index) and
+the encoder itself lives in the tagger's HIP engine (kbner.engine.Tagger), which keeps hidden states on the device.
+Only the configuration the KB-NER YAMLs use is implemented: layers '-1', pooling_operation 'first', single 512 window
+(inputs are cut to <= 510 sub-tokens at data-generation time, kb/context_process.py:974); anything else raises."""
+import json
+import logging
+import os
+import re
+from typing import List
+
+import numpy as np
+import torch
+
+import flair
+
+log = logging.getLogger("flair")
+
+
+class Embeddings(torch.nn.Module):
+    @property
+    def embedding_length(self) -> int:
+        raise NotImplementedError
+
+    @property
+    def embedding_type(self) -> str:
+        return "word-level"
+
+    def embed(self, sentences, embedding_mask=None):
+        if not isinstance(sentences, list) and not hasattr(sentences, "features"):
+            sentences = [sentences]
+        self._add_embeddings_internal(sentences)
+        return sentences
+
+    def _add_embeddings_internal(self, sentences):
+        raise NotImplementedError
+
+
+class TokenEmbeddings(Embeddings):
+    pass
+
+
+class StackedEmbeddings(TokenEmbeddings):
+    def __init__(self, embeddings: List[TokenEmbeddings], gpu_friendly=False):
+        super().__init__()
+        self.embeddings = embeddings
+        for i, e in enumerate(embeddings):
+            self.add_module("list_embedding_%d" % i, e)
+        self.name = "Stack"
+        self.static_embeddings = all(getattr(e, "static_embeddings", False) for e in embeddings)
+        self.gpu_friendly = gpu_friendly
+
+    @property
+    def embedding_length(self) -> int:
+        return sum(e.embedding_length for e in self.embeddings)
+
+    def embed(self, sentences, static_embeddings: bool = True, embedding_mask=None):
+        if not isinstance(sentences, list) and not hasattr(sentences, "features"):
+            sentences = [sentences]
+        for e in self.embeddings:
+            e.embed(sentences)
+        return sentences
+
+    def _add_embeddings_internal(self, sentences):
+        for e in self.embeddings:
+            e._add_embeddings_internal(sentences)
+        return sentences
+
+    def __str__(self):
+        return "StackedEmbeddings [%s]" % ",".join(str(e) for e in self.embeddings)
+
+
+class _EncoderHandle:
+    """What train.py / the trainer touch on `embedding.model`: `.config`, `.save_pretrained(dir)`, `.to()`, `.eval()`.
+    Weights are held as a HF-named state dict until the tagger moves them into its arena; afterwards `source` points at
+    the live engine so save_pretrained writes the CURRENT fine-tuned weights."""
+
+    def __init__(self, config, state_dict):
+        self.config = config
+        self._state_dict = state_dict
+        self.source = None  # kbner.engine.Tagger once attached
+
+    def state_dict(self):
+        if self.source is not None:
+            return {k: v.detach().float().cpu() for k, v in self.source.hf_state_dict().items()}
+        return self._state_dict
+
+    def save_pretrained(self, save_directory):
+        os.makedirs(save_directory, exist_ok=True)
+        cfg = self.config.to_dict() if hasattr(self.config, "to_dict") else dict(self.config)
+        with open(os.path.join(save_directory, "config.json"), "w") as f:
+            json.dump(cfg, f, indent=2, sort_keys=True, default=str)
+        sd = {"roberta." + k if False else k: v.contiguous() for k, v in self.state_dict().items()}
+        try:
+            from safetensors.torch import save_file
+            save_file(sd, os.path.join(save_directory, "model.safetensors"), metadata={"format": "pt"})
+        except Exception:
+            torch.save(sd, os.path.join(save_directory, "pytorch_model.bin"))
+
+    def to(self, *a, **k):
+        return self
+
+    def eval(self):
+        return self
+
+    def train(self, mode=True):
+        return self
+
+
+def _load_hf_dir(model_dir):
+    """(config, HF-named fp32 state dict) from a local HF directory: config.json + model.safetensors | pytorch_model.bin."""
+    from transformers import AutoConfig
+    config = AutoConfig.from_pretrained(model_dir)
+    st = os.path.join(model_dir, "model.safetensors")
+    if os.path.exists(st):
+        from safetensors.torch import load_file
+        sd = load_file(st)
+    else:
+        sd = torch.load(os.path.join(model_dir, "pytorch_model.bin"), map_location="cpu", weights_only=True)
+    out = {}
+    for k, v in sd.items():
+        for pre in ("roberta.", "xlm_roberta.", "bert."):
+            if k.startswith(pre):
+                k = k[len(pre):]
+        out[k] = v.float()
+    return config, out
+
+
+class TransformerWordEmbeddings(TokenEmbeddings):
+    def __init__(self, model: str = "xlm-roberta-large", layers: str = "-1", pooling_operation: str = "first", batch_size: int = 1,
+                 use_scalar_mix: bool = False, fine_tune: bool = False, allow_long_sentences: bool = True, stride: int = -1,
+                 maximum_window: bool = False, document_extraction: bool = False, embedding_name: str = None,
+                 doc_batch_size: int = 32, maximum_subtoken_length: int = 999, v2_doc: bool = False, ext_doc: bool = False,
+                 sentence_feat: bool = False, use_internal_doc: bool = False, **kwargs):
+        super().__init__()
+        os.environ["TOKENIZERS_PARALLELISM"] = "false"
+        if not os.path.isdir(model):
+            raise FileNotFoundError("TransformerWordEmbeddings(model=%r): a local HF directory is required (no network); it must "
+                                    "hold the tokenizer files, config.json and model.safetensors / pytorch_model.bin" % model)
+        if [int(x) for x in str(layers).split(",")] != [-1] or pooling_operation != "first" or use_scalar_mix:
+            raise NotImplementedError("only layers='-1', pooling_operation='first' (the KB-NER configs) are on the MI355X path")
+        if document_extraction or v2_doc or ext_doc or sentence_feat:
+            raise NotImplementedError("document-level variants are outside the hot path (SURVEY.md §8f-3)")
+        from transformers import AutoTokenizer
+        self.tokenizer = AutoTokenizer.from_pretrained(model, **kwargs)
+        config, sd = _load_hf_dir(model)
+        self.model = _EncoderHandle(config, sd)
+        self.name = str(model) if embedding_name is None else embedding_name
+        self.layer_indexes = [-1]
+        self.pooling_operation = pooling_operation
+        self.use_scalar_mix = False
+        self.fine_tune = fine_tune
+        self.static_embeddings = not fine_tune
+        self.batch_size = batch_size
+        self.sentence_feat = False
+        self.use_internal_doc = use_internal_doc
+        self.allow_long_sentences = allow_long_sentences
+        self.max_subtokens_sequence_length = min(512, int(getattr(self.tokenizer, "model_max_length", 512) or 512))
+        self.stride = self.max_subtokens_sequence_length // 2 if allow_long_sentences else 0
+        self.begin_offset = 1
+        self.maximum_subtoken_length = maximum_subtoken_length
+        bos = getattr(self.tokenizer, "bos_token", None) or getattr(self.tokenizer, "cls_token", None)
+        eos = getattr(self.tokenizer, "eos_token", None) or getattr(self.tokenizer, "sep_token", None)
+        if bos is None or eos is None:
+            raise ValueError("tokenizer needs bos/cls and eos/sep tokens")
+        self._bos_id = self.tokenizer.convert_tokens_to_ids(bos)
+        self._eos_id = self.tokenizer.convert_tokens_to_ids(eos)
+        self._eos_text = eos
+        self.special_tokens = [t for t in (bos, getattr(self.tokenizer, "cls_token", None)) if t]
+        self._hidden = int(config.hidden_size)
+
+    @property
+    def embedding_length(self) -> int:
+        return self._hidden
+
+    # ------------------------------------------------------------------ tokenisation (host, integers only)
+    @staticmethod
+    def _strip_markup(piece: str) -> str:
+        """drop the word-boundary markers sub-word tokenizers prepend / append (sentencepiece, BERT, byte-level BPE, XLM)"""
+        for pre in ("Ġ", "##", "▁"):
+            if piece.startswith(pre):
+                piece = piece[len(pre):]
+        return piece[:-4] if piece.endswith("</w>") else piece
+
+    def _token_text(self, token) -> str:
+        """the word token as the tokenizer spells it (its own pieces re-joined, lower-cased): unknown / normalised
+        characters then compare equal between the per-token and the per-sentence tokenisation (embeddings.py:3103-3109)"""
+        return "".join(self._strip_markup(p) for p in self.tokenizer.tokenize(token.text)).lower()
+
+    def reconstruct_tokens_from_subtokens(self, tokens, subtokens) -> List[int]:
+        """Sub-token count per word token, by re-assembling sub-token text against the word tokens in order.
+        A word token the tokenizer dropped entirely gets 0 (it will pool to a zero vector)."""
+        texts = [self._token_text(t) for t in tokens]
+        counts: List[int] = []
+        ti, acc, cnt = 0, "", 0
+        for si, piece in enumerate(subtokens):
+            if ti >= len(texts):
+                break
+            piece = self._strip_markup(piece)
+            if si == 0 and piece in self.special_tokens:
+                continue
+            low = piece.lower()
+            if cnt == 0 and not texts[ti].startswith(low):
+                # the tokenizer skipped one or more word tokens: give them 0 pieces and resynchronise
+                while ti < len(texts) and not texts[ti].startswith(low):
+                    counts.append(0)
+                    ti += 1
+                if ti >= len(texts):
+                    break
+            cnt += 1
+            acc += low
+            if acc == texts[ti]:
+                counts.append(cnt)
+                ti, acc, cnt = ti + 1, "", 0
+        while len(counts) < len(texts):
+            counts.append(cnt if cnt and len(counts) == ti else 0)
+            cnt = 0
+        return counts
+
+    def tokenize_sentence(self, sentence):
+        """-> (ids incl. <s>/</s>, first_idx per word token (-1 = no sub-token))"""
+        words = [self._eos_text if t.text == "<EOS>" else t.text for t in sentence]
+        text = " ".join(words)
+        pieces = self.tokenizer.tokenize(text)
+
+        class _W:  # word tokens with <EOS> already substituted, as the reference deep-copies and rewrites them
+            def __init__(self, s):
+                self.text = s
+
+        counts = self.reconstruct_tokens_from_subtokens([_W(w) for w in words], pieces)
+        if any(c > self.maximum_subtoken_length for c in counts):
+            kept, pos = [], 0
+            for c in counts:
+                kept += pieces[pos:pos + min(c, self.maximum_subtoken_length)]
+                pos += c
+            pieces = kept
+            counts = [min(c, self.maximum_subtoken_length) for c in counts]
+        ids = self.tokenizer.convert_tokens_to_ids(pieces)
+        budget = self.max_subtokens_sequence_length - 2
+        if len(ids) > budget:
+            raise NotImplementedError("sentence of %d sub-tokens exceeds the single %d window; the sliding-window path "
+                                      "(flair/embeddings.py:3203-3227,3292-3299) is not on the MI355X hot path yet"
+                                      % (len(ids), self.max_subtokens_sequence_length))
+        first, pos = [], self.begin_offset
+        for c in counts:
+            first.append(pos if c > 0 else -1)
+            pos += c
+        return [self._bos_id] + list(ids) + [self._eos_id], first
+
+    def prepare_batch(self, sentences):
+        """numpy integer batch: input_ids / attention_mask [B,S0] (padded with 0 like the reference), first_idx [B,n] (-1 pad),
+        lengths [B]."""
+        toks = [self.tokenize_sentence(s) for s in sentences]
+        B = len(toks)
+        S0 = max(len(t[0]) for t in toks)
+        n = max(len(s) for s in sentences)
+        ids = np.zeros((B, S0), np.int64)
+        am = np.zeros((B, S0), np.int64)
+        first = np.full((B, n), -1, np.int64)
+        lengths = np.zeros(B, np.int64)
+        for b, (i, f) in enumerate(toks):
+            ids[b, :len(i)] = i
+            am[b, :len(i)] = 1
+            first[b, :len(f)] = f
+            lengths[b] = len(sentences[b])
+        return ids, am, first, lengths
+
+    def _add_embeddings_internal(self, sentences):
+        """stores the integer batch on the BatchedData (or returns it); the tagger's engine turns it into features"""
+        batch = self.prepare_batch(sentences)
+        if hasattr(sentences, "features"):
+            sentences.features[self.name] = batch
+        return sentences
+
+    def train(self, mode=True):
+        self.training = bool(mode) and self.fine_tune
+        return self
+
+    def extra_repr(self):
+        return "model=%s" % self.name
+
+    def __str__(self):
+        return self.name

@@ -1,0 +1,333 @@
+"""SequenceTagger / FastSequenceTagger on the MI355X engine: XLM-R encoder -> first-sub-token gather -> linear emissions
+-> linear-chain CRF (forward-algorithm loss, Viterbi decode), `use_rnn: false`, `use_crf: true`, `remove_x` honoured.
+
+Behavioural reference (restated): flair/models/sequence_tagger_model.py -- constructor keywords (:100-163), transitions
+[to,from] with START row / STOP column = -1e12 (:402-410), forward (:844-1052), forward_loss (:1899-1921),
+_calculate_loss incl. remove_x (:2426-2506), _obtain_labels incl. S-X re-padding (:1157-1246), evaluate (:2593-2729:
+"token gold pred score" lines, span TP/FP/FN on (tag, str(span)) with the remove_x post-filter :2653-2672), state dict
+(:435-477).  All arithmetic runs in libkbner_hip.so through kbner.engine.Tagger; there is no torch autograd graph:
+`forward_backward` is the training entry point (forward + explicit backward into the gradient arena)."""
+import logging
+from pathlib import Path
+from typing import List
+
+import numpy as np
+import torch
+
+import flair
+import flair.nn
+from flair.data import Dictionary, Label, Sentence
+from flair.training_utils import Metric, Result, store_embeddings
+
+log = logging.getLogger("flair")
+
+START_TAG: str = "<START>"
+STOP_TAG: str = "<STOP>"
+
+_UNSUPPORTED_TRUE = ("use_mfvi", "use_rnn", "use_cnn", "distill_crf", "crf_attention", "biaf_attention", "use_language_attention",
+                     "distill_posterior", "posterior_constraint", "predict_posterior", "enhanced_crf", "use_transition_attention",
+                     "relearn_embeddings", "map_embeddings", "embedding_selector", "use_rl", "multi_view_training")
+
+
+class SequenceTagger(flair.nn.Model):
+    def __init__(self, hidden_size: int, embeddings, tag_dictionary: Dictionary, tag_type: str, use_crf: bool = True,
+                 use_rnn: bool = True, use_cnn: bool = False, rnn_layers: int = 1, dropout: float = 0.0, word_dropout: float = 0.05,
+                 locked_dropout: float = 0.5, sentence_loss: bool = False, remove_x: bool = False, config=None, target_languages: int = 1,
+                 use_decoder_timer: bool = True, testing: bool = False, **kwargs):
+        super().__init__()
+        for k in _UNSUPPORTED_TRUE:
+            v = {"use_rnn": use_rnn, "use_cnn": use_cnn}.get(k, kwargs.get(k, False))
+            if v:
+                raise NotImplementedError("%s=True is outside the MI355X hot path (XLM-R + linear + CRF, use_rnn: false)" % k)
+        if not use_crf:
+            raise NotImplementedError("use_crf=False (softmax head) is not on the hot path")
+        if dropout or locked_dropout:
+            raise NotImplementedError("dropout / locked_dropout > 0 on the tagger head is not implemented (KB-NER YAMLs use 0.0)")
+        self.hidden_size = hidden_size
+        self.embeddings = embeddings
+        self.tag_dictionary = tag_dictionary
+        self.tag_type = tag_type
+        self.tagset_size = len(tag_dictionary)
+        self.use_crf = True
+        self.use_rnn = False
+        self.use_cnn = False
+        self.sentence_level_loss = sentence_loss
+        self.remove_x = remove_x
+        self.use_word_dropout = word_dropout  # accepted; see DESIGN.md (dropout is a listed gap of this round)
+        self.use_dropout, self.use_locked_dropout = 0.0, 0.0
+        self.config = config
+        self.target_languages = target_languages
+        self.use_decoder_timer = use_decoder_timer
+        self.time = 0.0
+        self.trained_epochs = 0
+        self.use_bert = False
+        self.biaf_attention = False
+        self.use_language_attention = False
+        self.use_language_vector = False
+        self.distill_crf = self.distill_posterior = self.distill_prob = self.distill_exact = False
+        self.crf_attention = False
+        self.selection = None
+        self.mask = None
+        self.word_map = self.char_map = self.lemma_map = self.postag_map = None
+        self.start_idx = tag_dictionary.get_idx_for_item(START_TAG)
+        self.stop_idx = tag_dictionary.get_idx_for_item(STOP_TAG)
+        self.x_idx = tag_dictionary.get_idx_for_item("S-X") if remove_x else None
+        emb = embeddings.embeddings[0] if hasattr(embeddings, "embeddings") else embeddings
+        if hasattr(embeddings, "embeddings") and len(embeddings.embeddings) != 1:
+            raise NotImplementedError("exactly one TransformerWordEmbeddings is supported on the hot path")
+        self._emb = emb
+        self.engine = None
+        self._build_engine()
+
+    # ------------------------------------------------------------------ engine
+    def _build_engine(self):
+        from kbner import engine as E
+        hc = self._emb.model.config
+        cfg = E.EncoderConfig(vocab_size=hc.vocab_size, hidden_size=hc.hidden_size, num_hidden_layers=hc.num_hidden_layers,
+                              num_attention_heads=hc.num_attention_heads, intermediate_size=hc.intermediate_size,
+                              max_position_embeddings=hc.max_position_embeddings, type_vocab_size=getattr(hc, "type_vocab_size", 1),
+                              pad_token_id=getattr(hc, "pad_token_id", 1) if getattr(hc, "pad_token_id", 1) is not None else 1,
+                              layer_norm_eps=getattr(hc, "layer_norm_eps", 1e-5))
+        self.engine = E.Tagger(cfg, self.tagset_size, self.start_idx, self.stop_idx, device=flair.device)
+        self.engine.load_hf_state_dict(self._emb.model.state_dict())
+        g = torch.Generator().manual_seed(int(torch.initial_seed() % (2 ** 31)))
+        H = cfg.hidden_size
+        bound = 1.0 / (H ** 0.5)
+        self.engine.set_param("linear.weight", (torch.rand(self.tagset_size, H, generator=g) * 2 - 1) * bound)
+        self.engine.set_param("linear.bias", (torch.rand(self.tagset_size, generator=g) * 2 - 1) * bound)
+        tr = torch.randn(self.tagset_size, self.tagset_size, generator=g)
+        tr[self.start_idx, :] = -1e12
+        tr[:, self.stop_idx] = -1e12
+        self.engine.set_param("transitions", tr)
+        self._emb.model.source = self.engine
+        self._emb.model._state_dict = None  # the arena is the single owner of the weights now
+
+    @property
+    def transitions(self):
+        return self.engine.arena.param("transitions")
+
+    @property
+    def linear(self):
+        class _Lin:
+            pass
+
+        lin = _Lin()
+        lin.weight = self.engine.arena.param("linear.weight")
+        lin.bias = self.engine.arena.param("linear.bias")
+        return lin
+
+    def named_parameters(self, prefix="", recurse=True):
+        """(name, tensor view) with the reference's naming: `transitions`, `linear.*`, `embeddings.list_embedding_0.model.<hf>`"""
+        yield "transitions", self.engine.arena.param("transitions")
+        yield "linear.weight", self.engine.arena.param("linear.weight")
+        yield "linear.bias", self.engine.arena.param("linear.bias")
+        for k, v in self.engine.hf_state_dict().items():
+            yield "embeddings.list_embedding_0.model." + k, v
+
+    def parameters(self, recurse=True):
+        for _, p in self.named_parameters():
+            yield p
+
+    def zero_grad(self, set_to_none=False):
+        self.engine.arena.g.zero_()
+
+    def to(self, *a, **k):
+        return self
+
+    # ------------------------------------------------------------------ batches
+    def _device_batch(self, sentences):
+        from kbner import batch as kb
+        name = self._emb.name
+        feats = getattr(sentences, "features", None)
+        if feats is not None and name in feats and isinstance(feats[name], tuple):
+            ids, am, first, lengths = feats[name]
+        else:
+            ids, am, first, lengths = self._emb.prepare_batch(sentences)
+        n = first.shape[1]
+        tags = np.zeros((len(sentences), n), np.int64)
+        for b, s in enumerate(sentences):
+            t = getattr(s, self.tag_type + "_tags", None)
+            if t is not None:
+                t = np.asarray(t)
+                tags[b, :min(n, len(t))] = t[:n]
+            else:
+                tags[b, :len(s)] = [self.tag_dictionary.get_idx_for_item(tok.get_tag(self.tag_type).value) for tok in s]
+        hb = kb.assemble(ids, am, first, tags, lengths, self.x_idx)
+        return hb, kb.to_device(hb, flair.device)
+
+    # ------------------------------------------------------------------ forward / loss
+    def forward(self, sentences, prediction_mode=False):
+        """emissions f32 [B, n, T] for every word token (device tensor); sets self.mask to the length mask"""
+        self.embeddings.embed(sentences)
+        hb, db = self._device_batch(sentences)
+        feats = self.engine.forward_features(db)
+        n = feats.shape[1]
+        self.mask = (torch.arange(n, device=feats.device)[None, :] < db["lengths"][:, None]).float()
+        self._last = (hb, db)
+        return feats
+
+    def forward_loss(self, data_points, sort=True, return_features=False):
+        if isinstance(data_points, Sentence):
+            data_points = [data_points]
+        self.embeddings.embed(data_points)
+        hb, db = self._device_batch(data_points)
+        self._last = (hb, db)
+        self.mask = torch.from_numpy(hb["keep"].astype(np.float32)).to(flair.device)
+        return self.engine.forward_loss(db, backward=False)
+
+    def forward_backward(self, data_points, loss_scale=1.0):
+        """forward_loss + backward into the gradient arena (what `loss.backward()` does at finetune_trainer.py:957)"""
+        self.embeddings.embed(data_points)
+        hb, db = self._device_batch(data_points)
+        self._last = (hb, db)
+        self.mask = torch.from_numpy(hb["keep"].astype(np.float32)).to(flair.device)
+        return self.engine.forward_loss(db, loss_scale=loss_scale, backward=True)
+
+    def _calculate_loss(self, features, sentences, mask):
+        """CRF NLL of given emissions [B,n,T] (mean over sentences); narrows self.mask to the non-S-X tokens like the
+        reference's remove_x branch does (:2448-2453)."""
+        from kbner import ops
+        hb, db = self._last if getattr(self, "_last", None) is not None else self._device_batch(sentences)
+        B, n, T = features.shape
+        flat = features.reshape(B * n, T).contiguous()
+        nc = hb["ctags"].shape[1]
+        idx = torch.from_numpy(_compact_index(hb["keep"], nc)).to(features.device)
+        gathered = ops.gather_rows_f32(flat, idx)
+        logz, gold, _ = ops.crf_nll_fwd(gathered.view(B, nc, T).contiguous(), self.engine.arena.param("transitions"), db["ctags"],
+                                        db["clens"], self.start_idx, self.stop_idx)
+        self.mask = torch.from_numpy(hb["keep"].astype(np.float32)).to(features.device)
+        return (logz - gold).mean()
+
+    def _obtain_labels(self, feature, sentences, get_all_tags: bool = False):
+        """Viterbi over the rows self.mask keeps, S-X / confidence 1 re-padded around them (:1193-1210)."""
+        from kbner import ops
+        B, n, T = feature.shape
+        keep = self.mask.bool().cpu().numpy() if self.mask is not None else np.ones((B, n), bool)
+        lens = keep.sum(1).astype(np.int32)
+        nc = max(1, int(lens.max()))
+        idx = torch.from_numpy(_compact_index(keep, nc)).to(feature.device)
+        comp = ops.gather_rows_f32(feature.reshape(B * n, T).contiguous(), idx)
+        tags, conf = ops.crf_viterbi(comp.view(B, nc, T).contiguous(), self.engine.arena.param("transitions"),
+                                     torch.from_numpy(lens).to(feature.device), self.start_idx, self.stop_idx)
+        tags, conf = tags.cpu().numpy(), conf.cpu().numpy()
+        x_item = "S-X"
+        out = []
+        for b, s in enumerate(sentences):
+            L, k = len(s), int(lens[b])
+            path = [self.tag_dictionary.get_item_for_index(int(t)) for t in tags[b, :k]]
+            cf = [float(c) for c in conf[b, :k]]
+            if k < L:
+                kept = np.nonzero(keep[b])[0]
+                before = int(kept[0]) if len(kept) else 0
+                path = [x_item] * before + path
+                cf = [1.0] * before + cf
+                after = L - len(path)
+                path, cf = path + [x_item] * after, cf + [1.0] * after
+            out.append([Label(p, c) for p, c in zip(path, cf)])
+        return out, []
+
+    # ------------------------------------------------------------------ evaluation
+    def evaluate(self, data_loader, out_path: Path = None, embeddings_storage_mode: str = "cpu", prediction_mode=False,
+                 speed_test=False):
+        import time
+        eval_loss, batch_no, lines = 0.0, 0, []
+        metric = Metric("Evaluation")
+        t0 = time.time()
+        for batch in data_loader:
+            batch_no += 1
+            features = self.forward(batch, prediction_mode=prediction_mode)
+            if not speed_test:
+                loss = self._calculate_loss(features, batch, self.mask)
+                eval_loss += float(loss)
+            tags, _ = self._obtain_labels(features, batch)
+            for sentence, sent_tags in zip(batch, tags):
+                for token, tag in zip(sentence.tokens, sent_tags):
+                    token.add_tag_label("predicted", tag)
+                    lines.append("{} {} {} {}\n".format(token.text, token.get_tag(self.tag_type).value, tag.value, tag.score))
+                lines.append("\n")
+            for sentence in batch:
+                gold = [(s.tag, str(s)) for s in sentence.get_spans(self.tag_type)]
+                pred = [(s.tag, str(s)) for s in sentence.get_spans("predicted")]
+                if self.remove_x:
+                    x_ids = {t.idx for t in sentence.tokens if t.get_tag(self.tag_type).value.endswith("-X")}
+                    gold = [g for g in gold if g[0] != "X"]
+                    pred = [p for p, sp in zip(pred, sentence.get_spans("predicted"))
+                            if p[0] != "X" and not any(t.idx in x_ids for t in sp.tokens)]
+                for tag, span in pred:
+                    (metric.add_tp if (tag, span) in gold else metric.add_fp)(tag)
+                for tag, span in gold:
+                    if (tag, span) not in pred:
+                        metric.add_fn(tag)
+            store_embeddings(batch, embeddings_storage_mode)
+        if speed_test:
+            log.info("decode speed: %.2f sents/sec", getattr(data_loader, "num_examples", 0) / max(1e-9, time.time() - t0))
+        eval_loss /= max(1, batch_no)
+        if out_path is not None:
+            with open(out_path, "w", encoding="utf-8") as f:
+                f.write("".join(lines))
+        detailed = ("\nMICRO_AVG: acc {} - f1-score {}\nMACRO_AVG: acc {} - f1-score {}".format(
+            metric.micro_avg_accuracy(), metric.micro_avg_f_score(), metric.macro_avg_accuracy(), metric.macro_avg_f_score()))
+        for c in metric.get_classes():
+            detailed += ("\n{:<10} tp: {} - fp: {} - fn: {} - tn: {} - precision: {:.4f} - recall: {:.4f} - accuracy: {:.4f} - "
+                         "f1-score: {:.4f}".format(c, metric.get_tp(c), metric.get_fp(c), metric.get_fn(c), metric.get_tn(c),
+                                                   metric.precision(c), metric.recall(c), metric.accuracy(c), metric.f_score(c)))
+        result = Result(main_score=metric.micro_avg_f_score(), log_line="{}\t{}\t{}".format(metric.precision(), metric.recall(),
+                                                                                           metric.micro_avg_f_score()),
+                        log_header="PRECISION\tRECALL\tF1", detailed_results=detailed, macro_score=metric.macro_avg_f_score())
+        return result, eval_loss
+
+    def predict(self, sentences, mini_batch_size=32, embedding_storage_mode="none"):
+        from flair.custom_data_loader import BatchedData
+        if isinstance(sentences, Sentence):
+            sentences = [sentences]
+        for i in range(0, len(sentences), mini_batch_size):
+            batch = BatchedData(sentences[i:i + mini_batch_size])
+            feats = self.forward(batch)
+            tags, _ = self._obtain_labels(feats, batch)
+            for s, ts in zip(batch, tags):
+                for tok, tag in zip(s.tokens, ts):
+                    tok.add_tag_label(self.tag_type, tag)
+        return sentences
+
+    # ------------------------------------------------------------------ persistence
+    def _get_state_dict(self):
+        return {
+            "format": "kbner-mi355x-v1",
+            "encoder_state_dict": {k: v.detach().cpu() for k, v in self.engine.hf_state_dict().items()},
+            "linear.weight": self.engine.arena.param("linear.weight").detach().cpu().clone(),
+            "linear.bias": self.engine.arena.param("linear.bias").detach().cpu().clone(),
+            "transitions": self.engine.arena.param("transitions").detach().cpu().clone(),
+            "tag_dictionary": self.tag_dictionary, "tag_type": self.tag_type, "hidden_size": self.hidden_size,
+            "use_crf": True, "use_rnn": False, "remove_x": self.remove_x, "sentence_loss": self.sentence_level_loss,
+            "word_dropout": self.use_word_dropout, "embedding_model_dir": getattr(self._emb, "name", None),
+            "trained_epochs": self.trained_epochs,
+        }
+
+    @classmethod
+    def _init_model_with_state_dict(cls, state):
+        from flair.embeddings import StackedEmbeddings, TransformerWordEmbeddings
+        emb = TransformerWordEmbeddings(model=state["embedding_model_dir"], layers="-1", pooling_operation="first", fine_tune=True)
+        model = cls(hidden_size=state["hidden_size"], embeddings=StackedEmbeddings([emb]), tag_dictionary=state["tag_dictionary"],
+                    tag_type=state["tag_type"], use_crf=True, use_rnn=False, remove_x=state["remove_x"],
+                    sentence_loss=state["sentence_loss"], word_dropout=state.get("word_dropout", 0.0), dropout=0.0,
+                    locked_dropout=0.0)
+        model.engine.load_hf_state_dict(state["encoder_state_dict"])
+        for k in ("linear.weight", "linear.bias", "transitions"):
+            model.engine.set_param(k, state[k])
+        model.trained_epochs = state.get("trained_epochs", 0)
+        return model
+
+
+def _compact_index(keep, nc):
+    """flat row index [B*nc] into [B*n] of the kept tokens, -1 padded"""
+    B, n = keep.shape
+    out = np.full((B, nc), -1, np.int32)
+    for b in range(B):
+        k = np.nonzero(keep[b])[0]
+        out[b, :len(k)] = b * n + k
+    return out.reshape(-1)
+
+
+class FastSequenceTagger(SequenceTagger):
+    """same engine; the reference's 'Fast' variant differs only in how it batches the torch ops"""
+    pass

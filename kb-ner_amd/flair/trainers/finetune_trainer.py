@@ -1,0 +1,252 @@
+"""ModelFinetuner on the MI355X engine: the fine-tuning host loop of KB-NER with data parallelism added.
+
+Behavioural reference (restated): flair/trainers/finetune_trainer.py -- constructor keywords (:51-78), train() keywords
+(:379-437) and loop (:780-1348): ColumnDataLoader over train(+dev), batch-order reshuffle per epoch (:819), per micro-batch
+loss / gradient_accumulation_steps (:939-946) + backward (:957), every `accum` micro-batches clip_grad_norm_(5.0) (:1010) +
+AdamW.step (:1018) + zero_grad + scheduler.step (:1023) with the two lr groups of :552-571 (transitions at lr * lr_rate) and
+the linear decay of :686-688 (t_total = ceil(len(loader)/accum) * max_epochs, :679), per-epoch dev evaluation, best / final
+model files, optional `save_finetuned_embedding` HF directory (:1289-1312), final_test (:2136).
+Clip + AdamW + zero_grad are ONE fused HIP pass (kbner.engine.FusedAdamW); gradients are all-reduced once per step over
+RCCL when launched with torchrun (kbner.dp)."""
+import logging
+import random
+import time
+from pathlib import Path
+from typing import List, Union
+
+import torch
+from torch.utils.data.dataset import ConcatDataset
+
+import flair
+import flair.nn
+from flair.custom_data_loader import ColumnDataLoader
+from flair.training_utils import add_file_handler, init_output_file, log_line, store_embeddings
+
+log = logging.getLogger("flair")
+
+
+class ModelFinetuner:
+    def __init__(self, model: flair.nn.Model, teachers: List[flair.nn.Model], corpus, optimizer=None, professors=None,
+                 epoch: int = 0, optimizer_state: dict = None, scheduler_state: dict = None, use_tensorboard: bool = False,
+                 distill_mode: bool = False, ensemble_distill_mode: bool = False, config=None, train_with_professor: bool = False,
+                 is_test: bool = False, language_resample: bool = False, direct_upsample_rate: int = -1, down_sample_amount: int = -1,
+                 sentence_level_batch: bool = False, clip_sentences: int = -1, remove_sentences: bool = False,
+                 assign_doc_id: bool = False, train_with_doc: bool = False, pretrained_file_dict: dict = None,
+                 sentence_level_pretrained_data: bool = False, assign_doc_for_ext_context: bool = False, **kwargs):
+        if distill_mode or ensemble_distill_mode or train_with_professor:
+            raise NotImplementedError("knowledge distillation is outside the hot path (all KB-NER configs set distill_mode: false)")
+        self.model = model
+        self.corpus = corpus
+        self.config = config
+        self.teachers = teachers or []
+        self.professors = professors or []
+        self.epoch = epoch
+        self.sentence_level_batch = sentence_level_batch
+        self.use_bert = False          # 'bert' is not a substring of 'TransformerWordEmbeddings' 
+        self.bert_tokenizer = None
+        self.embeddings_storage_mode = "none"
+        self.corpus2id = {name: i for i, name in enumerate(getattr(corpus, "targets", []))}
+        if direct_upsample_rate > 0 and not is_test and hasattr(corpus, "train_list"):
+            # finetune_trainer.py:185-198: replicate each training set `rate` times
+            corpus.train_list = [ConcatDataset([d] * int(direct_upsample_rate)) for d in corpus.train_list]
+            corpus._train = ConcatDataset(list(corpus.train_list))
+        for i, name in enumerate(getattr(corpus, "targets", [])):
+            for part in ("train_list", "dev_list", "test_list"):
+                for s in getattr(corpus, part)[i]:
+                    s.lang_id = i
+
+    # ------------------------------------------------------------------ training
+    def train(self, base_path: Union[Path, str], learning_rate: float = 5e-5, mini_batch_size: int = 32,
+              eval_mini_batch_size: int = None, max_epochs: int = 100, train_with_dev: bool = False, monitor_train: bool = False,
+              monitor_test: bool = False, embeddings_storage_mode: str = "cpu", checkpoint: bool = False,
+              save_final_model: bool = True, shuffle: bool = True, true_reshuffle: bool = False, warmup_steps: int = 0,
+              use_warmup: bool = False, gradient_accumulation_steps: int = 1, lr_rate: int = 1, sort_data: bool = True,
+              fine_tune_mode: bool = False, save_finetuned_embedding: bool = False, one_by_one: bool = False,
+              select_model_by_macro: bool = False, max_epochs_without_improvement: int = 100, log_interval: int = None,
+              **kwargs) -> dict:
+        from kbner import dp
+        from kbner.engine import FusedAdamW
+        base_path = Path(base_path)
+        base_path.mkdir(parents=True, exist_ok=True)
+        is_main = dp.rank() == 0
+        handler = add_file_handler(log, base_path / "training.log") if is_main else None
+        self.embeddings_storage_mode = embeddings_storage_mode
+        eval_bs = eval_mini_batch_size or max(mini_batch_size, 32 if self.sentence_level_batch else mini_batch_size)
+        accum = max(1, int(gradient_accumulation_steps))
+        W = dp.world_size()
+
+        train_sets = list(self.corpus.train_list)
+        if train_with_dev:
+            train_sets = [ConcatDataset([t, d]) for t, d in zip(self.corpus.train_list, self.corpus.dev_list)]
+        train_data = [s for ds in train_sets for s in ds]
+        loader = ColumnDataLoader(train_data, mini_batch_size, shuffle, use_bert=self.use_bert, tokenizer=self.bert_tokenizer,
+                                  model=self.model, sentence_level_batch=self.sentence_level_batch, sort_data=sort_data)
+        loader.assign_tags(self.model.tag_type, self.model.tag_dictionary)
+        dev_loaders = []
+        if not train_with_dev:
+            for ds in self.corpus.dev_list:
+                dl = ColumnDataLoader(list(ds), eval_bs, False, sort_data=sort_data, model=self.model,
+                                      sentence_level_batch=self.sentence_level_batch)
+                dl.assign_tags(self.model.tag_type, self.model.tag_dictionary)
+                dev_loaders.append(dl)
+        test_loaders = []
+        if monitor_test:
+            for ds in self.corpus.test_list:
+                tl = ColumnDataLoader(list(ds), eval_bs, False, sort_data=sort_data, model=self.model,
+                                      sentence_level_batch=self.sentence_level_batch)
+                tl.assign_tags(self.model.tag_type, self.model.tag_dictionary)
+                test_loaders.append(tl)
+
+        steps_epoch = dp.steps_per_epoch(len(loader), accum, W)
+        t_total = steps_epoch * max_epochs
+        opt = FusedAdamW(self.model.engine.arena, lr=learning_rate, lr_rate=float(lr_rate), eps=1e-6, weight_decay=0.0,
+                         max_norm=5.0, t_total=t_total, warmup=warmup_steps if use_warmup else 0)
+        self.optimizer = opt
+        log_line(log)
+        log.info('Model: "XLM-R encoder + linear + CRF on kbner HIP engine", tags=%d', len(self.model.tag_dictionary))
+        log.info('Parameters: learning_rate "%s", mini_batch_size "%s", accumulate "%s", max_epochs "%s", world_size "%s", '
+                 'global batch "%s", t_total "%s"', learning_rate, mini_batch_size, accum, max_epochs, W,
+                 mini_batch_size * accum * W, t_total)
+        log.info('Model training base path: "%s"', base_path)
+        log_line(log)
+        loss_txt = init_output_file(base_path, "loss.tsv") if is_main else None
+        if is_main:
+            with open(loss_txt, "a") as f:
+                f.write("EPOCH\tTIMESTAMP\tLEARNING_RATE\tTRAIN_LOSS\tDEV_LOSS\tDEV_F1\tDEV_MACRO_F1\n")
+
+        dev_score_history, dev_loss_history, train_loss_history = [], [], []
+        best_score, bad_epochs = -1.0, 0
+        rng = random.Random(20220711)  # rank-shared shuffle of the batch order
+        log_every = log_interval or max(1, len(loader) // W // 10)
+        try:
+            for epoch in range(self.epoch, max_epochs):
+                if shuffle:
+                    if true_reshuffle:
+                        random.seed(20220711 + epoch)
+                        loader.true_reshuffle()
+                    else:
+                        rng.shuffle(loader.data)
+                self.model.train()
+                mine = dp.shard_indices(len(loader), dp.rank(), W)
+                losses, seen, micro = [], 0, 0
+                t_ep = t_log = time.time()
+                for local_no, bi in enumerate(mine):
+                    batch = loader[bi]
+                    losses.append(self.model.forward_backward(batch, loss_scale=1.0 / accum))
+                    seen += len(batch)
+                    micro += 1
+                    store_embeddings(batch, embeddings_storage_mode)
+                    last = local_no == len(mine) - 1
+                    if micro == accum or last:
+                        scale = dp.all_reduce_sum_(self.model.engine.arena.g)
+                        # a short final group keeps the 1/accum scaling, exactly like the reference (:939-946,1007)
+                        opt.step(grad_scale=scale)
+                        micro = 0
+                    if (local_no + 1) % log_every == 0 and is_main:
+                        cur = float(torch.stack(losses[-log_every:]).mean())
+                        dt = time.time() - t_log
+                        log.info("epoch %d - iter %d/%d - loss %.8f - samples/sec: %.2f (x%d ranks)", epoch + 1, local_no + 1,
+                                 len(mine), cur, log_every * mini_batch_size / max(dt, 1e-9), W)
+                        t_log = time.time()
+                loss_sum = float(torch.stack(losses).sum()) if losses else 0.0
+                tot, cnt = dp.all_reduce_scalars([loss_sum, float(len(losses))])
+                train_loss = tot / max(cnt, 1.0)
+                train_loss_history.append(train_loss)
+                self.model.trained_epochs = epoch + 1
+                self.model.eval()
+                log_line(log)
+                log.info("EPOCH %d done: loss %.4f - lr %.2e - %.1f sentences/sec (all ranks)", epoch + 1, train_loss,
+                         learning_rate * opt.lr_lambda(), W * seen / max(time.time() - t_ep, 1e-9))
+                # ---- evaluation + model selection on rank 0 (replicas are identical)
+                if is_main:
+                    score = macro = None
+                    if dev_loaders:
+                        f1s, dls = [], []
+                        for name, dl in zip(getattr(self.corpus, "targets", ["dev"]), dev_loaders):
+                            res, dl_loss = self.model.evaluate(dl, embeddings_storage_mode=embeddings_storage_mode)
+                            log.info("%s DEV : loss %.4f - f1 %.4f - macro %.4f", name, dl_loss, res.main_score, res.macro_score)
+                            f1s.append(res.macro_score if select_model_by_macro else res.main_score)
+                            dls.append(dl_loss)
+                        score = sum(f1s) / len(f1s)
+                        dev_score_history.append(score)
+                        dev_loss_history.append(sum(dls) / len(dls))
+                    for name, tl in zip(getattr(self.corpus, "targets", ["test"]), test_loaders):
+                        res, tl_loss = self.model.evaluate(tl, embeddings_storage_mode=embeddings_storage_mode)
+                        log.info("%s TEST: loss %.4f - f1 %.4f", name, tl_loss, res.main_score)
+                    with open(loss_txt, "a") as f:
+                        f.write("%d\t%s\t%.3e\t%.6f\t%s\t%s\t_\n" % (epoch + 1, time.strftime("%H:%M:%S"), learning_rate * opt.lr_lambda(),
+                                                                   train_loss, dev_loss_history[-1] if dev_loss_history else "_",
+                                                                   score if score is not None else "_"))
+                    improved = score is not None and score > best_score
+                    if improved:
+                        best_score, bad_epochs = score, 0
+                        self.model.save(base_path / "best-model.pt")
+                        if save_finetuned_embedding:
+                            self.save_finetuned_embedding(base_path)
+                    elif score is not None:
+                        bad_epochs += 1
+                    if checkpoint:
+                        self.model.save_checkpoint(base_path / "checkpoint.pt", {"t": opt.t}, {}, epoch + 1, train_loss)
+                stop = dp.broadcast_object(bad_epochs >= max_epochs_without_improvement if is_main else None)
+                if stop:
+                    log.info("no improvement for %d epochs: stopping", bad_epochs)
+                    break
+        except KeyboardInterrupt:
+            log_line(log)
+            log.info("Exiting from training early.")
+        if is_main and save_final_model:
+            self.model.save(base_path / "final-model.pt")
+            if save_finetuned_embedding and (train_with_dev or not (base_path / "best-model.pt").exists()):
+                self.save_finetuned_embedding(base_path)
+        dp.barrier()
+        final_score = 0.0
+        if self.corpus.test is not None and len(self.corpus.test) > 0 and is_main:
+            final_score = self.final_test(base_path, eval_bs, quiet_mode=False)
+        if handler is not None:
+            log.removeHandler(handler)
+        return {"test_score": final_score, "dev_score_history": dev_score_history, "train_loss_history": train_loss_history,
+                "dev_loss_history": dev_loss_history}
+
+    def save_finetuned_embedding(self, base_path):
+        """write `<base_path>/<basename of the embedding dir>/` with tokenizer + current encoder weights, the directory the
+        next fine-tuning stage's YAML names (finetune_trainer.py:1289-1312)"""
+        for emb in self.model.embeddings.embeddings:
+            if getattr(emb, "fine_tune", False) and hasattr(emb, "tokenizer"):
+                out = Path(base_path) / Path(str(emb.name)).name
+                out.mkdir(parents=True, exist_ok=True)
+                emb.tokenizer.save_pretrained(str(out))
+                emb.model.save_pretrained(str(out))
+
+    # ------------------------------------------------------------------ testing
+    def final_test(self, base_path: Path, eval_mini_batch_size: int, num_workers: int = 8, overall_test: bool = True,
+                   quiet_mode: bool = False, nocrf: bool = False, predict_posterior: bool = False, debug: bool = False,
+                   keep_embedding: int = -1, sort_data: bool = False, eval_train: bool = False, **kwargs):
+        base_path = Path(base_path)
+        log_line(log)
+        self.model.eval()
+        for name in ("best-model.pt", "final-model.pt"):
+            if (base_path / name).exists():
+                state = torch.load(str(base_path / name), map_location="cpu", weights_only=False)
+                self.model.engine.load_hf_state_dict(state["encoder_state_dict"])
+                for k in ("linear.weight", "linear.bias", "transitions"):
+                    self.model.engine.set_param(k, state[k])
+                log.info("Testing using %s ...", name.split("-")[0] + " model")
+                break
+        scores = []
+        parts = list(zip(getattr(self.corpus, "targets", ["test"]), self.corpus.test_list)) if hasattr(self.corpus, "test_list") \
+            else [("test", self.corpus.test)]
+        for name, ds in parts:
+            loader = ColumnDataLoader(list(ds), eval_mini_batch_size, False, sort_data=sort_data, model=self.model,
+                                      sentence_level_batch=self.sentence_level_batch)
+            loader.assign_tags(self.model.tag_type, self.model.tag_dictionary)
+            res, loss = self.model.evaluate(loader, out_path=base_path / ("%s-test.tsv" % name), embeddings_storage_mode="none")
+            log.info("%s", name)
+            log.info("%s", res.log_line)
+            log.info("%s", res.detailed_results)
+            scores.append(res.main_score)
+        log_line(log)
+        return sum(scores) / max(1, len(scores))
+
+    def assign_ext_context_doc(self, corpus):
+        """config 5 only (`assign_doc_for_ext_context`); the XLM-R + CRF configs feed the whole 'sentence <EOS> context' sequence"""
+        raise NotImplementedError("assign_doc_for_ext_context is a 'next' row (SURVEY.md §8f-1)")

@@ -62,6 +62,15 @@ def gather_rows(src, idx, out=None):
     return out
 
 
+def gather_rows_f32(src, idx):
+    """src f32 [Rsrc, W], idx i32 [R] (-1 -> zero row) -> f32 [R, W]"""
+    _chk(src, F32, "src"); _chk(idx, I32, "idx")
+    R, W = idx.numel(), src.shape[-1]
+    out = torch.empty((R, W), dtype=F32, device=src.device)
+    L.call("kbner_gather_rows_f32", ptr(src), ptr(idx), ptr(out), R, W, stream_ptr())
+    return out
+
+
 def scatter_rows(dout, idx, dsrc):
     _chk(dout, BF16, "dout"); _chk(idx, I32, "idx"); _chk(dsrc, BF16, "dsrc")
     L.call("kbner_scatter_rows", ptr(dout), ptr(idx), ptr(dsrc), idx.numel(), dout.shape[-1], stream_ptr())

@@ -308,6 +308,68 @@ def main():
             cases["p%d/%s" % (step + 1, n)] = p.detach().clone().numpy()
     cases["lrs"] = np.asarray(lrs, np.float64)
     np.savez_compressed(os.path.join(GOLD, "adamw.npz"), **cases)
+    # ---------------- G11: reconstruct_tokens_from_subtokens (embeddings.py:3347) with the tiny test tokenizer ----------
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import tiny_assets
+    from flair.embeddings import TransformerWordEmbeddings as RefTWE
+    from flair.data import Sentence as RefSentence
+    tdir = tempfile.mkdtemp()
+    tok = tiny_assets.build_tokenizer_dir(tdir)
+
+    class _Stub:
+        tokenizer = tok
+        special_tokens = ["<s>"]
+        _remove_special_markup = staticmethod(RefTWE._remove_special_markup)
+        _get_processed_token_text = RefTWE._get_processed_token_text
+
+    stub = _Stub()
+    texts = ["alice visited berlin </s> the museum of art", "zalando research is located in berlin .",
+             "Bob , Carol and ALICE ( 1999 ) -- new york city !", "a", "google founded by john smith 2021 </s> wikipedia article about history",
+             "river thames near london </s> london capital population language people"]
+    recs = []
+    for t in texts:
+        sent = RefSentence(t)
+        pieces = tok.tokenize(sent.to_tokenized_string())
+        lens = RefTWE.reconstruct_tokens_from_subtokens(stub, sent, pieces)
+        recs.append({"text": t, "tokens": [x.text for x in sent], "pieces": pieces, "lengths": [int(x) for x in lens]})
+    import json
+    with open(os.path.join(GOLD, "subtoken_lengths.json"), "w") as f:
+        json.dump(recs, f, indent=1, ensure_ascii=False)
+
+    # ---------------- G10: get_spans + Metric on predicted vs gold tag sequences (data.py:455, training_utils.py:26) ------
+    from flair.data import Sentence as RS
+    from flair.training_utils import Metric as RefMetric
+    tagsets = ["O", "B-LOC", "I-LOC", "E-LOC", "S-LOC", "B-PER", "E-PER", "S-PER", "S-X", "I-PER", "S-CORP"]
+    recs = []
+    metric = RefMetric("g10")
+    for k in range(12):
+        n = int(rng.integers(3, 12))
+        words = ["w%d" % i for i in range(n)]
+        gold = [str(x) for x in rng.choice(tagsets, size=n)]
+        pred = [g if rng.random() < 0.6 else str(rng.choice(tagsets)) for g in gold]
+        conf = [float(x) for x in np.round(rng.uniform(0.3, 1.0, size=n), 3)]
+        s = RS(" ".join(words))
+        for tkn, g_, p_, c_ in zip(s, gold, pred, conf):
+            tkn.add_tag("ner", g_)
+            tkn.add_tag("predicted", p_, c_)
+        gs = [(sp.tag, str(sp), float(sp.score)) for sp in s.get_spans("ner")]
+        ps = [(sp.tag, str(sp), float(sp.score)) for sp in s.get_spans("predicted")]
+        for tag, text, _ in ps:
+            if (tag, text) in [(a, b) for a, b, _ in gs]:
+                metric.add_tp(tag)
+            else:
+                metric.add_fp(tag)
+        for tag, text, _ in gs:
+            if (tag, text) not in [(a, b) for a, b, _ in ps]:
+                metric.add_fn(tag)
+        recs.append({"words": words, "gold": gold, "pred": pred, "conf": conf, "gold_spans": gs, "pred_spans": ps})
+    summary = {"classes": metric.get_classes(), "micro_f": metric.micro_avg_f_score(), "macro_f": metric.macro_avg_f_score(),
+               "precision": metric.precision(), "recall": metric.recall(), "accuracy": metric.accuracy(),
+               "per_class": {c: [metric.get_tp(c), metric.get_fp(c), metric.get_fn(c), metric.f_score(c)] for c in metric.get_classes()}}
+    with open(os.path.join(GOLD, "spans_metric.json"), "w") as f:
+        json.dump({"sentences": recs, "metric": summary}, f, indent=1)
+
     print("wrote fixtures to", GOLD)
     for f in sorted(os.listdir(GOLD)):
         print("  %-28s %8d bytes" % (f, os.path.getsize(os.path.join(GOLD, f))))

@@ -1,0 +1,113 @@
+"""CPU, world_size 2 over gloo: the data-parallel host logic (kbner.dp) -- shard coverage, the sum-all-reduce + 1/W contract
+that FusedAdamW's grad_scale completes, global step counting -- and that 2-rank gradient averaging reproduces the
+single-process gradient of the doubled batch (checked on the oracle's fp32 tagger so it runs without a GPU)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _tiny_problem():
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "kb-ner_amd"))
+    from kbner import batch as kb
+    from oracle import encoder as oenc
+    cfg = oenc.EncoderConfig(vocab_size=97, hidden_size=32, num_hidden_layers=1, num_attention_heads=2, intermediate_size=64,
+                             max_position_embeddings=40)
+    params = oenc.init_params(cfg, seed=3, std=0.2)
+    g = torch.Generator().manual_seed(5)
+    T, start, stop, x_idx = 8, 6, 7, 5
+    params["linear.weight"] = torch.randn(T, 32, generator=g) * 0.3
+    params["linear.bias"] = torch.zeros(T)
+    tr = torch.randn(T, T, generator=g)
+    tr[start, :] = -1e12
+    tr[:, stop] = -1e12
+    params["transitions"] = tr
+    ids, am, first, tags, lengths = kb.synthetic_sentences(4, 32, vocab=97, T=T, x_idx=x_idx, start=start, stop=stop, n_real=4, seed=9)
+    return cfg, params, (ids, am, first, tags, lengths), (start, stop, x_idx)
+
+
+def _grads(cfg, params, data, tagsinfo, rows):
+    from oracle import train_step as ots
+    ids, am, first, tags, lengths = data
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    b = dict(input_ids=torch.from_numpy(ids[rows]), attention_mask=torch.from_numpy(am[rows]),
+             first_idx=torch.from_numpy(first[rows]), tags=torch.from_numpy(tags[rows]), lengths=torch.from_numpy(lengths[rows]))
+    loss, _ = ots.tagger_forward_loss(p, cfg, b, *tagsinfo)
+    loss.backward()
+    names = sorted(p)
+    return torch.cat([(p[n].grad if p[n].grad is not None else torch.zeros_like(p[n])).flatten() for n in names]), float(loss)
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "kb-ner_amd"))
+    torch.set_num_threads(1)
+    from kbner import dp
+    dp.init_from_env(backend="gloo")
+    assert dp.world_size() == world and dp.rank() == rank
+    # 1. shard coverage: every micro-batch index is run, every rank runs the same count
+    mine = dp.shard_indices(7)
+    assert len(mine) == 4 and mine == [(rank + i * world) % 7 for i in range(4)]
+    # 2. gradient contract: sum over ranks, caller applies 1/W
+    flat = torch.full((1000,), float(rank + 1))
+    scale = dp.all_reduce_sum_(flat)
+    assert scale == 0.5 and torch.all(flat == 3.0)
+    # 3. DP gradient == single-process gradient of the doubled batch
+    cfg, params, data, tagsinfo = _tiny_problem()
+    rows = np.arange(4)[rank::world]
+    g_local, loss_local = _grads(cfg, params, data, tagsinfo, rows)
+    sc = dp.all_reduce_sum_(g_local)
+    g_dp = g_local * sc
+    tot, cnt = dp.all_reduce_scalars([loss_local, 1.0])
+    if rank == 0:
+        g_full, loss_full = _grads(cfg, params, data, tagsinfo, np.arange(4))
+        out.put((float((g_dp - g_full).abs().max()), float(g_full.abs().max()), tot / cnt, loss_full,
+                 dp.steps_per_epoch(10, 4), dp.broadcast_object({"stop": False})))
+    else:
+        dp.broadcast_object(None)
+    dp.barrier()
+    import torch.distributed as dist
+    dist.destroy_process_group()
+
+
+def test_dp_two_ranks_gloo():
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = out.get(timeout=240)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    err, gmax, loss_dp, loss_full, steps, obj = res
+    assert err <= 2e-5 * max(gmax, 1.0), res          # same gradient up to fp32 summation order
+    assert abs(loss_dp - loss_full) <= 1e-5 * abs(loss_full)
+    assert steps == 2                                  # ceil(ceil(10/2)/4) global optimizer steps per epoch
+    assert obj == {"stop": False}
+
+
+def test_shard_indices_properties():
+    sys.path.insert(0, os.path.join(ROOT, "kb-ner_amd"))
+    from kbner import dp
+    for n in (1, 5, 8, 13):
+        for w in (1, 2, 4, 8):
+            parts = [dp.shard_indices(n, r, w) for r in range(w)]
+            assert len({len(p) for p in parts}) == 1                   # equal step counts
+            assert set(i for p in parts for i in p) == set(range(n))   # every batch is visited

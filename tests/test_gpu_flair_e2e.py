@@ -1,0 +1,128 @@
+"""GPU: the drop-in path end to end -- YAML -> ConfigParser -> FastSequenceTagger -> ModelFinetuner.train on a tiny KB-NER-style
+corpus (sentence <EOS> context, B-X context tags, remove_x) -- plus full-size (BASELINE config) invariants of the CRF / encoder."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def workdir(tmp_path_factory):
+    import tiny_assets
+    d = tmp_path_factory.mktemp("e2e")
+    tiny_assets.build_model_dir(str(d / "xlmr-tiny"))
+    tiny_assets.write_conll_corpus(str(d / "data"), n_train=32, n_dev=8, n_test=8)
+    cfg = {
+        "ModelFinetuner": {"distill_mode": False, "sentence_level_batch": True},
+        "embeddings": {"TransformerWordEmbeddings-0": {"fine_tune": True, "layers": "-1", "model": str(d / "xlmr-tiny"),
+                                                        "pooling_operation": "first"}},
+        "model": {"FastSequenceTagger": {"crf_attention": False, "dropout": 0.0, "hidden_size": 256, "locked_dropout": 0.0,
+                                         "remove_x": True, "sentence_loss": True, "use_cnn": False, "use_crf": True,
+                                         "use_rnn": False, "word_dropout": 0.1}},
+        "model_name": "tiny_run", "target_dir": str(d / "out"), "targets": "ner", "trainer": "ModelFinetuner",
+        "ner": {"Corpus": "ColumnCorpus-TINY", "tag_dictionary": str(d / "tags.pkl"),
+                "ColumnCorpus-TINY": {"column_format": {0: "text", 1: "pos", 2: "upos", 3: "ner"}, "comment_symbol": "# id",
+                                      "data_folder": str(d / "data"), "tag_to_bioes": "ner"}},
+        "train": {"embeddings_storage_mode": "none", "fine_tune_mode": True, "gradient_accumulation_steps": 2,
+                  "learning_rate": 2.0e-3, "lr_rate": 50, "max_epochs": 6, "mini_batch_size": 4, "monitor_test": False,
+                  "save_finetuned_embedding": True, "select_model_by_macro": True, "train_with_dev": False,
+                  "true_reshuffle": False, "use_warmup": False},
+    }
+    with open(d / "cfg.yaml", "w") as f:
+        yaml.safe_dump(cfg, f)
+    return d
+
+
+def test_yaml_to_trained_model(workdir):
+    import flair
+    from flair.config_parser import ConfigParser
+    from flair.trainers import ModelFinetuner
+    from flair.utils.from_params import Params
+    torch.manual_seed(1)
+    cp = ConfigParser(Params.from_file(str(workdir / "cfg.yaml")))
+    td = cp.tag_dictionary
+    assert "S-X" in td.get_items() and td.get_items()[-2:] == ["<START>", "<STOP>"]
+    student = cp.create_student()
+    names = [n for n, _ in student.named_parameters()]
+    assert names[:3] == ["transitions", "linear.weight", "linear.bias"]
+    assert any(n.startswith("embeddings.list_embedding_0.model.encoder.layer.0.attention.self.query") for n in names)
+    trainer = ModelFinetuner(student, None, cp.corpus, config=cp.config, **cp.config["ModelFinetuner"])
+    out = trainer.train(cp.get_target_path, **cp.config["train"])
+    hist = out["train_loss_history"]
+    assert len(hist) == 6 and hist[-1] < 0.6 * hist[0], hist                 # it learns
+    assert len(out["dev_score_history"]) == 6 and max(out["dev_score_history"]) > 0.0
+    base = cp.get_target_path
+    for f in ("training.log", "loss.tsv", "final-model.pt", "best-model.pt"):
+        assert (base / f).exists(), f
+    hf_dir = base / "xlmr-tiny"
+    assert (hf_dir / "config.json").exists() and (hf_dir / "model.safetensors").exists() and (hf_dir / "tokenizer.json").exists()
+    # prediction file format "token gold pred score" and S-X re-padding of context tokens
+    lines = open(base / "ColumnCorpus-TINY-test.tsv").read().strip().split("\n")
+    rows = [l.split(" ") for l in lines if l]
+    assert all(len(r) == 4 for r in rows)
+    assert all(r[2] == "S-X" and float(r[3]) == 1.0 for r in rows if r[1] == "S-X")
+    assert all(r[2] != "S-X" for r in rows if r[1] != "S-X")
+    # reload round trip: same predictions
+    from flair.models import FastSequenceTagger
+    again = FastSequenceTagger.load(base / "final-model.pt")
+    from flair.custom_data_loader import ColumnDataLoader
+    dl = ColumnDataLoader(list(cp.corpus.test), 8, sentence_level_batch=True)
+    dl.assign_tags("ner", td)
+    r1, _ = student.evaluate(dl)
+    r2, _ = again.evaluate(dl)
+    assert r1.log_line == r2.log_line
+    # the saved HF directory is a valid next-stage `embeddings.model`
+    from flair.embeddings import TransformerWordEmbeddings
+    nxt = TransformerWordEmbeddings(model=str(hf_dir), layers="-1", pooling_operation="first", fine_tune=True)
+    w0 = nxt.model.state_dict()["encoder.layer.0.output.dense.weight"]
+    w1 = student.engine.hf_state_dict()["encoder.layer.0.output.dense.weight"].cpu()
+    assert torch.allclose(w0, w1)
+
+
+def test_full_size_invariants():
+    """BASELINE sizes (XLM-R-large dims, S=512, T=29): size-independent properties instead of an oracle run."""
+    from kbner import batch as kb
+    from kbner import engine, ops
+    T, start, stop, x_idx = 29, 27, 28, 9
+    cfg = engine.EncoderConfig(vocab_size=250002, num_hidden_layers=2)      # large width, 2 of the 24 identical layers
+    tg = engine.Tagger(cfg, T, start, stop)
+    tg.init_random()
+    b = kb.synthetic_batch(2, 512, vocab=250002, T=T, x_idx=x_idx, start=start, stop=stop)
+    bd = kb.to_device(b)
+    loss = tg.forward_loss(bd, backward=True)
+    torch.cuda.synchronize()
+    assert np.isfinite(float(loss)) and float(loss) > 0                      # logZ >= gold path score
+    a = tg.arena
+    # emission gradients are (marginals - one-hot): the head bias gradient sums to 0; untouched embedding rows get 0 gradient
+    assert abs(float(a.grad("linear.bias").sum())) < 1e-3
+    used = torch.unique(torch.from_numpy(b["input_ids"].reshape(-1)).to("cuda"))
+    gw = a.grad("emb.word")
+    mask = torch.ones(gw.shape[0], dtype=torch.bool, device="cuda")
+    mask[used] = False
+    assert float(gw[mask].abs().max()) == 0.0 and float(gw[used].abs().max()) > 0.0
+    # START row / STOP column of the transitions never receive probability mass
+    gt = a.grad("transitions")
+    assert float(gt[start, :].abs().max()) == 0.0 and float(gt[:, stop].abs().max()) == 0.0
+    # Viterbi path score <= logZ, and decoding is idempotent / deterministic
+    em = tg.forward_features(bd)
+    lens = bd["lengths"]
+    t1, c1 = tg.viterbi(em, lens)
+    t2, c2 = tg.viterbi(em, lens)
+    assert torch.equal(t1, t2) and torch.equal(c1, c2)
+    tags = t1.clamp(min=0).contiguous()
+    logz, gold, _ = ops.crf_nll_fwd(em.contiguous(), a.param("transitions"), tags, lens, start, stop)
+    assert bool((gold <= logz + 1e-3).all())                                 # best path score is a lower bound of logZ
+    # linearity of the GEMM path: Y(2x) - b = 2 (Y(x) - b)
+    M, H = 256, 1024
+    x = (torch.randn(M, H, device="cuda") * 0.1).to(torch.bfloat16)
+    w = a.bf("l0.ffn1.weight")
+    y1 = torch.zeros(M, 4096, dtype=torch.bfloat16, device="cuda")
+    y2 = torch.zeros_like(y1)
+    ops.gemm(0, x, w, M, 4096, H, C=y1)
+    ops.gemm(0, (x.float() * 2).to(torch.bfloat16), w, M, 4096, H, C=y2)
+    torch.cuda.synchronize()
+    assert float((y2.float() - 2 * y1.float()).abs().max()) <= 2e-2 * float(y1.float().abs().max())

@@ -1,0 +1,104 @@
+"""Test helpers: a tiny local 'HF directory' (tokenizer + config + random-init weights) and a KB-NER-style CoNLL corpus,
+built at test time -- there are no XLM-R weights / vocab on this machine and no network."""
+import json
+import os
+
+import numpy as np
+
+WORDS = ("the quick brown fox jumps over lazy dog berlin paris london zalando research amazon google university of "
+         "cambridge river thames eiffel tower alice bob carol visited works at lives in near and or with from to new york "
+         "city museum art science music band album song released year 1999 2021 company founded by john smith mary jones "
+         "wikipedia article about history location country capital population language people famous known for").split()
+
+
+def build_tokenizer_dir(path, vocab_size=300, seed=0):
+    """Unigram + Metaspace fast tokenizer with <s>=0 <pad>=1 </s>=2 <unk>=3 (XLM-R's special-token ids), saved so that
+    AutoTokenizer.from_pretrained(path) loads it."""
+    from tokenizers import Tokenizer, models, pre_tokenizers, trainers, decoders
+    from transformers import PreTrainedTokenizerFast
+    rng = np.random.default_rng(seed)
+    corpus = [" ".join(rng.choice(WORDS, size=12)) for _ in range(400)]
+    tok = Tokenizer(models.Unigram())
+    tok.pre_tokenizer = pre_tokenizers.Metaspace()
+    tok.decoder = decoders.Metaspace()
+    tr = trainers.UnigramTrainer(vocab_size=vocab_size, special_tokens=["<s>", "<pad>", "</s>", "<unk>"], unk_token="<unk>")
+    tok.train_from_iterator(corpus, tr)
+    os.makedirs(path, exist_ok=True)
+    fast = PreTrainedTokenizerFast(tokenizer_object=tok, bos_token="<s>", eos_token="</s>", pad_token="<pad>", unk_token="<unk>",
+                                   cls_token="<s>", sep_token="</s>", model_max_length=512)
+    fast.save_pretrained(path)
+    return fast
+
+
+def build_model_dir(path, hidden=128, layers=2, heads=2, inter=256, seed=0):
+    """tokenizer + config.json + model.safetensors (random init, HF names) for a tiny XLM-R-shaped encoder (head_dim 64)"""
+    import torch
+    from safetensors.torch import save_file
+    tok = build_tokenizer_dir(path, seed=seed)
+    V = len(tok)
+    cfg = dict(model_type="xlm-roberta", architectures=["XLMRobertaModel"], vocab_size=V, hidden_size=hidden,
+               num_hidden_layers=layers, num_attention_heads=heads, intermediate_size=inter, max_position_embeddings=514,
+               type_vocab_size=1, pad_token_id=1, bos_token_id=0, eos_token_id=2, layer_norm_eps=1e-5, hidden_act="gelu",
+               hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    with open(os.path.join(path, "config.json"), "w") as f:
+        json.dump(cfg, f)
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+
+    def w(*shape, std=0.05):
+        return torch.empty(*shape).normal_(0, std, generator=g)
+
+    sd["embeddings.word_embeddings.weight"] = w(V, hidden)
+    sd["embeddings.position_embeddings.weight"] = w(514, hidden)
+    sd["embeddings.token_type_embeddings.weight"] = w(1, hidden)
+    sd["embeddings.LayerNorm.weight"] = torch.ones(hidden)
+    sd["embeddings.LayerNorm.bias"] = torch.zeros(hidden)
+    for i in range(layers):
+        p = "encoder.layer.%d." % i
+        for nm in ("query", "key", "value"):
+            sd[p + "attention.self.%s.weight" % nm] = w(hidden, hidden)
+            sd[p + "attention.self.%s.bias" % nm] = torch.zeros(hidden)
+        sd[p + "attention.output.dense.weight"] = w(hidden, hidden)
+        sd[p + "attention.output.dense.bias"] = torch.zeros(hidden)
+        sd[p + "attention.output.LayerNorm.weight"] = torch.ones(hidden)
+        sd[p + "attention.output.LayerNorm.bias"] = torch.zeros(hidden)
+        sd[p + "intermediate.dense.weight"] = w(inter, hidden)
+        sd[p + "intermediate.dense.bias"] = torch.zeros(inter)
+        sd[p + "output.dense.weight"] = w(hidden, inter)
+        sd[p + "output.dense.bias"] = torch.zeros(hidden)
+        sd[p + "output.LayerNorm.weight"] = torch.ones(hidden)
+        sd[p + "output.LayerNorm.bias"] = torch.zeros(hidden)
+    save_file(sd, os.path.join(path, "model.safetensors"), metadata={"format": "pt"})
+    return path
+
+
+ENTITIES = {"berlin": "LOC", "paris": "LOC", "london": "LOC", "zalando": "CORP", "amazon": "CORP", "google": "CORP",
+            "alice": "PER", "bob": "PER", "carol": "PER"}
+
+
+def write_conll_corpus(folder, n_train=24, n_dev=8, n_test=8, seed=0):
+    """KB-NER file format (kb/context_process.py output): `token POS UPOS NER` columns, `# id ...` comment lines, the sentence,
+    then `<EOS> B-X B-X B-X` and retrieved-context tokens all tagged `B-X`."""
+    rng = np.random.default_rng(seed)
+    os.makedirs(folder, exist_ok=True)
+
+    def sentence():
+        n = int(rng.integers(4, 9))
+        words = list(rng.choice(WORDS, size=n))
+        if rng.random() < 0.9:
+            words[int(rng.integers(0, n))] = str(rng.choice(list(ENTITIES)))
+        lines = []
+        for wd in words:
+            tag = "B-" + ENTITIES[wd] if wd in ENTITIES else "O"
+            lines.append("%s _ _ %s" % (wd, tag))
+        lines.append("<EOS> B-X B-X B-X")
+        for wd in rng.choice(WORDS, size=int(rng.integers(5, 14))):
+            lines.append("%s B-X B-X B-X" % wd)
+        return lines
+
+    for name, k in (("train.txt", n_train), ("dev.txt", n_dev), ("test.txt", n_test)):
+        with open(os.path.join(folder, name), "w") as f:
+            for i in range(k):
+                f.write("# id %s-%d\tdomain=en\n" % (name, i))
+                f.write("\n".join(sentence()) + "\n\n")
+    return folder
