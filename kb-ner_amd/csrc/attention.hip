@@ -123,9 +123,15 @@ static __device__ __forceinline__ float group4_max(float v) {
 // ------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------
+// NKB = S / 16 is a template parameter: with a compile-time key count the whole 16-row pass is straight-line code
+// (no per-fragment branches), so hipcc interleaves the K-panel ds_reads, the 2*NKB QK^T MFMAs, the softmax VALU work
+// and the V transpose-reads instead of serialising them block by block.  LDS addresses are one per-lane base per
+// (k-step | d-block) plus compile-time offsets (the XOR swizzle of a row depends only on the lane, not on the tile).
+template <int NKB>
 __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ maskbias,
-                                                          bf16_t* __restrict__ ctx, float* __restrict__ lse, int S, int H,
-                                                          int A, float scale, int rpw) {
+                                                          bf16_t* __restrict__ ctx, float* __restrict__ lse, int H, int A,
+                                                          float scale, int rpw) {
+  constexpr int S = NKB * 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sK = smem;
   unsigned char* sV = smem + AT_MAXS * 128;
@@ -135,73 +141,94 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const bf16_t* __restri
   const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int ld = 3 * H;
   const bf16_t* base = qkv + (size_t)b * S * ld + h * AT_D;
+  const float scale2 = scale * 1.4426950408889634f;
+  for (int i = tid; i < S; i += 512) sMask[i] = maskbias[(size_t)b * S + i] * 1.4426950408889634f;
   stage_panel(base + H, ld, S, sK, wid, lane);
   stage_panel(base + 2 * H, ld, S, sV, wid, lane);
-  for (int i = tid; i < S; i += 512) sMask[i] = maskbias[(size_t)b * S + i];
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
   const int g = lane >> 4, li = lane & 15;
-  const int nkb = S / 16;
+  // per-lane LDS bases (see kc_frag / tr_frag): K rows f*16 + li -> + f*2048 ; V rows kc*32 + g*4 + (li>>2) -> + kc*4096
+  const unsigned char* kb0 = sK + li * 128 + (((0 * 4 + g) ^ kc_swz(li)) << 4);
+  const unsigned char* kb1 = sK + li * 128 + (((1 * 4 + g) ^ kc_swz(li)) << 4);
+  const int vrow = g * 4 + (li >> 2);
+  const unsigned char* vb[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+    vb[db] = sV + vrow * 128 + (((db * 2 + ((li & 3) >> 1)) ^ kc_swz(vrow)) << 4) + ((li & 1) << 3);
+  // K has landed when at most the V pieces (S/64 per wave, issued after K) are still in flight
+  wait_vm(S / 64);
+  __syncthreads();
+  bool v_ready = false;
 #pragma unroll 1
   for (int pass = 0; pass < rpw / 128; ++pass) {
     const int q0 = qt * rpw + wid * (rpw / 8) + pass * 16;
-    if (q0 >= S) break;
-    const bf16x8 qf0 = glb_frag(base, ld, q0, 0, lane);
-    const bf16x8 qf1 = glb_frag(base, ld, q0, 1, lane);
-    f4v st[AT_MAXS / 16];
-    float mx = -INFINITY;
+    const bool active = q0 < S;
+    f4v st[NKB];
+    float mx = -INFINITY, sum = 0.0f;
+    if (active) {
+      const bf16x8 qf0 = glb_frag(base, ld, q0, 0, lane);
+      const bf16x8 qf1 = glb_frag(base, ld, q0, 1, lane);
 #pragma unroll
-    for (int f = 0; f < AT_MAXS / 16; ++f) {
-      if (f < nkb) {
+      for (int f = 0; f < NKB; ++f) {
         f4v a = (f4v){0.f, 0.f, 0.f, 0.f};
-        a = MFMA(kc_frag(sK, f * 16, 0, lane), qf0, a);
-        a = MFMA(kc_frag(sK, f * 16, 1, lane), qf1, a);
+        a = MFMA(__builtin_bit_cast(bf16x8, *reinterpret_cast<const s8v*>(kb0 + f * 2048)), qf0, a);
+        a = MFMA(__builtin_bit_cast(bf16x8, *reinterpret_cast<const s8v*>(kb1 + f * 2048)), qf1, a);
         const float4 mb = *reinterpret_cast<const float4*>(sMask + f * 16 + g * 4);
-        a[0] = a[0] * scale + mb.x;
-        a[1] = a[1] * scale + mb.y;
-        a[2] = a[2] * scale + mb.z;
-        a[3] = a[3] * scale + mb.w;
+        // scores in the log2 domain (scale and mask pre-multiplied by log2 e): exp becomes a bare v_exp_f32
+        a[0] = a[0] * scale2 + mb.x;
+        a[1] = a[1] * scale2 + mb.y;
+        a[2] = a[2] * scale2 + mb.z;
+        a[3] = a[3] * scale2 + mb.w;
         mx = fmaxf(mx, fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])));
         st[f] = a;
       }
-    }
-    mx = group4_max(mx);
-    float sum = 0.0f;
+      mx = group4_max(mx);
 #pragma unroll
-    for (int f = 0; f < AT_MAXS / 16; ++f) {
-      if (f < nkb) {
+      for (int f = 0; f < NKB; ++f) {
         f4v a = st[f];
-        a[0] = __expf(a[0] - mx);
-        a[1] = __expf(a[1] - mx);
-        a[2] = __expf(a[2] - mx);
-        a[3] = __expf(a[3] - mx);
+        a[0] = __builtin_amdgcn_exp2f(a[0] - mx);
+        a[1] = __builtin_amdgcn_exp2f(a[1] - mx);
+        a[2] = __builtin_amdgcn_exp2f(a[2] - mx);
+        a[3] = __builtin_amdgcn_exp2f(a[3] - mx);
         sum += (a[0] + a[1]) + (a[2] + a[3]);
         st[f] = a;
       }
+      sum = group4_sum(sum);
     }
-    sum = group4_sum(sum);
-    const float inv = 1.0f / sum;
-    f4v o[4];
+    if (!v_ready) {  // first pass only (uniform): V is needed from here on
+      wait_vm(0);
+      __syncthreads();
+      v_ready = true;
+    }
+    if (active) {
+      const float inv = 1.0f / sum;
+      f4v o[4];
 #pragma unroll
-    for (int db = 0; db < 4; ++db) o[db] = (f4v){0.f, 0.f, 0.f, 0.f};
+      for (int db = 0; db < 4; ++db) o[db] = (f4v){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int kc = 0; kc < AT_MAXS / 32; ++kc) {
-      if (kc * 2 < nkb) {
+      for (int kc = 0; kc < NKB / 2; ++kc) {
         const bf16x8 pb = pack_b(st[2 * kc] * inv, st[2 * kc + 1] * inv);
 #pragma unroll
-        for (int db = 0; db < 4; ++db) o[db] = MFMA(tr_frag(sV, kc, db, lane), pb, o[db]);
+        for (int db = 0; db < 4; ++db) {
+          const unsigned char* a = vb[db] + kc * 4096;
+          const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4v __attribute__((address_space(3)))*)(a));
+          const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4v __attribute__((address_space(3)))*)(a + 16 * 128));
+          s8v v;
+          v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+          v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+          o[db] = MFMA(__builtin_bit_cast(bf16x8, v), pb, o[db]);
+        }
       }
-    }
-    // O^T fragment: lane holds O[q0+li][db*16 + g*4 .. +3]
-    bf16_t* orow = ctx + (size_t)(b * S + q0 + li) * H + h * AT_D;
+      // O^T fragment: lane holds O[q0+li][db*16 + g*4 .. +3]
+      bf16_t* orow = ctx + (size_t)(b * S + q0 + li) * H + h * AT_D;
 #pragma unroll
-    for (int db = 0; db < 4; ++db) {
-      uint2 u;
-      u.x = pack2bf(o[db][0], o[db][1]);
-      u.y = pack2bf(o[db][2], o[db][3]);
-      *reinterpret_cast<uint2*>(orow + db * 16 + g * 4) = u;
+      for (int db = 0; db < 4; ++db) {
+        uint2 u;
+        u.x = pack2bf(o[db][0], o[db][1]);
+        u.y = pack2bf(o[db][2], o[db][3]);
+        *reinterpret_cast<uint2*>(orow + db * 16 + g * 4) = u;
+      }
+      if (g == 0) lse[((size_t)b * A + h) * S + q0 + li] = (mx + __log2f(sum)) * 0.6931471805599453f;
     }
-    if (g == 0) lse[((size_t)b * A + h) * S + q0 + li] = mx + __logf(sum);
   }
 }
 
@@ -416,22 +443,40 @@ static inline int pick_rpw(int B, int S, int A) {
   return rpw;
 }
 
+template <int NKB>
+static int launch_attn_fwd(const bf16_t* qkv, const float* maskbias, bf16_t* ctx, float* lse, int B, int H, int A, int rpw,
+                           hipStream_t stream) {
+  static bool once = false;
+  if (!once) {
+    int r = set_lds(reinterpret_cast<const void*>(attn_fwd_kernel<NKB>), AT_LDS_BYTES);
+    if (r) return r;
+    once = true;
+  }
+  const int S = NKB * 16;
+  hipLaunchKernelGGL(attn_fwd_kernel<NKB>, dim3((S + rpw - 1) / rpw, A, B), dim3(512), AT_LDS_BYTES, stream, qkv, maskbias, ctx,
+                     lse, H, A, 0.125f, rpw);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
 extern "C" {
 
 // qkv bf16 [B*S, 3H] ; maskbias f32 [B,S] ; ctx bf16 [B*S, H] ; lse f32 [B, A, S]
 // constraints: H = A * 64, S % 64 == 0, 64 <= S <= 512
 int kbner_attn_fwd(const bf16_t* qkv, const float* maskbias, bf16_t* ctx, float* lse, int B, int S, int H, int A, void* stream) {
   KBNER_CHECK_ARG(B > 0 && A > 0 && H == A * AT_D && S % 64 == 0 && S >= 64 && S <= AT_MAXS);
-  static bool once = false;
-  if (!once) {
-    int r = set_lds(reinterpret_cast<const void*>(attn_fwd_kernel), AT_LDS_BYTES);
-    if (r) return r;
-    once = true;
-  }
   const int rpw = pick_rpw(B, S, A);
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3((S + rpw - 1) / rpw, A, B), dim3(512), AT_LDS_BYTES, (hipStream_t)stream, qkv,
-                     maskbias, ctx, lse, S, H, A, 0.125f, rpw);
-  KBNER_LAUNCH_RET();
+  hipStream_t st = (hipStream_t)stream;
+  switch (S / 64) {
+    case 1: return launch_attn_fwd<4>(qkv, maskbias, ctx, lse, B, H, A, rpw, st);
+    case 2: return launch_attn_fwd<8>(qkv, maskbias, ctx, lse, B, H, A, rpw, st);
+    case 3: return launch_attn_fwd<12>(qkv, maskbias, ctx, lse, B, H, A, rpw, st);
+    case 4: return launch_attn_fwd<16>(qkv, maskbias, ctx, lse, B, H, A, rpw, st);
+    case 5: return launch_attn_fwd<20>(qkv, maskbias, ctx, lse, B, H, A, rpw, st);
+    case 6: return launch_attn_fwd<24>(qkv, maskbias, ctx, lse, B, H, A, rpw, st);
+    case 7: return launch_attn_fwd<28>(qkv, maskbias, ctx, lse, B, H, A, rpw, st);
+    default: return launch_attn_fwd<32>(qkv, maskbias, ctx, lse, B, H, A, rpw, st);
+  }
 }
 
 // dctx bf16 [B*S,H] (dO) ; ctx (O) ; lse ; Dws f32 [B,A,S] workspace ; dqkv bf16 [B*S,3H] out

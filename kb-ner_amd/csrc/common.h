@@ -28,16 +28,14 @@ typedef float f4v __attribute__((ext_vector_type(4)));
 typedef float f16v __attribute__((ext_vector_type(16)));
 
 static __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
-static __device__ __forceinline__ bf16_t f2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  // round-to-nearest-even; NaN stays NaN (quiet)
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
-}
+// fp32 -> bf16 through the native conversion: hipcc lowers a pair to ONE v_cvt_pk_bf16_f32 (round-to-nearest-even)
+// instead of the ~12 integer VALU ops of a hand-rolled rounding -- this sits in every GEMM / attention / LN epilogue.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 static __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+  const bf16x2_t v = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(uint32_t, v);
 }
+static __device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack2bf(f, 0.0f) & 0xffffu); }
 
 static __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
