@@ -120,6 +120,35 @@ static __device__ __forceinline__ float group4_max(float v) {
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 
+// Hoisted addressing: the XOR swizzle of an LDS row depends only on (row & 15), so every fragment address is a
+// per-lane base (computed once per kernel) plus a tile offset that is a multiple of 2048 bytes.
+struct PanelBases {
+  const unsigned char* kc[2];  // k-contiguous fragment bases for k-step 0 / 1 (row = lane & 15)
+  const unsigned char* tr[4];  // transpose-read bases for d-block 0..3 (row = g*4 + (lane&15)>>2)
+};
+static __device__ __forceinline__ PanelBases panel_bases(const unsigned char* s, int lane) {
+  PanelBases b;
+  const int g = lane >> 4, li = lane & 15;
+  b.kc[0] = s + li * 128 + (((0 * 4 + g) ^ kc_swz(li)) << 4);
+  b.kc[1] = s + li * 128 + (((1 * 4 + g) ^ kc_swz(li)) << 4);
+  const int vrow = g * 4 + (li >> 2);
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+    b.tr[db] = s + vrow * 128 + (((db * 2 + ((li & 3) >> 1)) ^ kc_swz(vrow)) << 4) + ((li & 1) << 3);
+  return b;
+}
+static __device__ __forceinline__ bf16x8 kc_at(const unsigned char* base, int off) {
+  return __builtin_bit_cast(bf16x8, *reinterpret_cast<const s8v*>(base + off));
+}
+static __device__ __forceinline__ bf16x8 tr_at(const unsigned char* base, int off) {
+  const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4v __attribute__((address_space(3)))*)(base + off));
+  const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4v __attribute__((address_space(3)))*)(base + off + 16 * 128));
+  s8v v;
+  v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+  v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+  return __builtin_bit_cast(bf16x8, v);
+}
+
 // ------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------
@@ -276,11 +305,13 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(const bf16_t* __res
   const bf16_t* base = qkv + (size_t)b * S * ld + h * AT_D;
   stage_panel(base + H, ld, S, sK, wid, lane);
   stage_panel(base + 2 * H, ld, S, sV, wid, lane);
-  for (int i = tid; i < S; i += 512) sMask[i] = maskbias[(size_t)b * S + i];
+  for (int i = tid; i < S; i += 512) sMask[i] = maskbias[(size_t)b * S + i] * 1.4426950408889634f;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   const int g = lane >> 4, li = lane & 15;
   const int nkc = S / 32;
+  const float scale2 = scale * 1.4426950408889634f;
+  const PanelBases pK = panel_bases(sK, lane), pV = panel_bases(sV, lane);
   const bf16_t* dob = dctx + (size_t)b * S * H + h * AT_D;
 #pragma unroll 1
   for (int pass = 0; pass < rpw / 128; ++pass) {
@@ -291,22 +322,32 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(const bf16_t* __res
     const bf16x8 do0 = glb_frag(dob, H, q0, 0, lane);
     const bf16x8 do1 = glb_frag(dob, H, q0, 1, lane);
     const size_t sidx = ((size_t)b * A + h) * S + q0 + li;
-    const float l_q = lse[sidx];
+    const float l_q = lse[sidx] * 1.4426950408889634f;  // log2 domain
     const float d_q = Dv[sidx];
     f4v dq[4];
 #pragma unroll
     for (int db = 0; db < 4; ++db) dq[db] = (f4v){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
+    // two-stage software pipeline: the 8 score / dP MFMAs of chunk kc+1 are issued before the softmax VALU work
+    // of chunk kc, so the matrix pipe runs under the exp2 / multiply stream of the same wave
+#define DQ_SP(S0, S1, P0, P1, CO)                 \
+  S0 = MFMA(kc_at(pK.kc[0], (CO)), qf0, zero4);          \
+  S0 = MFMA(kc_at(pK.kc[1], (CO)), qf1, S0);             \
+  S1 = MFMA(kc_at(pK.kc[0], (CO) + 2048), qf0, zero4);   \
+  S1 = MFMA(kc_at(pK.kc[1], (CO) + 2048), qf1, S1);      \
+  P0 = MFMA(kc_at(pV.kc[0], (CO)), do0, zero4);          \
+  P0 = MFMA(kc_at(pV.kc[1], (CO)), do1, P0);             \
+  P1 = MFMA(kc_at(pV.kc[0], (CO) + 2048), do0, zero4);   \
+  P1 = MFMA(kc_at(pV.kc[1], (CO) + 2048), do1, P1)
+    const f4v zero4 = (f4v){0.f, 0.f, 0.f, 0.f};
+    f4v s0, s1, p0, p1;
+    DQ_SP(s0, s1, p0, p1, 0);
     for (int kc = 0; kc < nkc; ++kc) {
-      f4v s0 = (f4v){0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
-      s0 = MFMA(kc_frag(sK, kc * 32, 0, lane), qf0, s0);
-      s0 = MFMA(kc_frag(sK, kc * 32, 1, lane), qf1, s0);
-      s1 = MFMA(kc_frag(sK, kc * 32 + 16, 0, lane), qf0, s1);
-      s1 = MFMA(kc_frag(sK, kc * 32 + 16, 1, lane), qf1, s1);
-      p0 = MFMA(kc_frag(sV, kc * 32, 0, lane), do0, p0);
-      p0 = MFMA(kc_frag(sV, kc * 32, 1, lane), do1, p0);
-      p1 = MFMA(kc_frag(sV, kc * 32 + 16, 0, lane), do0, p1);
-      p1 = MFMA(kc_frag(sV, kc * 32 + 16, 1, lane), do1, p1);
+      const int co = kc * 4096;
+      // branch-free prefetch of the next chunk (the last iteration recomputes chunk 0 and discards it) so the whole
+      // body is ONE basic block the scheduler can interleave
+      f4v n0, n1, m0_, m1_;
+      const int con = (kc + 1 < nkc) ? co + 4096 : 0;
+      DQ_SP(n0, n1, m0_, m1_, con);
       const float4 m0 = *reinterpret_cast<const float4*>(sMask + kc * 32 + g * 4);
       const float4 m1 = *reinterpret_cast<const float4*>(sMask + kc * 32 + 16 + g * 4);
       const float mb0[4] = {m0.x, m0.y, m0.z, m0.w};
@@ -314,15 +355,17 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(const bf16_t* __res
       f4v ds0, ds1;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float pr0 = __expf(s0[r] * scale + mb0[r] - l_q);
-        const float pr1 = __expf(s1[r] * scale + mb1[r] - l_q);
+        const float pr0 = __builtin_amdgcn_exp2f(s0[r] * scale2 + mb0[r] - l_q);
+        const float pr1 = __builtin_amdgcn_exp2f(s1[r] * scale2 + mb1[r] - l_q);
         ds0[r] = pr0 * (p0[r] - d_q);
         ds1[r] = pr1 * (p1[r] - d_q);
       }
       const bf16x8 dsb = pack_b(ds0, ds1);
 #pragma unroll
-      for (int db = 0; db < 4; ++db) dq[db] = MFMA(tr_frag(sK, kc, db, lane), dsb, dq[db]);
+      for (int db = 0; db < 4; ++db) dq[db] = MFMA(tr_at(pK.tr[db], co), dsb, dq[db]);
+      s0 = n0; s1 = n1; p0 = m0_; p1 = m1_;
     }
+#undef DQ_SP
     bf16_t* orow = dqkv + (size_t)(b * S + q0 + li) * ld + h * AT_D;
 #pragma unroll
     for (int db = 0; db < 4; ++db) {
@@ -356,13 +399,15 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
   stage_panel(dob, H, S, sO, wid, lane);
   const size_t sbase = ((size_t)b * A + h) * S;
   for (int i = tid; i < S; i += 512) {
-    sL[i] = lse[sbase + i];
+    sL[i] = lse[sbase + i] * 1.4426950408889634f;  // log2 domain
     sD[i] = Dv[sbase + i];
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   const int g = lane >> 4, li = lane & 15;
   const int nqc = S / 32;
+  const float scale2 = scale * 1.4426950408889634f;
+  const PanelBases pQ = panel_bases(sQ, lane), pO = panel_bases(sO, lane);
 #pragma unroll 1
   for (int pass = 0; pass < rpw / 128; ++pass) {
     const int k0 = kt * rpw + wid * (rpw / 8) + pass * 16;
@@ -371,25 +416,31 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
     const bf16x8 kf1 = glb_frag(base + H, ld, k0, 1, lane);
     const bf16x8 vf0 = glb_frag(base + 2 * H, ld, k0, 0, lane);
     const bf16x8 vf1 = glb_frag(base + 2 * H, ld, k0, 1, lane);
-    const float mb = maskbias[(size_t)b * S + k0 + li];
+    const float mb = maskbias[(size_t)b * S + k0 + li] * 1.4426950408889634f;
     f4v dk[4], dv[4];
 #pragma unroll
     for (int db = 0; db < 4; ++db) {
       dk[db] = (f4v){0.f, 0.f, 0.f, 0.f};
       dv[db] = (f4v){0.f, 0.f, 0.f, 0.f};
     }
-#pragma unroll 2
+#define DKV_SP(S0, S1, P0, P1, CO)                \
+  S0 = MFMA(kc_at(pQ.kc[0], (CO)), kf0, zero4);          \
+  S0 = MFMA(kc_at(pQ.kc[1], (CO)), kf1, S0);             \
+  S1 = MFMA(kc_at(pQ.kc[0], (CO) + 2048), kf0, zero4);   \
+  S1 = MFMA(kc_at(pQ.kc[1], (CO) + 2048), kf1, S1);      \
+  P0 = MFMA(kc_at(pO.kc[0], (CO)), vf0, zero4);          \
+  P0 = MFMA(kc_at(pO.kc[1], (CO)), vf1, P0);             \
+  P1 = MFMA(kc_at(pO.kc[0], (CO) + 2048), vf0, zero4);   \
+  P1 = MFMA(kc_at(pO.kc[1], (CO) + 2048), vf1, P1)
+    const f4v zero4 = (f4v){0.f, 0.f, 0.f, 0.f};
+    f4v s0, s1, p0, p1;
+    DKV_SP(s0, s1, p0, p1, 0);
     for (int qc = 0; qc < nqc; ++qc) {
       // S and dP in [q rows, key cols] orientation: lane holds q = qc*32 + f*16 + g*4 + r, key = k0 + li
-      f4v s0 = (f4v){0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
-      s0 = MFMA(kc_frag(sQ, qc * 32, 0, lane), kf0, s0);
-      s0 = MFMA(kc_frag(sQ, qc * 32, 1, lane), kf1, s0);
-      s1 = MFMA(kc_frag(sQ, qc * 32 + 16, 0, lane), kf0, s1);
-      s1 = MFMA(kc_frag(sQ, qc * 32 + 16, 1, lane), kf1, s1);
-      p0 = MFMA(kc_frag(sO, qc * 32, 0, lane), vf0, p0);
-      p0 = MFMA(kc_frag(sO, qc * 32, 1, lane), vf1, p0);
-      p1 = MFMA(kc_frag(sO, qc * 32 + 16, 0, lane), vf0, p1);
-      p1 = MFMA(kc_frag(sO, qc * 32 + 16, 1, lane), vf1, p1);
+      const int co = qc * 4096;
+      f4v n0, n1, m0_, m1_;
+      const int con = (qc + 1 < nqc) ? co + 4096 : 0;  // branch-free (see attn_bwd_dq_kernel)
+      DKV_SP(n0, n1, m0_, m1_, con);
       const float4 l0 = *reinterpret_cast<const float4*>(sL + qc * 32 + g * 4);
       const float4 l1 = *reinterpret_cast<const float4*>(sL + qc * 32 + 16 + g * 4);
       const float4 d0 = *reinterpret_cast<const float4*>(sD + qc * 32 + g * 4);
@@ -399,8 +450,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
       f4v pr0, pr1, ds0, ds1;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        pr0[r] = __expf(s0[r] * scale + mb - la[r]);
-        pr1[r] = __expf(s1[r] * scale + mb - lb[r]);
+        pr0[r] = __builtin_amdgcn_exp2f(s0[r] * scale2 + mb - la[r]);
+        pr1[r] = __builtin_amdgcn_exp2f(s1[r] * scale2 + mb - lb[r]);
         ds0[r] = pr0[r] * (p0[r] - da[r]);
         ds1[r] = pr1[r] * (p1[r] - dbv[r]);
       }
@@ -408,10 +459,12 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
       const bf16x8 dsb = pack_b(ds0, ds1);
 #pragma unroll
       for (int db = 0; db < 4; ++db) {
-        dv[db] = MFMA(tr_frag(sO, qc, db, lane), pb, dv[db]);
-        dk[db] = MFMA(tr_frag(sQ, qc, db, lane), dsb, dk[db]);
+        dv[db] = MFMA(tr_at(pO.tr[db], co), pb, dv[db]);
+        dk[db] = MFMA(tr_at(pQ.tr[db], co), dsb, dk[db]);
       }
+      s0 = n0; s1 = n1; p0 = m0_; p1 = m1_;
     }
+#undef DKV_SP
     bf16_t* krow = dqkv + (size_t)(b * S + k0 + li) * ld + H + h * AT_D;
     bf16_t* vrow = krow + H;
 #pragma unroll
