@@ -63,15 +63,17 @@ int kbner_colsum(const kbner_bf16* x, float* out, int M, int N, int ld, void* st
 /* ---------------- LayerNorm / embeddings (transformers BertEmbeddings, BertSelfOutput, BertOutput) ---------------- */
 int kbner_ln_fwd(const kbner_bf16* h, const float* gamma, const float* beta, float eps, kbner_bf16* y, float* mean,
                  float* rstd, int M, int H, void* stream);
+/* ws: kbner_ln_bwd_ws_floats(H) floats of scratch for the per-block partial column sums (dgamma, dbeta, dbias are +=) */
+int kbner_ln_bwd_ws_floats(int H);
 int kbner_ln_bwd(const kbner_bf16* dy, const kbner_bf16* h, const float* mean, const float* rstd, const float* gamma,
-                 kbner_bf16* dh, float* dgamma, float* dbeta, float* dbias, int M, int H, void* stream);
+                 kbner_bf16* dh, float* dgamma, float* dbeta, float* dbias, float* ws, int M, int H, void* stream);
 /* word[ids] + pos[pos_ids] + type[0] -> h0 (saved) -> LayerNorm -> y */
 int kbner_embed_ln_fwd(const int* ids, const int* pos_ids, const float* word, const float* pos, const float* type0,
                        const float* gamma, const float* beta, float eps, kbner_bf16* h0, kbner_bf16* y, float* mean,
                        float* rstd, int M, int H, void* stream);
 int kbner_embed_ln_bwd(const kbner_bf16* dy, const kbner_bf16* h0, const float* mean, const float* rstd, const float* gamma,
                        const int* ids, const int* pos_ids, float* dgamma, float* dbeta, float* dword, float* dpos,
-                       float* dtype0, int M, int H, void* stream);
+                       float* dtype0, float* ws, int M, int H, void* stream);
 
 /* ---------------- bf16 MFMA GEMM (torch.nn.Linear fwd/bwd inside transformers' BertLayer) ---------------- */
 #define KBNER_GEMM_NT 0 /* C[M,N] = A[M,K] . B[N,K]^T        forward  */
@@ -90,6 +92,7 @@ int kbner_gemm_bf16(int layout, const kbner_bf16* A, int lda, const kbner_bf16* 
 /* Grouped GEMM on the 256x256x64 / 8-wave kernel: up to 16 problems of one layout per launch (the weight-
  * gradient GEMMs of four encoder layers = 768 tiles fill the chip without split-K).  Per problem M,N % 256 == 0, K % 64 == 0. */
 #define KBNER_EPI_RMW32 32 /* C32 += result by non-atomic 16-byte read-modify-write */
+#define KBNER_EPI_COLSUM 64 /* also accumulate the output's column sums (the producing layer's bias gradient) */
 typedef struct kbner_gemm_problem {
   const kbner_bf16* A;
   const kbner_bf16* B;
@@ -99,6 +102,7 @@ typedef struct kbner_gemm_problem {
   const kbner_bf16* addend;
   const kbner_bf16* aux;
   kbner_bf16* out2;
+  float* colsum; /* KBNER_EPI_COLSUM: colsum[n] += sum_m out[m,n] (fp32 atomics) */
   int M, N, K;
   int lda, ldb, ldc, ldc32, ldadd, ldaux, ldout2;
   int epi;

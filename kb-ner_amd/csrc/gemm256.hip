@@ -17,6 +17,7 @@
 #define EPI_DGELU 8
 #define EPI_ATOMIC32 16
 #define EPI_RMW32 32  // C32[m,n] += result, non-atomic 16-byte RMW (each output element owned by one lane)
+#define EPI_COLSUM 64  // colsum[n] += sum_m out[m,n] (bias gradient of the producing layer), fp32 atomics, 2 per column per tile
 
 #define G2_MAXP 16
 
@@ -29,6 +30,7 @@ struct GemmProblem {
   const bf16_t* addend;
   const bf16_t* aux;
   bf16_t* out2;
+  float* colsum;
   int M, N, K;
   int lda, ldb, ldc, ldc32, ldadd, ldaux, ldout2;
   int epi;
@@ -279,6 +281,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GroupArgs ga) {
   const int epi = g.epi;
   const float alpha = g.alpha;
   const int gq = lane >> 4;
+  float csum[2][8];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int r = 0; r < 8; ++r) csum[q][r] = 0.0f;
 #pragma unroll
   for (int mi = 0; mi < 8; ++mi) {
     const int m = m0 + wm * 128 + mi * 16 + (lane & 15);
@@ -352,7 +359,23 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GroupArgs ga) {
       o.z = pack2bf(v[4], v[5]);
       o.w = pack2bf(v[6], v[7]);
       *reinterpret_cast<uint4*>(g.C + (size_t)m * g.ldc + n) = o;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) csum[q][r] += v[r];
     }
+  }
+  if (epi & EPI_COLSUM) {
+    // this wave's 128 rows: 8 in registers (mi), 16 across the lanes of a group (xor-shuffle), then one atomic per column
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        float x = csum[q][r];
+        x += __shfl_xor(x, 1, 64);
+        x += __shfl_xor(x, 2, 64);
+        x += __shfl_xor(x, 4, 64);
+        x += __shfl_xor(x, 8, 64);
+        if ((lane & 15) == 0) atomicAdd(g.colsum + n0 + wn * 64 + q * 32 + gq * 8 + r, x);
+      }
   }
   if (!has_next) break;
   pend = (epi & EPI_ATOMIC32) ? 0 : ((epi & (EPI_GELU | EPI_RMW32)) ? 32 : 16);
@@ -396,6 +419,7 @@ struct kbner_gemm_problem {
   const bf16_t* addend;
   const bf16_t* aux;
   bf16_t* out2;
+  float* colsum;
   int M, N, K;
   int lda, ldb, ldc, ldc32, ldadd, ldaux, ldout2;
   int epi;
@@ -424,8 +448,9 @@ int kbner_gemm_bf16_grouped(int layout, int nprob, const kbner_gemm_problem* pro
     if (s.epi & EPI_ADD) KBNER_CHECK_ARG(s.addend != nullptr && s.ldadd % 8 == 0);
     if (s.epi & EPI_DGELU) KBNER_CHECK_ARG(s.aux != nullptr && s.ldaux % 8 == 0);
     if (s.epi & EPI_GELU) KBNER_CHECK_ARG(s.out2 != nullptr && s.ldout2 % 8 == 0);
+    if (s.epi & EPI_COLSUM) KBNER_CHECK_ARG(s.colsum != nullptr && !(s.epi & (EPI_ATOMIC32 | EPI_RMW32)));
     GemmProblem& d = ga.p[i];
-    d.A = s.A; d.B = s.B; d.C = s.C; d.C32 = s.C32; d.bias = s.bias; d.addend = s.addend; d.aux = s.aux; d.out2 = s.out2;
+    d.A = s.A; d.B = s.B; d.C = s.C; d.C32 = s.C32; d.bias = s.bias; d.addend = s.addend; d.aux = s.aux; d.out2 = s.out2; d.colsum = s.colsum;
     d.M = s.M; d.N = s.N; d.K = s.K; d.lda = s.lda; d.ldb = s.ldb; d.ldc = s.ldc; d.ldc32 = s.ldc32; d.ldadd = s.ldadd;
     d.ldaux = s.ldaux; d.ldout2 = s.ldout2; d.epi = s.epi; d.alpha = s.alpha; d.tile_begin = tiles; d.pad_ = 0;
     ga.tile_begin[i] = tiles;

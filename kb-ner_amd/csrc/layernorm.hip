@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                      float* __restrict__ dbias, const int* __restrict__ ids,
                                                      const int* __restrict__ pos_ids, float* __restrict__ dword,
-                                                     float* __restrict__ dpos, int M, int H) {
+                                                     float* __restrict__ dpos, float* __restrict__ ws, int M, int H) {
   __shared__ float red[3][4][64 * 8 * NCH];
   const int lane = threadIdx.x % 64;
   const int wid = threadIdx.x / 64;
@@ -238,7 +238,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
       }
     }
   }
-  // block reduction of the per-column accumulators, then one atomic per column per block
+  // Column sums: combine the block's 4 waves in LDS, then write the block's partial row to the workspace with plain
+  // coalesced stores; ln_colreduce_kernel sums the partial rows.  (Per-block global atomics -- 3 x H per block -- were
+  // the bottleneck of this kernel: with enough blocks to hide HBM latency they outnumber the useful traffic.)
 #pragma unroll
   for (int c = 0; c < NCH; ++c)
 #pragma unroll
@@ -249,17 +251,39 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
       red[2][wid][col] = ah.v[c][j];
     }
   __syncthreads();
+  float* wrow = ws + (size_t)blockIdx.x * 3 * H;
   for (int col = threadIdx.x; col < H; col += 256) {
-    const float a = red[0][0][col] + red[0][1][col] + red[0][2][col] + red[0][3][col];
-    const float b = red[1][0][col] + red[1][1][col] + red[1][2][col] + red[1][3][col];
-    atomicAdd(dgamma + col, a);
-    atomicAdd(dbeta + col, b);
-    if (dbias) {
-      const float cc = red[2][0][col] + red[2][1][col] + red[2][2][col] + red[2][3][col];
-      atomicAdd(dbias + col, cc);
-    }
+    wrow[col] = (red[0][0][col] + red[0][1][col]) + (red[0][2][col] + red[0][3][col]);
+    wrow[H + col] = (red[1][0][col] + red[1][1][col]) + (red[1][2][col] + red[1][3][col]);
+    wrow[2 * H + col] = (red[2][0][col] + red[2][1][col]) + (red[2][2][col] + red[2][3][col]);
   }
 }
+
+// out_k[col] += sum_blocks ws[block][k][col], k = 0..2 (dgamma, dbeta, dbias).  grid = (ceil(3H/64), 8): a block owns 64
+// consecutive entries of the 3H-wide partial row and one eighth of the partial rows; 4 row-groups of threads x 8-way
+// unrolled loads keep ~32 loads in flight per thread-column, the 8 slices meet through one atomic per entry.
+__global__ __launch_bounds__(256) void ln_colreduce_kernel(const float* __restrict__ ws, int nblocks, int H, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta, float* __restrict__ dbias) {
+  __shared__ float red[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + tx;  // over 3*H
+  const int per = (nblocks + gridDim.y - 1) / gridDim.y;
+  const int b0 = blockIdx.y * per, b1 = min(nblocks, b0 + per);
+  float acc = 0.0f;
+  if (i < 3 * H) {
+#pragma unroll 8
+    for (int b = b0 + ty; b < b1; b += 4) acc += ws[(size_t)b * 3 * H + i];
+  }
+  red[ty][tx] = acc;
+  __syncthreads();
+  if (ty == 0 && i < 3 * H) {
+    const int k = i / H, col = i % H;
+    float* out = k == 0 ? dgamma : (k == 1 ? dbeta : dbias);
+    if (out != nullptr) atomicAdd(out + col, (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]));
+  }
+}
+
+#define LN_BWD_MAXBLOCKS 1024
 
 static inline int ln_grid(int M) {
   int g = (M + 3) / 4;
@@ -269,6 +293,8 @@ static inline int ln_grid(int M) {
 }
 
 extern "C" {
+
+int kbner_ln_bwd_ws_floats(int H) { return LN_BWD_MAXBLOCKS * 3 * H; }
 
 int kbner_ln_fwd(const bf16_t* h, const float* gamma, const float* beta, float eps, bf16_t* y, float* mean, float* rstd,
                  int M, int H, void* stream) {
@@ -296,34 +322,39 @@ int kbner_embed_ln_fwd(const int* ids, const int* pos_ids, const float* word, co
 }
 
 // dh may be NULL (embedding LayerNorm: nothing upstream).  dbias may be NULL.
+// ws: kbner_ln_bwd_ws_floats(H) floats of scratch (per-block partial column sums)
 int kbner_ln_bwd(const bf16_t* dy, const bf16_t* h, const float* mean, const float* rstd, const float* gamma, bf16_t* dh,
-                 float* dgamma, float* dbeta, float* dbias, int M, int H, void* stream) {
-  KBNER_CHECK_ARG(M >= 0 && H > 0 && H % 8 == 0 && H <= 64 * 8 * LN_MAXCH);
+                 float* dgamma, float* dbeta, float* dbias, float* ws, int M, int H, void* stream) {
+  KBNER_CHECK_ARG(M >= 0 && H > 0 && H % 8 == 0 && H <= 64 * 8 * LN_MAXCH && ws != nullptr);
   if (M == 0) return 0;
   int grid = ln_grid(M);
-  if (grid > 1024) grid = 1024;
+  if (grid > LN_BWD_MAXBLOCKS) grid = LN_BWD_MAXBLOCKS;
   if (H <= 512)
     hipLaunchKernelGGL((ln_bwd_kernel<1, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, h, mean, rstd, gamma, dh,
-                       dgamma, dbeta, dbias, nullptr, nullptr, nullptr, nullptr, M, H);
+                       dgamma, dbeta, dbias, nullptr, nullptr, nullptr, nullptr, ws, M, H);
   else
     hipLaunchKernelGGL((ln_bwd_kernel<2, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, h, mean, rstd, gamma, dh,
-                       dgamma, dbeta, dbias, nullptr, nullptr, nullptr, nullptr, M, H);
+                       dgamma, dbeta, dbias, nullptr, nullptr, nullptr, nullptr, ws, M, H);
+  hipLaunchKernelGGL(ln_colreduce_kernel, dim3((3 * H + 63) / 64, 8), dim3(256), 0, (hipStream_t)stream, ws, grid, H, dgamma, dbeta,
+                     dbias);
   KBNER_LAUNCH_RET();
 }
 
 int kbner_embed_ln_bwd(const bf16_t* dy, const bf16_t* h0, const float* mean, const float* rstd, const float* gamma,
                        const int* ids, const int* pos_ids, float* dgamma, float* dbeta, float* dword, float* dpos,
-                       float* dtype0, int M, int H, void* stream) {
-  KBNER_CHECK_ARG(M >= 0 && H > 0 && H % 8 == 0 && H <= 64 * 8 * LN_MAXCH);
+                       float* dtype0, float* ws, int M, int H, void* stream) {
+  KBNER_CHECK_ARG(M >= 0 && H > 0 && H % 8 == 0 && H <= 64 * 8 * LN_MAXCH && ws != nullptr);
   if (M == 0) return 0;
   int grid = ln_grid(M);
-  if (grid > 1024) grid = 1024;
+  if (grid > LN_BWD_MAXBLOCKS) grid = LN_BWD_MAXBLOCKS;
   if (H <= 512)
     hipLaunchKernelGGL((ln_bwd_kernel<1, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, h0, mean, rstd, gamma,
-                       (bf16_t*)nullptr, dgamma, dbeta, dtype0, ids, pos_ids, dword, dpos, M, H);
+                       (bf16_t*)nullptr, dgamma, dbeta, dtype0, ids, pos_ids, dword, dpos, ws, M, H);
   else
     hipLaunchKernelGGL((ln_bwd_kernel<2, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, h0, mean, rstd, gamma,
-                       (bf16_t*)nullptr, dgamma, dbeta, dtype0, ids, pos_ids, dword, dpos, M, H);
+                       (bf16_t*)nullptr, dgamma, dbeta, dtype0, ids, pos_ids, dword, dpos, ws, M, H);
+  hipLaunchKernelGGL(ln_colreduce_kernel, dim3((3 * H + 63) / 64, 8), dim3(256), 0, (hipStream_t)stream, ws, grid, H, dgamma, dbeta,
+                     dtype0);
   KBNER_LAUNCH_RET();
 }
 

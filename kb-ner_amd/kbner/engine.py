@@ -15,7 +15,7 @@ import math
 import torch
 
 from . import ops
-from .lib import EPI_ADD, EPI_ATOMIC32, EPI_BIAS, EPI_DGELU, EPI_GELU, EPI_RMW32, GEMM_NN, GEMM_NT, GEMM_TN
+from .lib import EPI_ADD, EPI_ATOMIC32, EPI_BIAS, EPI_COLSUM, EPI_DGELU, EPI_GELU, EPI_RMW32, GEMM_NN, GEMM_NT, GEMM_TN
 
 BF16, F32, I32 = torch.bfloat16, torch.float32, torch.int32
 
@@ -324,9 +324,13 @@ class Tagger:
             ops.ln_bwd(dx, ac.h2[l], ac.st2[l][0], ac.st2[l][1], a.param(p + "ln2.g"), dh, a.grad(p + "ln2.g"),
                        a.grad(p + "ln2.b"), a.grad(p + "ffn2.bias"))
             # FFN down dgrad: dpre = (dh W2) * gelu'(pre)
-            ops.gemm(GEMM_NN, dh, a.bf(p + "ffn2.weight"), Mp, F_, H, C=dpre, aux=ac.pre[l], epi=EPI_DGELU)
+            # (its column sums = d ffn1.bias are accumulated by the same epilogue when the 256^2 kernel runs)
+            fused = Mp % 256 == 0 and F_ % 256 == 0
+            ops.gemm(GEMM_NN, dh, a.bf(p + "ffn2.weight"), Mp, F_, H, C=dpre, aux=ac.pre[l],
+                     epi=EPI_DGELU | (EPI_COLSUM if fused else 0), colsum=a.grad(p + "ffn1.bias") if fused else None)
             # FFN up
-            ops.colsum(dpre, a.grad(p + "ffn1.bias"))
+            if not fused:
+                ops.colsum(dpre, a.grad(p + "ffn1.bias"))
             ops.gemm(GEMM_NN, dpre, a.bf(p + "ffn1.weight"), Mp, H, F_, C=ac.dx1, addend=dh, epi=EPI_ADD)
             # LN1 backward; fused: d o.bias
             ops.ln_bwd(ac.dx1, ac.h1[l], ac.st1[l][0], ac.st1[l][1], a.param(p + "ln1.g"), dh1, a.grad(p + "ln1.g"),

@@ -28,9 +28,10 @@ SIGNATURES = {
     "kbner_head_bwd_dw": (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
     "kbner_colsum": (c_int, [P, P, c_int, c_int, c_int, P]),
     "kbner_ln_fwd": (c_int, [P, P, P, c_float, P, P, P, c_int, c_int, P]),
-    "kbner_ln_bwd": (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, P]),
+    "kbner_ln_bwd_ws_floats": (c_int, [c_int]),
+    "kbner_ln_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, c_int, P]),
     "kbner_embed_ln_fwd": (c_int, [P, P, P, P, P, P, P, c_float, P, P, P, P, c_int, c_int, P]),
-    "kbner_embed_ln_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, P]),
+    "kbner_embed_ln_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, P]),
     "kbner_gemm_bf16": (c_int, [c_int, P, c_int, P, c_int, c_int, c_int, c_int, P, c_int, P, c_int, P, P, c_int, P, c_int,
                                 P, c_int, c_int, c_int, c_float, P]),
     "kbner_gemm_bf16_grouped": (c_int, [c_int, c_int, P, P]),
@@ -47,12 +48,12 @@ SIGNATURES = {
 }
 
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
-EPI_BIAS, EPI_GELU, EPI_ADD, EPI_DGELU, EPI_ATOMIC32, EPI_RMW32 = 1, 2, 4, 8, 16, 32
+EPI_BIAS, EPI_GELU, EPI_ADD, EPI_DGELU, EPI_ATOMIC32, EPI_RMW32, EPI_COLSUM = 1, 2, 4, 8, 16, 32, 64
 
 
 class GemmProblem(ctypes.Structure):
     """mirror of kbner_gemm_problem (include/kbner.h)"""
-    _fields_ = [("A", P), ("B", P), ("C", P), ("C32", P), ("bias", P), ("addend", P), ("aux", P), ("out2", P),
+    _fields_ = [("A", P), ("B", P), ("C", P), ("C32", P), ("bias", P), ("addend", P), ("aux", P), ("out2", P), ("colsum", P),
                 ("M", c_int), ("N", c_int), ("K", c_int), ("lda", c_int), ("ldb", c_int), ("ldc", c_int), ("ldc32", c_int),
                 ("ldadd", c_int), ("ldaux", c_int), ("ldout2", c_int), ("epi", c_int), ("alpha", c_float)]
 

@@ -108,10 +108,21 @@ def ln_fwd(h, gamma, beta, eps, y, mean, rstd):
     L.call("kbner_ln_fwd", ptr(h), ptr(gamma), ptr(beta), eps, ptr(y), ptr(mean), ptr(rstd), M, H, stream_ptr())
 
 
+_LN_WS = {}
+
+
+def ln_ws(H, device):
+    """scratch for the LayerNorm-backward column sums (one buffer per (H, device); launches on one stream serialise)"""
+    key = (H, str(device))
+    if key not in _LN_WS:
+        _LN_WS[key] = torch.empty(L.load().kbner_ln_bwd_ws_floats(H), dtype=F32, device=device)
+    return _LN_WS[key]
+
+
 def ln_bwd(dy, h, mean, rstd, gamma, dh, dgamma, dbeta, dbias=None):
     M, H = h.shape
     L.call("kbner_ln_bwd", ptr(dy), ptr(h), ptr(mean), ptr(rstd), ptr(gamma), ptr(dh), ptr(dgamma), ptr(dbeta), ptr(dbias),
-           M, H, stream_ptr())
+           ptr(ln_ws(H, h.device)), M, H, stream_ptr())
 
 
 def embed_ln_fwd(ids, pos_ids, word, pos, type0, gamma, beta, eps, h0, y, mean, rstd):
@@ -124,7 +135,7 @@ def embed_ln_fwd(ids, pos_ids, word, pos, type0, gamma, beta, eps, h0, y, mean, 
 def embed_ln_bwd(dy, h0, mean, rstd, gamma, ids, pos_ids, dgamma, dbeta, dword, dpos, dtype0):
     M, H = ids.numel(), dword.shape[1]
     L.call("kbner_embed_ln_bwd", ptr(dy), ptr(h0), ptr(mean), ptr(rstd), ptr(gamma), ptr(ids), ptr(pos_ids), ptr(dgamma),
-           ptr(dbeta), ptr(dword), ptr(dpos), ptr(dtype0), M, H, stream_ptr())
+           ptr(dbeta), ptr(dword), ptr(dpos), ptr(dtype0), ptr(ln_ws(H, dy.device)), M, H, stream_ptr())
 
 
 # ---------------------------------------------------------------- GEMM
@@ -136,9 +147,9 @@ def _addr(t):
     return t.data_ptr() if t is not None else None
 
 
-def make_problem(A, B, M, N, K, C=None, C32=None, bias=None, addend=None, aux=None, out2=None, epi=0, alpha=1.0):
+def make_problem(A, B, M, N, K, C=None, C32=None, bias=None, addend=None, aux=None, out2=None, epi=0, alpha=1.0, colsum=None):
     _chk(A, BF16, "A"); _chk(B, BF16, "B")
-    return L.GemmProblem(_addr(A), _addr(B), _addr(C), _addr(C32), _addr(bias), _addr(addend), _addr(aux), _addr(out2),
+    return L.GemmProblem(_addr(A), _addr(B), _addr(C), _addr(C32), _addr(bias), _addr(addend), _addr(aux), _addr(out2), _addr(colsum),
                          M, N, K, A.shape[1], B.shape[1], C.shape[1] if C is not None else 0,
                          C32.shape[1] if C32 is not None else 0, addend.shape[1] if addend is not None else 0,
                          aux.shape[1] if aux is not None else 0, out2.shape[1] if out2 is not None else 0, epi, alpha)
@@ -159,12 +170,14 @@ def gemm_grouped(layout, problems):
 
 
 def gemm(layout, A, B, M, N, K, C=None, C32=None, bias=None, addend=None, aux=None, out2=None, epi=0, splitk=1, alpha=1.0,
-         lda=None, ldb=None):
+         lda=None, ldb=None, colsum=None):
     """C[M,N] (bf16) or C32[M,N] += (fp32).  A/B are 2-D bf16 tensors in their memory layouts.
     Shapes divisible by 256 go to the 256^2 8-wave kernel, others to the 128^2 kernel."""
     _chk(A, BF16, "A"); _chk(B, BF16, "B")
     if M % 256 == 0 and N % 256 == 0 and splitk == 1 and lda is None and ldb is None and not FORCE_128:
-        return gemm_grouped(layout, [make_problem(A, B, M, N, K, C, C32, bias, addend, aux, out2, epi, alpha)])
+        return gemm_grouped(layout, [make_problem(A, B, M, N, K, C, C32, bias, addend, aux, out2, epi, alpha, colsum)])
+    if colsum is not None:
+        raise L.KbnerError("EPI_COLSUM needs the 256x256 kernel (M, N % 256 == 0)")
     lda = A.shape[1] if lda is None else lda
     ldb = B.shape[1] if ldb is None else ldb
     hook = GEMM_HOOK

@@ -41,6 +41,23 @@ def test_gemm(st, layout, M, N, K, epi, sk):
     assert st.check_gemm(layout, M, N, K, epi, sk) < 6e-3
 
 
+def test_gemm_colsum_epilogue(st):
+    """EPI_COLSUM: the dgrad GEMM also accumulates its output's column sums (bias gradient of the producing layer)."""
+    from kbner import ops
+    from kbner.lib import EPI_COLSUM, EPI_DGELU, GEMM_NN
+    g = torch.Generator(device="cpu").manual_seed(0)
+    M, N, K = 768, 512, 256
+    A = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16).cuda()
+    W = (torch.randn(K, N, generator=g) * 0.5).to(torch.bfloat16).cuda()
+    aux = torch.randn(M, N, generator=g).to(torch.bfloat16).cuda()
+    C = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+    cs = torch.full((N,), 3.0, device="cuda")
+    ops.gemm(GEMM_NN, A, W, M, N, K, C=C, aux=aux, epi=EPI_DGELU | EPI_COLSUM, colsum=cs)
+    torch.cuda.synchronize()
+    ref = C.float().sum(0) + 3.0
+    assert float((cs - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
+
+
 def test_gemm_grouped_wgrad(st):
     assert st.check_gemm_grouped() < 1e-5
 
