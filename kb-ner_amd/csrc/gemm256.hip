@@ -165,10 +165,17 @@ static __device__ __forceinline__ void pick_tile(const GroupArgs& ga, int id, in
 #else
   g = ga.p[pi];
 #endif
+  // Grouped (8 tile-rows at a time, column-major inside the group) ordering: the ~32 tiles an XCD works on concurrently
+  // then form an 8 x 4 patch that shares 8 A panels and 4 B panels through that XCD's L2, instead of a 1 x 32 strip that
+  // shares one A panel and streams 32 different B panels from MALL/HBM (measured: the strip order is fabric-bound).
   const int tile = wg - g.tile_begin;
-  const int tiles_n = g.N / T2;
-  m0 = (tile / tiles_n) * T2;
-  n0 = (tile % tiles_n) * T2;
+  const int tiles_n = g.N / T2, tiles_m = g.M / T2;
+  const int group = 8 * tiles_n;
+  const int first_m = (tile / group) * 8;
+  const int gm = min(tiles_m - first_m, 8);
+  const int r = tile % group;
+  m0 = (first_m + r % gm) * T2;
+  n0 = (r / gm) * T2;
 }
 
 template <bool A_KS, bool B_KS>

@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libkbner_hip.so")
+LIB_PATH = os.environ.get("KBNER_LIB") or os.path.join(_HERE, "libkbner_hip.so")  # KBNER_LIB: experiment builds only
 
 c_int, c_float, c_void_p, c_size_t = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
 P = c_void_p
