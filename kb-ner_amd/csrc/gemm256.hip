@@ -289,10 +289,24 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GroupArgs ga) {
   const float alpha = g.alpha;
   const int gq = lane >> 4;
   float csum[2][8];
+  float bq[2][8];  // this lane's 16 bias values, loaded once per tile (not once per row fragment)
 #pragma unroll
   for (int q = 0; q < 2; ++q)
 #pragma unroll
-    for (int r = 0; r < 8; ++r) csum[q][r] = 0.0f;
+    for (int r = 0; r < 8; ++r) {
+      csum[q][r] = 0.0f;
+      bq[q][r] = 0.0f;
+    }
+  if (epi & EPI_BIAS) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const float* bp = g.bias + n0 + wn * 64 + q * 32 + gq * 8;
+      const float4 b0 = *reinterpret_cast<const float4*>(bp);
+      const float4 b1 = *reinterpret_cast<const float4*>(bp + 4);
+      bq[q][0] = b0.x; bq[q][1] = b0.y; bq[q][2] = b0.z; bq[q][3] = b0.w;
+      bq[q][4] = b1.x; bq[q][5] = b1.y; bq[q][6] = b1.z; bq[q][7] = b1.w;
+    }
+  }
 #pragma unroll
   for (int mi = 0; mi < 8; ++mi) {
     const int m = m0 + wm * 128 + mi * 16 + (lane & 15);
@@ -321,10 +335,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GroupArgs ga) {
         continue;
       }
       if (epi & EPI_BIAS) {
-        const float4 b0 = *reinterpret_cast<const float4*>(g.bias + n);
-        const float4 b1 = *reinterpret_cast<const float4*>(g.bias + n + 4);
-        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
-        v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] += bq[q][r];
       }
       if (epi & EPI_ADD) {
         const uint4 u = *reinterpret_cast<const uint4*>(g.addend + (size_t)m * g.ldadd + n);
