@@ -91,7 +91,7 @@ def main():
     ap.add_argument("--seq-len", type=int, default=512)
     ap.add_argument("--model", default="large", choices=["large", "base"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sentences", type=int, default=2)
+    ap.add_argument("--cpu-sentences", type=int, default=8)
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
@@ -106,8 +106,14 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # one process per GPU over RCCL ("nccl" IS RCCL on ROCm).  KBNER_DIST_BACKEND=gloo is a functional-test escape
+        # hatch only (several ranks sharing one GPU on a 1-GPU box); never used for reported numbers.
+        backend = os.environ.get("KBNER_DIST_BACKEND", "nccl")
+        torch.cuda.set_device(local_rank % torch.cuda.device_count())
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())

@@ -220,10 +220,13 @@ class Tagger:
 
     # ---------------------------------------------------------------- parameters
     def init_random(self, seed=20220711, std=0.02):
-        """HF-style random init (N(0,0.02) matrices/embeddings, zero biases, unit LN gains, zero pad rows);
-        linear head as torch.nn.Linear default; transitions as sequence_tagger_model.py:402-410."""
-        g = torch.Generator(device="cpu").manual_seed(seed)
+        """HF-style random init (N(0,std) matrices/embeddings, zero biases, unit LN gains, zero pad rows); linear head as
+        torch.nn.Linear's default; transitions as sequence_tagger_model.py:402-410.  Generated ON the device from a seeded
+        generator: every DP rank builds the identical replica without 560 M host-side randn per process."""
         a, cfg = self.arena, self.cfg
+        on_gpu = self.device.type == "cuda"
+        g = torch.Generator(device=self.device if on_gpu else "cpu").manual_seed(seed)
+        dev = self.device if on_gpu else "cpu"
         for name, shape in a.shapes.items():
             dst = a.param(name)
             if name.endswith("ln.g") or name.endswith("ln1.g") or name.endswith("ln2.g"):
@@ -231,21 +234,15 @@ class Tagger:
             elif name.endswith(".bias") or name.endswith("ln.b") or name.endswith("ln1.b") or name.endswith("ln2.b"):
                 dst.zero_()
             elif name == "transitions":
-                t = torch.randn(shape, generator=g)
+                t = torch.randn(shape, generator=g, device=dev)
                 t[self.start, :] = -1e12
                 t[:, self.stop] = -1e12
                 dst.copy_(t)
             elif name == "linear.weight":
                 bound = 1.0 / math.sqrt(shape[1])
-                dst.copy_((torch.rand(shape, generator=g) * 2 - 1) * bound)
+                dst.copy_((torch.rand(shape, generator=g, device=dev) * 2 - 1) * bound)
             else:
-                # generate in chunks to bound host memory for the 250k x 1024 table
-                rows = shape[0]
-                step = max(1, (1 << 24) // max(1, shape[1] if len(shape) > 1 else 1))
-                for r0 in range(0, rows, step):
-                    r1 = min(rows, r0 + step)
-                    blk = torch.empty((r1 - r0,) + tuple(shape[1:])).normal_(0.0, std, generator=g)
-                    dst[r0:r1].copy_(blk)
+                dst.normal_(0.0, std, generator=g) if on_gpu else dst.copy_(torch.empty(shape).normal_(0.0, std, generator=g))
         a.param("emb.word")[cfg.pad_token_id].zero_()
         a.param("emb.pos")[cfg.pad_token_id].zero_()
         a.refresh_shadow()
