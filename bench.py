@@ -93,6 +93,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sentences", type=int, default=8)
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dropout", type=float, default=0.0,
+                    help="train with this dropout probability at the encoder's three HF sites + WordDropout (default 0: "
+                         "BASELINE.md's workload is 'dropout off', and so is the cpu_baseline leg)")
     args = ap.parse_args()
 
     import torch
@@ -122,9 +125,13 @@ def main():
     cfg_kw = dict(vocab_size=250002, max_position_embeddings=514)
     if args.model == "base":
         cfg_kw.update(hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072)
-    cfg = engine.EncoderConfig(**cfg_kw)
+    cfg = engine.EncoderConfig(hidden_dropout_prob=args.dropout, attention_probs_dropout_prob=args.dropout, **cfg_kw)
     tg = engine.Tagger(cfg, T, start, stop, device=dev)
     tg.init_random(seed=kb.SEED)  # identical replicas on every rank
+    if args.dropout > 0.0:
+        tg.train(True)
+        tg.word_dropout = args.dropout
+        tg.seed_dropout(kb.SEED + 7919 * rank)
     B, S, accum = args.micro_batch, args.seq_len, args.accum
     # each rank gets its own shard of synthetic sentences (weak scaling: per-GPU work fixed)
     micro = [kb.to_device(kb.synthetic_batch(B, S, vocab=cfg.vocab_size, T=T, x_idx=x_idx, start=start, stop=stop,
@@ -197,8 +204,10 @@ def main():
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "configs[1]: xlm-roberta-%s (random-init, L%d/H%d/A%d/F%d, V=250002) + linear head + CRF (T=29), "
                                    "seq_len=%d, bf16 MFMA GEMMs/attention, fp32 master weights + AdamW(HF) + clip 5.0, "
-                                   "dropout 0 (BASELINE.md workload spec)" % (args.model, cfg.num_hidden_layers, cfg.hidden_size,
-                                                                              cfg.num_attention_heads, cfg.intermediate_size, S),
+                                   "dropout %s" % (args.model, cfg.num_hidden_layers, cfg.hidden_size, cfg.num_attention_heads,
+                                                   cfg.intermediate_size, S,
+                                                   ("%.2f (embeddings, attention probabilities, sub-layer outputs, WordDropout)"
+                                                    % args.dropout) if args.dropout > 0 else "off (BASELINE.md workload spec)"),
                        "micro_batch": B, "accumulate": accum, "global_batch": world * B * accum, "seq_len": S,
                        "parallelism": "dp%d" % world},
             "encoder_tflops_fwd_bwd_per_sentence": round(fl_sent / 1e12, 4),

@@ -65,15 +65,26 @@ int kbner_ln_fwd(const kbner_bf16* h, const float* gamma, const float* beta, flo
                  float* rstd, int M, int H, void* stream);
 /* ws: kbner_ln_bwd_ws_floats(H) floats of scratch for the per-block partial column sums (dgamma, dbeta, dbias are +=) */
 int kbner_ln_bwd_ws_floats(int H);
+/* drop_thresh != 0 (training with hidden dropout): the branch that fed this LayerNorm's input was dropout(GEMM out);
+ * additionally write dhm = mask(drop_seed) * dh / (1-p), the dY of that GEMM; dbias then sums dhm. */
 int kbner_ln_bwd(const kbner_bf16* dy, const kbner_bf16* h, const float* mean, const float* rstd, const float* gamma,
-                 kbner_bf16* dh, float* dgamma, float* dbeta, float* dbias, float* ws, int M, int H, void* stream);
-/* word[ids] + pos[pos_ids] + type[0] -> h0 (saved) -> LayerNorm -> y */
+                 kbner_bf16* dh, float* dgamma, float* dbeta, float* dbias, float* ws, int M, int H, kbner_bf16* dhm,
+                 uint32_t drop_seed, uint32_t drop_thresh, void* stream);
+/* word[ids] + pos[pos_ids] + type[0] -> h0 (saved) -> LayerNorm -> dropout -> y (BertEmbeddings.forward) */
 int kbner_embed_ln_fwd(const int* ids, const int* pos_ids, const float* word, const float* pos, const float* type0,
                        const float* gamma, const float* beta, float eps, kbner_bf16* h0, kbner_bf16* y, float* mean,
-                       float* rstd, int M, int H, void* stream);
+                       float* rstd, int M, int H, uint32_t drop_seed, uint32_t drop_thresh, void* stream);
 int kbner_embed_ln_bwd(const kbner_bf16* dy, const kbner_bf16* h0, const float* mean, const float* rstd, const float* gamma,
                        const int* ids, const int* pos_ids, float* dgamma, float* dbeta, float* dword, float* dpos,
-                       float* dtype0, float* ws, int M, int H, void* stream);
+                       float* dtype0, float* ws, int M, int H, uint32_t drop_seed, uint32_t drop_thresh, void* stream);
+
+/* ---------------- dropout (torch.nn.Dropout inside transformers' BertEmbeddings / BertSelfAttention / BertSelfOutput /
+ * BertOutput, active while ModelFinetuner trains: finetune_trainer.py:938 model.train()) ----------------
+ * Counter-based and replayable: element (i,j) of a site is kept iff
+ *   ((mix(seed + i) ^ mix((seed*0x9E3779B1 + 0x7F4A7C15) ^ j)) * 0x9E3779B1) >= drop_thresh,  drop_thresh = p * 2^32,
+ * kept values are scaled by 1/(1-p).  No mask is stored: backward passes the same (seed, thresh).  drop_thresh = 0 disables.
+ * kbner_dropout_mask materialises the multiplier (tests): out f32[Z,M,N], element (z,i,j) -> keys (z*M+i, z*N+j). */
+int kbner_dropout_mask(float* out, int Z, int M, int N, uint32_t seed, uint32_t thresh, void* stream);
 
 /* ---------------- bf16 MFMA GEMM (torch.nn.Linear fwd/bwd inside transformers' BertLayer) ---------------- */
 #define KBNER_GEMM_NT 0 /* C[M,N] = A[M,K] . B[N,K]^T        forward  */
@@ -84,10 +95,11 @@ int kbner_embed_ln_bwd(const kbner_bf16* dy, const kbner_bf16* h0, const float* 
 #define KBNER_EPI_ADD 4
 #define KBNER_EPI_DGELU 8
 #define KBNER_EPI_ATOMIC32 16
+#define KBNER_EPI_DROP 128 /* C = dropout(alpha*acc + bias) + addend : hidden dropout of BertSelfOutput / BertOutput */
 int kbner_gemm_bf16(int layout, const kbner_bf16* A, int lda, const kbner_bf16* B, int ldb, int M, int N, int K,
                     kbner_bf16* C, int ldc, float* C32, int ldc32, const float* bias, const kbner_bf16* addend, int ldadd,
                     const kbner_bf16* aux, int ldaux, kbner_bf16* out2, int ldout2, int epi, int splitk, float alpha,
-                    void* stream);
+                    uint32_t drop_seed, uint32_t drop_thresh, void* stream);
 
 /* Grouped GEMM on the 256x256x64 / 8-wave kernel: up to 16 problems of one layout per launch (the weight-
  * gradient GEMMs of four encoder layers = 768 tiles fill the chip without split-K).  Per problem M,N % 256 == 0, K % 64 == 0. */
@@ -107,14 +119,17 @@ typedef struct kbner_gemm_problem {
   int lda, ldb, ldc, ldc32, ldadd, ldaux, ldout2;
   int epi;
   float alpha;
+  uint32_t drop_seed, drop_thresh; /* KBNER_EPI_DROP */
 } kbner_gemm_problem;
 int kbner_gemm_bf16_grouped(int layout, int nprob, const kbner_gemm_problem* probs, void* stream);
 
 /* ---------------- fused self-attention (transformers BertSelfAttention), head_dim 64, S<=512 ---------------- */
+/* drop_*: attention-probability dropout, element (i,j) = (bh*S + query, bh*S + key) with bh = b*A + head */
 int kbner_attn_fwd(const kbner_bf16* qkv, const float* maskbias, kbner_bf16* ctx, float* lse, int B, int S, int H, int A,
-                   void* stream);
+                   uint32_t drop_seed, uint32_t drop_thresh, void* stream);
 int kbner_attn_bwd(const kbner_bf16* qkv, const kbner_bf16* ctx, const kbner_bf16* dctx, const float* maskbias,
-                   const float* lse, float* Dws, kbner_bf16* dqkv, int B, int S, int H, int A, void* stream);
+                   const float* lse, float* Dws, kbner_bf16* dqkv, int B, int S, int H, int A, uint32_t drop_seed,
+                   uint32_t drop_thresh, void* stream);
 
 /* ---------------- optimiser (transformers==3.0.0 AdamW + clip_grad_norm_, finetune_trainer.py:1010,1018) ------------- */
 int kbner_sqnorm_ws_floats(void);

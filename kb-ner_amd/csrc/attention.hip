@@ -156,22 +156,31 @@ static __device__ __forceinline__ bf16x8 tr_at(const unsigned char* base, int of
 // (no per-fragment branches), so hipcc interleaves the K-panel ds_reads, the 2*NKB QK^T MFMAs, the softmax VALU work
 // and the V transpose-reads instead of serialising them block by block.  LDS addresses are one per-lane base per
 // (k-step | d-block) plus compile-time offsets (the XOR swizzle of a row depends only on the lane, not on the tile).
-template <int NKB>
+// DROP: attention-probability dropout (BertSelfAttention.dropout).  Element (query q, key k) of head (b,h) is kept iff
+// drop_keep(rowkey(bh*S + q), colkey(bh*S + k)) (common.h); the normaliser `sum` / the stored lse are those of the
+// UNdropped softmax, the kept probabilities are scaled by 1/(1-p) through `inv`.
+template <int NKB, bool DROP>
 __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ maskbias,
                                                           bf16_t* __restrict__ ctx, float* __restrict__ lse, int H, int A,
-                                                          float scale, int rpw) {
+                                                          float scale, int rpw, uint32_t drop_seed, uint32_t drop_thresh) {
   constexpr int S = NKB * 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sK = smem;
   unsigned char* sV = smem + AT_MAXS * 128;
   float* sMask = reinterpret_cast<float*>(smem + 2 * AT_MAXS * 128);
+  uint32_t* sCk = reinterpret_cast<uint32_t*>(sMask + AT_MAXS);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int ld = 3 * H;
   const bf16_t* base = qkv + (size_t)b * S * ld + h * AT_D;
   const float scale2 = scale * 1.4426950408889634f;
-  for (int i = tid; i < S; i += 512) sMask[i] = maskbias[(size_t)b * S + i] * 1.4426950408889634f;
+  const uint32_t bhS = (uint32_t)((b * A + h) * S);
+  const float dscale = DROP ? drop_scale(drop_thresh) : 1.0f;
+  for (int i = tid; i < S; i += 512) {
+    sMask[i] = maskbias[(size_t)b * S + i] * 1.4426950408889634f;
+    if (DROP) sCk[i] = drop_colkey(drop_seed, bhS + (uint32_t)i);
+  }
   stage_panel(base + H, ld, S, sK, wid, lane);
   stage_panel(base + 2 * H, ld, S, sV, wid, lane);
   const int g = lane >> 4, li = lane & 15;
@@ -211,6 +220,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const bf16_t* __restri
         st[f] = a;
       }
       mx = group4_max(mx);
+      const uint32_t rk = DROP ? drop_rowkey(drop_seed, bhS + (uint32_t)(q0 + li)) : 0u;
 #pragma unroll
       for (int f = 0; f < NKB; ++f) {
         f4v a = st[f];
@@ -219,6 +229,13 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const bf16_t* __restri
         a[2] = __builtin_amdgcn_exp2f(a[2] - mx);
         a[3] = __builtin_amdgcn_exp2f(a[3] - mx);
         sum += (a[0] + a[1]) + (a[2] + a[3]);
+        if (DROP) {
+          const uint4 ck = *reinterpret_cast<const uint4*>(sCk + f * 16 + g * 4);
+          a[0] = drop_keep(rk, ck.x, drop_thresh) ? a[0] : 0.0f;
+          a[1] = drop_keep(rk, ck.y, drop_thresh) ? a[1] : 0.0f;
+          a[2] = drop_keep(rk, ck.z, drop_thresh) ? a[2] : 0.0f;
+          a[3] = drop_keep(rk, ck.w, drop_thresh) ? a[3] : 0.0f;
+        }
         st[f] = a;
       }
       sum = group4_sum(sum);
@@ -229,7 +246,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const bf16_t* __restri
       v_ready = true;
     }
     if (active) {
-      const float inv = 1.0f / sum;
+      const float inv = dscale / sum;
       f4v o[4];
 #pragma unroll
       for (int db = 0; db < 4; ++db) o[db] = (f4v){0.f, 0.f, 0.f, 0.f};
@@ -290,22 +307,32 @@ __global__ __launch_bounds__(256) void attn_rowdot_kernel(const bf16_t* __restri
 // ------------------------------------------------------------------------------------------
 // backward: dQ   (owner = query rows; panels K, V)
 // ------------------------------------------------------------------------------------------
+// DROP replays the forward mask: dP_eff = mask * dP / (1-p) before the softmax backward (D = rowdot(dO, O) already
+// contains the dropped probabilities through O).
+template <bool DROP>
 __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dctx,
                                                              const float* __restrict__ maskbias, const float* __restrict__ lse,
                                                              const float* __restrict__ Dv, bf16_t* __restrict__ dqkv, int S,
-                                                             int H, int A, float scale, int rpw) {
+                                                             int H, int A, float scale, int rpw, uint32_t drop_seed,
+                                                             uint32_t drop_thresh) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sK = smem;
   unsigned char* sV = smem + AT_MAXS * 128;
   float* sMask = reinterpret_cast<float*>(smem + 2 * AT_MAXS * 128);
+  uint32_t* sCk = reinterpret_cast<uint32_t*>(sMask + AT_MAXS);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int ld = 3 * H;
   const bf16_t* base = qkv + (size_t)b * S * ld + h * AT_D;
+  const uint32_t bhS = (uint32_t)((b * A + h) * S);
+  const float dscale = DROP ? drop_scale(drop_thresh) : 1.0f;
   stage_panel(base + H, ld, S, sK, wid, lane);
   stage_panel(base + 2 * H, ld, S, sV, wid, lane);
-  for (int i = tid; i < S; i += 512) sMask[i] = maskbias[(size_t)b * S + i] * 1.4426950408889634f;
+  for (int i = tid; i < S; i += 512) {
+    sMask[i] = maskbias[(size_t)b * S + i] * 1.4426950408889634f;
+    if (DROP) sCk[i] = drop_colkey(drop_seed, bhS + (uint32_t)i);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   const int g = lane >> 4, li = lane & 15;
@@ -324,6 +351,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(const bf16_t* __res
     const size_t sidx = ((size_t)b * A + h) * S + q0 + li;
     const float l_q = lse[sidx] * 1.4426950408889634f;  // log2 domain
     const float d_q = Dv[sidx];
+    const uint32_t rk = DROP ? drop_rowkey(drop_seed, bhS + (uint32_t)(q0 + li)) : 0u;
     f4v dq[4];
 #pragma unroll
     for (int db = 0; db < 4; ++db) dq[db] = (f4v){0.f, 0.f, 0.f, 0.f};
@@ -353,12 +381,24 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(const bf16_t* __res
       const float mb0[4] = {m0.x, m0.y, m0.z, m0.w};
       const float mb1[4] = {m1.x, m1.y, m1.z, m1.w};
       f4v ds0, ds1;
+      uint32_t ck0[4] = {0u, 0u, 0u, 0u}, ck1[4] = {0u, 0u, 0u, 0u};
+      if (DROP) {
+        const uint4 c0 = *reinterpret_cast<const uint4*>(sCk + kc * 32 + g * 4);
+        const uint4 c1 = *reinterpret_cast<const uint4*>(sCk + kc * 32 + 16 + g * 4);
+        ck0[0] = c0.x; ck0[1] = c0.y; ck0[2] = c0.z; ck0[3] = c0.w;
+        ck1[0] = c1.x; ck1[1] = c1.y; ck1[2] = c1.z; ck1[3] = c1.w;
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float pr0 = __builtin_amdgcn_exp2f(s0[r] * scale2 + mb0[r] - l_q);
         const float pr1 = __builtin_amdgcn_exp2f(s1[r] * scale2 + mb1[r] - l_q);
-        ds0[r] = pr0 * (p0[r] - d_q);
-        ds1[r] = pr1 * (p1[r] - d_q);
+        float dp0 = p0[r], dp1 = p1[r];
+        if (DROP) {
+          dp0 = drop_keep(rk, ck0[r], drop_thresh) ? dp0 * dscale : 0.0f;
+          dp1 = drop_keep(rk, ck1[r], drop_thresh) ? dp1 * dscale : 0.0f;
+        }
+        ds0[r] = pr0 * (dp0 - d_q);
+        ds1[r] = pr1 * (dp1 - d_q);
       }
       const bf16x8 dsb = pack_b(ds0, ds1);
 #pragma unroll
@@ -380,15 +420,18 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(const bf16_t* __res
 // ------------------------------------------------------------------------------------------
 // backward: dK, dV   (owner = key rows; panels Q, dO)
 // ------------------------------------------------------------------------------------------
+template <bool DROP>
 __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dctx,
                                                               const float* __restrict__ maskbias, const float* __restrict__ lse,
                                                               const float* __restrict__ Dv, bf16_t* __restrict__ dqkv, int S,
-                                                              int H, int A, float scale, int rpw) {
+                                                              int H, int A, float scale, int rpw, uint32_t drop_seed,
+                                                              uint32_t drop_thresh) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sQ = smem;
   unsigned char* sO = smem + AT_MAXS * 128;
   float* sL = reinterpret_cast<float*>(smem + 2 * AT_MAXS * 128);
   float* sD = sL + AT_MAXS;
+  uint32_t* sRk = reinterpret_cast<uint32_t*>(sD + AT_MAXS);  // dropout row keys of the head's queries
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
@@ -398,9 +441,12 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
   stage_panel(base, ld, S, sQ, wid, lane);
   stage_panel(dob, H, S, sO, wid, lane);
   const size_t sbase = ((size_t)b * A + h) * S;
+  const uint32_t bhS = (uint32_t)sbase;
+  const float dscale = DROP ? drop_scale(drop_thresh) : 1.0f;
   for (int i = tid; i < S; i += 512) {
     sL[i] = lse[sbase + i] * 1.4426950408889634f;  // log2 domain
     sD[i] = Dv[sbase + i];
+    if (DROP) sRk[i] = drop_rowkey(drop_seed, bhS + (uint32_t)i);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -417,6 +463,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
     const bf16x8 vf0 = glb_frag(base + 2 * H, ld, k0, 0, lane);
     const bf16x8 vf1 = glb_frag(base + 2 * H, ld, k0, 1, lane);
     const float mb = maskbias[(size_t)b * S + k0 + li] * 1.4426950408889634f;
+    const uint32_t ck = DROP ? drop_colkey(drop_seed, bhS + (uint32_t)(k0 + li)) : 0u;
     f4v dk[4], dv[4];
 #pragma unroll
     for (int db = 0; db < 4; ++db) {
@@ -448,12 +495,29 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
       const float la[4] = {l0.x, l0.y, l0.z, l0.w}, lb[4] = {l1.x, l1.y, l1.z, l1.w};
       const float da[4] = {d0.x, d0.y, d0.z, d0.w}, dbv[4] = {d1.x, d1.y, d1.z, d1.w};
       f4v pr0, pr1, ds0, ds1;
+      uint32_t rk0[4] = {0u, 0u, 0u, 0u}, rk1[4] = {0u, 0u, 0u, 0u};
+      if (DROP) {
+        const uint4 c0 = *reinterpret_cast<const uint4*>(sRk + qc * 32 + g * 4);
+        const uint4 c1 = *reinterpret_cast<const uint4*>(sRk + qc * 32 + 16 + g * 4);
+        rk0[0] = c0.x; rk0[1] = c0.y; rk0[2] = c0.z; rk0[3] = c0.w;
+        rk1[0] = c1.x; rk1[1] = c1.y; rk1[2] = c1.z; rk1[3] = c1.w;
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        pr0[r] = __builtin_amdgcn_exp2f(s0[r] * scale2 + mb - la[r]);
-        pr1[r] = __builtin_amdgcn_exp2f(s1[r] * scale2 + mb - lb[r]);
-        ds0[r] = pr0[r] * (p0[r] - da[r]);
-        ds1[r] = pr1[r] * (p1[r] - dbv[r]);
+        const float e0 = __builtin_amdgcn_exp2f(s0[r] * scale2 + mb - la[r]);
+        const float e1 = __builtin_amdgcn_exp2f(s1[r] * scale2 + mb - lb[r]);
+        float dp0 = p0[r], dp1 = p1[r];
+        pr0[r] = e0;
+        pr1[r] = e1;
+        if (DROP) {  // dV sees mask * P / (1-p); dS = P * (mask * dP / (1-p) - D)
+          const bool k0_ = drop_keep(rk0[r], ck, drop_thresh), k1_ = drop_keep(rk1[r], ck, drop_thresh);
+          pr0[r] = k0_ ? e0 * dscale : 0.0f;
+          pr1[r] = k1_ ? e1 * dscale : 0.0f;
+          dp0 = k0_ ? dp0 * dscale : 0.0f;
+          dp1 = k1_ ? dp1 * dscale : 0.0f;
+        }
+        ds0[r] = e0 * (dp0 - da[r]);
+        ds1[r] = e1 * (dp1 - dbv[r]);
       }
       const bf16x8 pb = pack_b(pr0, pr1);
       const bf16x8 dsb = pack_b(ds0, ds1);
@@ -486,7 +550,7 @@ static int set_lds(const void* f, int bytes) {
   return e == hipSuccess ? 0 : -(int)e;
 }
 
-#define AT_LDS_BYTES (2 * AT_MAXS * 128 + 2 * AT_MAXS * 4)
+#define AT_LDS_BYTES (2 * AT_MAXS * 128 + 3 * AT_MAXS * 4)
 
 // rows per workgroup: the whole head (one DMA of each panel per head) when the grid still covers the
 // chip several times over, otherwise smaller row tiles so small batches spread over more CUs
@@ -496,18 +560,45 @@ static inline int pick_rpw(int B, int S, int A) {
   return rpw;
 }
 
-template <int NKB>
-static int launch_attn_fwd(const bf16_t* qkv, const float* maskbias, bf16_t* ctx, float* lse, int B, int H, int A, int rpw,
-                           hipStream_t stream) {
+template <int NKB, bool DROP>
+static int launch_attn_fwd2(const bf16_t* qkv, const float* maskbias, bf16_t* ctx, float* lse, int B, int H, int A, int rpw,
+                            uint32_t seed, uint32_t thresh, hipStream_t stream) {
   static bool once = false;
   if (!once) {
-    int r = set_lds(reinterpret_cast<const void*>(attn_fwd_kernel<NKB>), AT_LDS_BYTES);
+    int r = set_lds(reinterpret_cast<const void*>(attn_fwd_kernel<NKB, DROP>), AT_LDS_BYTES);
     if (r) return r;
     once = true;
   }
   const int S = NKB * 16;
-  hipLaunchKernelGGL(attn_fwd_kernel<NKB>, dim3((S + rpw - 1) / rpw, A, B), dim3(512), AT_LDS_BYTES, stream, qkv, maskbias, ctx,
-                     lse, H, A, 0.125f, rpw);
+  hipLaunchKernelGGL((attn_fwd_kernel<NKB, DROP>), dim3((S + rpw - 1) / rpw, A, B), dim3(512), AT_LDS_BYTES, stream, qkv, maskbias,
+                     ctx, lse, H, A, 0.125f, rpw, seed, thresh);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+template <int NKB>
+static int launch_attn_fwd(const bf16_t* qkv, const float* maskbias, bf16_t* ctx, float* lse, int B, int H, int A, int rpw,
+                           uint32_t seed, uint32_t thresh, hipStream_t stream) {
+  if (thresh) return launch_attn_fwd2<NKB, true>(qkv, maskbias, ctx, lse, B, H, A, rpw, seed, thresh, stream);
+  return launch_attn_fwd2<NKB, false>(qkv, maskbias, ctx, lse, B, H, A, rpw, seed, thresh, stream);
+}
+
+template <bool DROP>
+static int launch_attn_bwd(const bf16_t* qkv, const bf16_t* dctx, const float* maskbias, const float* lse, const float* Dws,
+                           bf16_t* dqkv, int B, int S, int H, int A, uint32_t seed, uint32_t thresh, hipStream_t s) {
+  static bool once = false;
+  if (!once) {
+    int r = set_lds(reinterpret_cast<const void*>(attn_bwd_dq_kernel<DROP>), AT_LDS_BYTES);
+    if (r) return r;
+    r = set_lds(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<DROP>), AT_LDS_BYTES);
+    if (r) return r;
+    once = true;
+  }
+  const int rpw = pick_rpw(B, S, A);
+  const dim3 grid((S + rpw - 1) / rpw, A, B);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel<DROP>, grid, dim3(512), AT_LDS_BYTES, s, qkv, dctx, maskbias, lse, Dws, dqkv, S, H, A,
+                     0.125f, rpw, seed, thresh);
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel<DROP>, grid, dim3(512), AT_LDS_BYTES, s, qkv, dctx, maskbias, lse, Dws, dqkv, S, H, A,
+                     0.125f, rpw, seed, thresh);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }
@@ -515,45 +606,34 @@ static int launch_attn_fwd(const bf16_t* qkv, const float* maskbias, bf16_t* ctx
 extern "C" {
 
 // qkv bf16 [B*S, 3H] ; maskbias f32 [B,S] ; ctx bf16 [B*S, H] ; lse f32 [B, A, S]
-// constraints: H = A * 64, S % 64 == 0, 64 <= S <= 512
-int kbner_attn_fwd(const bf16_t* qkv, const float* maskbias, bf16_t* ctx, float* lse, int B, int S, int H, int A, void* stream) {
+// constraints: H = A * 64, S % 64 == 0, 64 <= S <= 512.  drop_thresh = p * 2^32 (0 = no dropout), drop_seed: the site's seed.
+int kbner_attn_fwd(const bf16_t* qkv, const float* maskbias, bf16_t* ctx, float* lse, int B, int S, int H, int A,
+                   uint32_t drop_seed, uint32_t drop_thresh, void* stream) {
   KBNER_CHECK_ARG(B > 0 && A > 0 && H == A * AT_D && S % 64 == 0 && S >= 64 && S <= AT_MAXS);
   const int rpw = pick_rpw(B, S, A);
   hipStream_t st = (hipStream_t)stream;
   switch (S / 64) {
-    case 1: return launch_attn_fwd<4>(qkv, maskbias, ctx, lse, B, H, A, rpw, st);
-    case 2: return launch_attn_fwd<8>(qkv, maskbias, ctx, lse, B, H, A, rpw, st);
-    case 3: return launch_attn_fwd<12>(qkv, maskbias, ctx, lse, B, H, A, rpw, st);
-    case 4: return launch_attn_fwd<16>(qkv, maskbias, ctx, lse, B, H, A, rpw, st);
-    case 5: return launch_attn_fwd<20>(qkv, maskbias, ctx, lse, B, H, A, rpw, st);
-    case 6: return launch_attn_fwd<24>(qkv, maskbias, ctx, lse, B, H, A, rpw, st);
-    case 7: return launch_attn_fwd<28>(qkv, maskbias, ctx, lse, B, H, A, rpw, st);
-    default: return launch_attn_fwd<32>(qkv, maskbias, ctx, lse, B, H, A, rpw, st);
+    case 1: return launch_attn_fwd<4>(qkv, maskbias, ctx, lse, B, H, A, rpw, drop_seed, drop_thresh, st);
+    case 2: return launch_attn_fwd<8>(qkv, maskbias, ctx, lse, B, H, A, rpw, drop_seed, drop_thresh, st);
+    case 3: return launch_attn_fwd<12>(qkv, maskbias, ctx, lse, B, H, A, rpw, drop_seed, drop_thresh, st);
+    case 4: return launch_attn_fwd<16>(qkv, maskbias, ctx, lse, B, H, A, rpw, drop_seed, drop_thresh, st);
+    case 5: return launch_attn_fwd<20>(qkv, maskbias, ctx, lse, B, H, A, rpw, drop_seed, drop_thresh, st);
+    case 6: return launch_attn_fwd<24>(qkv, maskbias, ctx, lse, B, H, A, rpw, drop_seed, drop_thresh, st);
+    case 7: return launch_attn_fwd<28>(qkv, maskbias, ctx, lse, B, H, A, rpw, drop_seed, drop_thresh, st);
+    default: return launch_attn_fwd<32>(qkv, maskbias, ctx, lse, B, H, A, rpw, drop_seed, drop_thresh, st);
   }
 }
 
 // dctx bf16 [B*S,H] (dO) ; ctx (O) ; lse ; Dws f32 [B,A,S] workspace ; dqkv bf16 [B*S,3H] out
 int kbner_attn_bwd(const bf16_t* qkv, const bf16_t* ctx, const bf16_t* dctx, const float* maskbias, const float* lse,
-                   float* Dws, bf16_t* dqkv, int B, int S, int H, int A, void* stream) {
+                   float* Dws, bf16_t* dqkv, int B, int S, int H, int A, uint32_t drop_seed, uint32_t drop_thresh,
+                   void* stream) {
   KBNER_CHECK_ARG(B > 0 && A > 0 && H == A * AT_D && S % 64 == 0 && S >= 64 && S <= AT_MAXS);
-  static bool once = false;
-  if (!once) {
-    int r = set_lds(reinterpret_cast<const void*>(attn_bwd_dq_kernel), AT_LDS_BYTES);
-    if (r) return r;
-    r = set_lds(reinterpret_cast<const void*>(attn_bwd_dkv_kernel), AT_LDS_BYTES);
-    if (r) return r;
-    once = true;
-  }
   hipStream_t s = (hipStream_t)stream;
   const int n = B * S * A;
   hipLaunchKernelGGL(attn_rowdot_kernel, dim3((n + 255) / 256), dim3(256), 0, s, dctx, ctx, Dws, B, S, H, A);
-  const int rpw = pick_rpw(B, S, A);
-  const dim3 grid((S + rpw - 1) / rpw, A, B);
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(512), AT_LDS_BYTES, s, qkv, dctx, maskbias, lse, Dws, dqkv, S, H, A, 0.125f,
-                     rpw);
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(512), AT_LDS_BYTES, s, qkv, dctx, maskbias, lse, Dws, dqkv, S, H, A,
-                     0.125f, rpw);
-  KBNER_LAUNCH_RET();
+  if (drop_thresh) return launch_attn_bwd<true>(qkv, dctx, maskbias, lse, Dws, dqkv, B, S, H, A, drop_seed, drop_thresh, s);
+  return launch_attn_bwd<false>(qkv, dctx, maskbias, lse, Dws, dqkv, B, S, H, A, drop_seed, drop_thresh, s);
 }
 
 }  // extern "C"

@@ -48,6 +48,31 @@ static __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// Counter-based dropout shared by every kernel that applies or replays a mask (GEMM epilogue, LayerNorm
+// backward, embeddings, attention forward / dQ / dKdV): element (i, j) of a site is kept iff
+//   ((rowkey(seed, i) ^ colkey(seed, j)) * 0x9E3779B1) >= thresh        thresh = p * 2^32
+// The separable form costs one xor + one multiply + one compare per element whichever axis a lane walks (the
+// attention kernels see the same probability tile in both orientations), needs no stored mask, and is replayed
+// bit-identically in backward from (seed, thresh) alone.
+static __device__ __forceinline__ uint32_t drop_mix(uint32_t x) {
+  x ^= x >> 16;
+  x *= 0x7feb352du;
+  x ^= x >> 15;
+  x *= 0x846ca68bu;
+  x ^= x >> 16;
+  return x;
+}
+static __device__ __forceinline__ uint32_t drop_rowkey(uint32_t seed, uint32_t i) { return drop_mix(seed + i); }
+static __device__ __forceinline__ uint32_t drop_colkey(uint32_t seed, uint32_t j) {
+  return drop_mix((seed * 0x9E3779B1u + 0x7F4A7C15u) ^ j);
+}
+static __device__ __forceinline__ bool drop_keep(uint32_t rk, uint32_t ck, uint32_t thresh) {
+  return ((rk ^ ck) * 0x9E3779B1u) >= thresh;
+}
+static __host__ __device__ __forceinline__ float drop_scale(uint32_t thresh) {
+  return 4294967296.0f / (4294967296.0f - (float)thresh);
+}
+
 // GELU, erf form (HF hidden_act="gelu"), and its derivative.  erf by Abramowitz-Stegun 7.1.26
 // (|error| <= 1.5e-7, far below the bf16 rounding of the stored result) so the GEMM epilogue costs
 // one v_rcp + one v_exp + a 5-term Horner per element instead of libm erff; exp(-x^2/2) is shared

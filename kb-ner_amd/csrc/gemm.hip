@@ -25,6 +25,7 @@
 #define EPI_ADD 4      // + addend[m,n] (bf16)
 #define EPI_DGELU 8    // * gelu'(aux[m,n])
 #define EPI_ATOMIC32 16  // atomicAdd into C32 (fp32), no bf16 output
+#define EPI_DROP 128     // dropout on (acc*alpha + bias) before the residual add
 
 struct GemmArgs {
   const bf16_t* A;
@@ -45,6 +46,8 @@ struct GemmArgs {
   int splitk;
   int epi;
   float alpha;
+  uint32_t drop_seed;
+  uint32_t drop_thresh;
 };
 
 #define BM 128
@@ -189,6 +192,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
         const float4 b = *reinterpret_cast<const float4*>(g.bias + n);
         v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
       }
+      if (epi & EPI_DROP) {  // same counter-based mask as gemm256.hip (common.h)
+        const uint32_t rk = drop_rowkey(g.drop_seed, (uint32_t)m);
+        const float ds = drop_scale(g.drop_thresh);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          v[r] = drop_keep(rk, drop_colkey(g.drop_seed, (uint32_t)(n + r)), g.drop_thresh) ? v[r] * ds : 0.0f;
+      }
       if (epi & EPI_ADD) {
         const uint2 u = *reinterpret_cast<const uint2*>(g.addend + (size_t)m * g.ldadd + n);
         v[0] += __uint_as_float(u.x << 16);
@@ -245,7 +255,8 @@ extern "C" {
 // Constraints: M % 128 == 0, N % 128 == 0, K % (64 * splitk) == 0, all ld % 8 == 0.
 int kbner_gemm_bf16(int layout, const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K, bf16_t* C, int ldc,
                     float* C32, int ldc32, const float* bias, const bf16_t* addend, int ldadd, const bf16_t* aux, int ldaux,
-                    bf16_t* out2, int ldout2, int epi, int splitk, float alpha, void* stream) {
+                    bf16_t* out2, int ldout2, int epi, int splitk, float alpha, uint32_t drop_seed, uint32_t drop_thresh,
+                    void* stream) {
   KBNER_CHECK_ARG(layout >= 0 && layout <= 2);
   KBNER_CHECK_ARG(M > 0 && N > 0 && K > 0 && splitk >= 1);
   KBNER_CHECK_ARG(M % BM == 0 && N % BN == 0 && K % (BK * splitk) == 0);
@@ -265,6 +276,8 @@ int kbner_gemm_bf16(int layout, const bf16_t* A, int lda, const bf16_t* B, int l
   g.C = C; g.ldc = ldc; g.C32 = C32; g.ldc32 = ldc32; g.bias = bias;
   g.addend = addend; g.ldadd = ldadd; g.aux = aux; g.ldaux = ldaux; g.out2 = out2; g.ldout2 = ldout2;
   g.splitk = splitk; g.epi = epi; g.alpha = alpha;
+  g.drop_seed = drop_seed; g.drop_thresh = (epi & EPI_DROP) ? drop_thresh : 0u;
+  if (epi & EPI_DROP) KBNER_CHECK_ARG(!(epi & (EPI_ATOMIC32 | EPI_GELU | EPI_DGELU)));
   hipStream_t s = (hipStream_t)stream;
   switch (layout) {
     case 0: return launch_gemm<false, false>(g, s);

@@ -18,6 +18,7 @@
 #define EPI_ATOMIC32 16
 #define EPI_RMW32 32  // C32[m,n] += result, non-atomic 16-byte RMW (each output element owned by one lane)
 #define EPI_COLSUM 64  // colsum[n] += sum_m out[m,n] (bias gradient of the producing layer), fp32 atomics, 2 per column per tile
+#define EPI_DROP 128   // dropout on (acc*alpha + bias) BEFORE the residual add (BertSelfOutput / BertOutput); not with COLSUM
 
 #define G2_MAXP 16
 
@@ -36,6 +37,8 @@ struct GemmProblem {
   int epi;
   float alpha;
   int tile_begin;
+  uint32_t drop_seed;
+  uint32_t drop_thresh;
   int pad_;
 };
 
@@ -297,6 +300,16 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GroupArgs ga) {
       csum[q][r] = 0.0f;
       bq[q][r] = 0.0f;
     }
+  const bool drop = (epi & EPI_DROP) != 0;
+  const float dscale = drop_scale(g.drop_thresh);
+  if (drop) {
+    // the 16 column keys of this lane live in csum's registers (EPI_DROP excludes EPI_COLSUM): no extra VGPRs
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+        csum[q][r] = __uint_as_float(drop_colkey(g.drop_seed, (uint32_t)(n0 + wn * 64 + q * 32 + gq * 8 + r)));
+  }
   if (epi & EPI_BIAS) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -310,6 +323,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GroupArgs ga) {
 #pragma unroll
   for (int mi = 0; mi < 8; ++mi) {
     const int m = m0 + wm * 128 + mi * 16 + (lane & 15);
+    const uint32_t rk = drop ? drop_rowkey(g.drop_seed, (uint32_t)m) : 0u;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int n = n0 + wn * 64 + q * 32 + gq * 8;  // 8 contiguous columns owned by this lane
@@ -337,6 +351,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GroupArgs ga) {
       if (epi & EPI_BIAS) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] += bq[q][r];
+      }
+      if (drop) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = drop_keep(rk, __float_as_uint(csum[q][r]), g.drop_thresh) ? v[r] * dscale : 0.0f;
       }
       if (epi & EPI_ADD) {
         const uint4 u = *reinterpret_cast<const uint4*>(g.addend + (size_t)m * g.ldadd + n);
@@ -378,8 +396,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GroupArgs ga) {
       o.z = pack2bf(v[4], v[5]);
       o.w = pack2bf(v[6], v[7]);
       *reinterpret_cast<uint4*>(g.C + (size_t)m * g.ldc + n) = o;
+      if (!drop) {
 #pragma unroll
-      for (int r = 0; r < 8; ++r) csum[q][r] += v[r];
+        for (int r = 0; r < 8; ++r) csum[q][r] += v[r];
+      }
     }
   }
   if (epi & EPI_COLSUM) {
@@ -443,6 +463,8 @@ struct kbner_gemm_problem {
   int lda, ldb, ldc, ldc32, ldadd, ldaux, ldout2;
   int epi;
   float alpha;
+  uint32_t drop_seed;
+  uint32_t drop_thresh;
 };
 
 extern "C" {
@@ -468,10 +490,12 @@ int kbner_gemm_bf16_grouped(int layout, int nprob, const kbner_gemm_problem* pro
     if (s.epi & EPI_DGELU) KBNER_CHECK_ARG(s.aux != nullptr && s.ldaux % 8 == 0);
     if (s.epi & EPI_GELU) KBNER_CHECK_ARG(s.out2 != nullptr && s.ldout2 % 8 == 0);
     if (s.epi & EPI_COLSUM) KBNER_CHECK_ARG(s.colsum != nullptr && !(s.epi & (EPI_ATOMIC32 | EPI_RMW32)));
+    if (s.epi & EPI_DROP) KBNER_CHECK_ARG(!(s.epi & (EPI_ATOMIC32 | EPI_RMW32 | EPI_COLSUM | EPI_GELU | EPI_DGELU)));
     GemmProblem& d = ga.p[i];
     d.A = s.A; d.B = s.B; d.C = s.C; d.C32 = s.C32; d.bias = s.bias; d.addend = s.addend; d.aux = s.aux; d.out2 = s.out2; d.colsum = s.colsum;
     d.M = s.M; d.N = s.N; d.K = s.K; d.lda = s.lda; d.ldb = s.ldb; d.ldc = s.ldc; d.ldc32 = s.ldc32; d.ldadd = s.ldadd;
     d.ldaux = s.ldaux; d.ldout2 = s.ldout2; d.epi = s.epi; d.alpha = s.alpha; d.tile_begin = tiles; d.pad_ = 0;
+    d.drop_seed = s.drop_seed; d.drop_thresh = (s.epi & EPI_DROP) ? s.drop_thresh : 0u;
     ga.tile_begin[i] = tiles;
     tiles += (s.M / T2) * (s.N / T2);
   }

@@ -71,6 +71,24 @@ static __device__ __forceinline__ void load_row_f32(const float* __restrict__ p,
   }
 }
 
+// dropout column keys of this lane's columns (common.h: drop_colkey), kept as raw bits in a RowF
+template <int NCH>
+static __device__ __forceinline__ void load_colkeys(uint32_t seed, int lane, RowF<NCH>& k) {
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) k.v[c][j] = __uint_as_float(drop_colkey(seed, (uint32_t)((lane + 64 * c) * 8 + j)));
+}
+template <int NCH>
+static __device__ __forceinline__ void drop_row(RowF<NCH>& x, const RowF<NCH>& ck, uint32_t seed, uint32_t thresh, float scale,
+                                                int row) {
+  const uint32_t rk = drop_rowkey(seed, (uint32_t)row);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x.v[c][j] = drop_keep(rk, __float_as_uint(ck.v[c][j]), thresh) ? x.v[c][j] * scale : 0.0f;
+}
+
 // round a row through bf16 (what is stored is what is normalised: fwd/bwd stay consistent)
 template <int NCH>
 static __device__ __forceinline__ void round_row(RowF<NCH>& r) {
@@ -137,11 +155,14 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int* __restrict
                                                            const float* __restrict__ type0, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float eps, bf16_t* __restrict__ h0,
                                                            bf16_t* __restrict__ y, float* __restrict__ mean_o,
-                                                           float* __restrict__ rstd_o, int M, int H) {
+                                                           float* __restrict__ rstd_o, int M, int H, uint32_t drop_seed,
+                                                           uint32_t drop_thresh) {
   const int lane = threadIdx.x % 64;
   const int wave = blockIdx.x * 4 + threadIdx.x / 64;
   const int nwave = gridDim.x * 4;
-  RowF<NCH> g, b, ty;
+  RowF<NCH> g, b, ty, ck;
+  if (drop_thresh) load_colkeys<NCH>(drop_seed, lane, ck);
+  const float dscale = drop_scale(drop_thresh);
   load_row_f32<NCH>(gamma, H, lane, g);
   load_row_f32<NCH>(beta, H, lane, b);
   load_row_f32<NCH>(type0, H, lane, ty);
@@ -161,6 +182,7 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int* __restrict
     for (int c = 0; c < NCH; ++c)
 #pragma unroll
       for (int j = 0; j < 8; ++j) x.v[c][j] = (x.v[c][j] - mean) * rstd * g.v[c][j] + b.v[c][j];
+    if (drop_thresh) drop_row<NCH>(x, ck, drop_seed, drop_thresh, dscale, r);  // BertEmbeddings.dropout
     store_row_bf16<NCH>(y + (size_t)r * H, H, lane, x);
     if (lane == 0) {
       mean_o[r] = mean;
@@ -178,14 +200,20 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                      float* __restrict__ dbias, const int* __restrict__ ids,
                                                      const int* __restrict__ pos_ids, float* __restrict__ dword,
-                                                     float* __restrict__ dpos, float* __restrict__ ws, int M, int H) {
+                                                     float* __restrict__ dpos, float* __restrict__ ws, int M, int H,
+                                                     bf16_t* __restrict__ dhm, uint32_t drop_seed, uint32_t drop_thresh) {
+  // Dropout replay (drop_thresh != 0): EMBED -> the incoming dy is masked first (y = drop(LN(h0)));
+  // otherwise -> the GEMM whose (dropped) output fed this LayerNorm's input gets dhm = mask * dh as its dY, the
+  // residual branch keeps the unmasked dh, and the GEMM's bias gradient (dbias) sums the masked rows.
   __shared__ float red[3][4][64 * 8 * NCH];
   const int lane = threadIdx.x % 64;
   const int wid = threadIdx.x / 64;
   const int wave = blockIdx.x * 4 + wid;
   const int nwave = gridDim.x * 4;
-  RowF<NCH> g, ag, ab, ah;
+  RowF<NCH> g, ag, ab, ah, ck;
   load_row_f32<NCH>(gamma, H, lane, g);
+  if (drop_thresh) load_colkeys<NCH>(drop_seed, lane, ck);
+  const float dscale = drop_scale(drop_thresh);
 #pragma unroll
   for (int c = 0; c < NCH; ++c)
 #pragma unroll
@@ -195,6 +223,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
     RowF<NCH> x, d;
     load_row_bf16<NCH>(h + (size_t)r * H, H, lane, x);
     load_row_bf16<NCH>(dy + (size_t)r * H, H, lane, d);
+    if (EMBED && drop_thresh) drop_row<NCH>(d, ck, drop_seed, drop_thresh, dscale, r);
     const float mean = mean_i[r], rstd = rstd_i[r];
     float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
@@ -217,11 +246,17 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
     for (int c = 0; c < NCH; ++c)
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const float v = rstd * (d.v[c][j] * g.v[c][j] - s1 - x.v[c][j] * s2);
-        d.v[c][j] = v;
-        ah.v[c][j] += v;
+        d.v[c][j] = rstd * (d.v[c][j] * g.v[c][j] - s1 - x.v[c][j] * s2);
       }
     if (dh) store_row_bf16<NCH>(dh + (size_t)r * H, H, lane, d);
+    if (!EMBED && drop_thresh) {
+      drop_row<NCH>(d, ck, drop_seed, drop_thresh, dscale, r);
+      store_row_bf16<NCH>(dhm + (size_t)r * H, H, lane, d);
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ah.v[c][j] += d.v[c][j];
     if (EMBED) {
       float* dw = dword + (size_t)ids[r] * H;
       float* dp = dpos + (size_t)pos_ids[r] * H;
@@ -309,32 +344,35 @@ int kbner_ln_fwd(const bf16_t* h, const float* gamma, const float* beta, float e
 
 int kbner_embed_ln_fwd(const int* ids, const int* pos_ids, const float* word, const float* pos, const float* type0,
                        const float* gamma, const float* beta, float eps, bf16_t* h0, bf16_t* y, float* mean, float* rstd,
-                       int M, int H, void* stream) {
+                       int M, int H, uint32_t drop_seed, uint32_t drop_thresh, void* stream) {
   KBNER_CHECK_ARG(M >= 0 && H > 0 && H % 8 == 0 && H <= 64 * 8 * LN_MAXCH);
   if (M == 0) return 0;
   if (H <= 512)
     hipLaunchKernelGGL(embed_ln_fwd_kernel<1>, dim3(ln_grid(M)), dim3(256), 0, (hipStream_t)stream, ids, pos_ids, word, pos,
-                       type0, gamma, beta, eps, h0, y, mean, rstd, M, H);
+                       type0, gamma, beta, eps, h0, y, mean, rstd, M, H, drop_seed, drop_thresh);
   else
     hipLaunchKernelGGL(embed_ln_fwd_kernel<2>, dim3(ln_grid(M)), dim3(256), 0, (hipStream_t)stream, ids, pos_ids, word, pos,
-                       type0, gamma, beta, eps, h0, y, mean, rstd, M, H);
+                       type0, gamma, beta, eps, h0, y, mean, rstd, M, H, drop_seed, drop_thresh);
   KBNER_LAUNCH_RET();
 }
 
 // dh may be NULL (embedding LayerNorm: nothing upstream).  dbias may be NULL.
 // ws: kbner_ln_bwd_ws_floats(H) floats of scratch (per-block partial column sums)
+// drop_thresh != 0: also write dhm = dropout-mask(drop_seed) * dh (the dY of the GEMM that produced the dropped branch)
 int kbner_ln_bwd(const bf16_t* dy, const bf16_t* h, const float* mean, const float* rstd, const float* gamma, bf16_t* dh,
-                 float* dgamma, float* dbeta, float* dbias, float* ws, int M, int H, void* stream) {
+                 float* dgamma, float* dbeta, float* dbias, float* ws, int M, int H, bf16_t* dhm, uint32_t drop_seed,
+                 uint32_t drop_thresh, void* stream) {
   KBNER_CHECK_ARG(M >= 0 && H > 0 && H % 8 == 0 && H <= 64 * 8 * LN_MAXCH && ws != nullptr);
+  KBNER_CHECK_ARG(drop_thresh == 0 || dhm != nullptr);
   if (M == 0) return 0;
   int grid = ln_grid(M);
   if (grid > LN_BWD_MAXBLOCKS) grid = LN_BWD_MAXBLOCKS;
   if (H <= 512)
     hipLaunchKernelGGL((ln_bwd_kernel<1, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, h, mean, rstd, gamma, dh,
-                       dgamma, dbeta, dbias, nullptr, nullptr, nullptr, nullptr, ws, M, H);
+                       dgamma, dbeta, dbias, nullptr, nullptr, nullptr, nullptr, ws, M, H, dhm, drop_seed, drop_thresh);
   else
     hipLaunchKernelGGL((ln_bwd_kernel<2, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, h, mean, rstd, gamma, dh,
-                       dgamma, dbeta, dbias, nullptr, nullptr, nullptr, nullptr, ws, M, H);
+                       dgamma, dbeta, dbias, nullptr, nullptr, nullptr, nullptr, ws, M, H, dhm, drop_seed, drop_thresh);
   hipLaunchKernelGGL(ln_colreduce_kernel, dim3((3 * H + 63) / 64, 8), dim3(256), 0, (hipStream_t)stream, ws, grid, H, dgamma, dbeta,
                      dbias);
   KBNER_LAUNCH_RET();
@@ -342,17 +380,19 @@ int kbner_ln_bwd(const bf16_t* dy, const bf16_t* h, const float* mean, const flo
 
 int kbner_embed_ln_bwd(const bf16_t* dy, const bf16_t* h0, const float* mean, const float* rstd, const float* gamma,
                        const int* ids, const int* pos_ids, float* dgamma, float* dbeta, float* dword, float* dpos,
-                       float* dtype0, float* ws, int M, int H, void* stream) {
+                       float* dtype0, float* ws, int M, int H, uint32_t drop_seed, uint32_t drop_thresh, void* stream) {
   KBNER_CHECK_ARG(M >= 0 && H > 0 && H % 8 == 0 && H <= 64 * 8 * LN_MAXCH && ws != nullptr);
   if (M == 0) return 0;
   int grid = ln_grid(M);
   if (grid > LN_BWD_MAXBLOCKS) grid = LN_BWD_MAXBLOCKS;
   if (H <= 512)
     hipLaunchKernelGGL((ln_bwd_kernel<1, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, h0, mean, rstd, gamma,
-                       (bf16_t*)nullptr, dgamma, dbeta, dtype0, ids, pos_ids, dword, dpos, ws, M, H);
+                       (bf16_t*)nullptr, dgamma, dbeta, dtype0, ids, pos_ids, dword, dpos, ws, M, H, (bf16_t*)nullptr, drop_seed,
+                       drop_thresh);
   else
     hipLaunchKernelGGL((ln_bwd_kernel<2, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, h0, mean, rstd, gamma,
-                       (bf16_t*)nullptr, dgamma, dbeta, dtype0, ids, pos_ids, dword, dpos, ws, M, H);
+                       (bf16_t*)nullptr, dgamma, dbeta, dtype0, ids, pos_ids, dword, dpos, ws, M, H, (bf16_t*)nullptr, drop_seed,
+                       drop_thresh);
   hipLaunchKernelGGL(ln_colreduce_kernel, dim3((3 * H + 63) / 64, 8), dim3(256), 0, (hipStream_t)stream, ws, grid, H, dgamma, dbeta,
                      dtype0);
   KBNER_LAUNCH_RET();

@@ -40,7 +40,7 @@ int kbner_probe_mfma(const bf16_t* a, const bf16_t* b, float* c, void* stream) {
   KBNER_LAUNCH_RET();
 }
 
-int kbner_abi_version(void) { return 1; }
+int kbner_abi_version(void) { return 2; }
 
 // returns the number of visible HIP devices, or -(hipError)
 int kbner_device_count(void) {

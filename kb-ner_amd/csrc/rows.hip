@@ -263,3 +263,25 @@ extern "C" int kbner_gather_rows_f32(const float* src, const int* idx, float* ou
   hipLaunchKernelGGL(gather_rows_f32_kernel, dim3((R * W + 255) / 256), dim3(256), 0, (hipStream_t)stream, src, idx, out, R, W);
   KBNER_LAUNCH_RET();
 }
+
+// Materialise a dropout site's multiplier (tests / debugging only: the product kernels regenerate it in registers):
+// out[z,i,j] = drop_keep(rowkey(seed, z*M+i), colkey(seed, z*N+j)) ? 1/(1-p) : 0.  Hidden-state sites: Z=1, [M tokens, H];
+// attention-probability sites: Z = B*A heads, M = N = S.
+__global__ __launch_bounds__(256) void dropout_mask_kernel(float* __restrict__ out, int Z, int M, int N, uint32_t seed,
+                                                           uint32_t thresh) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)Z * M * N) return;
+  const int j = (int)(i % N);
+  const int r = (int)((i / N) % M);
+  const int z = (int)(i / ((size_t)M * N));
+  const bool keep = drop_keep(drop_rowkey(seed, (uint32_t)(z * M + r)), drop_colkey(seed, (uint32_t)(z * N + j)), thresh);
+  out[i] = keep ? drop_scale(thresh) : 0.0f;
+}
+
+extern "C" int kbner_dropout_mask(float* out, int Z, int M, int N, uint32_t seed, uint32_t thresh, void* stream) {
+  KBNER_CHECK_ARG(out != nullptr && Z > 0 && M > 0 && N > 0);
+  const size_t n = (size_t)Z * M * N;
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, Z, M, N, seed,
+                     thresh);
+  KBNER_LAUNCH_RET();
+}

@@ -11,6 +11,8 @@ import logging
 from pathlib import Path
 from typing import List
 
+import os
+
 import numpy as np
 import torch
 
@@ -53,7 +55,7 @@ class SequenceTagger(flair.nn.Model):
         self.use_cnn = False
         self.sentence_level_loss = sentence_loss
         self.remove_x = remove_x
-        self.use_word_dropout = word_dropout  # accepted; see DESIGN.md (dropout is a listed gap of this round)
+        self.use_word_dropout = word_dropout  # flair.nn.WordDropout on the token features while training (engine.word_dropout)
         self.use_dropout, self.use_locked_dropout = 0.0, 0.0
         self.config = config
         self.target_languages = target_languages
@@ -87,8 +89,13 @@ class SequenceTagger(flair.nn.Model):
                               num_attention_heads=hc.num_attention_heads, intermediate_size=hc.intermediate_size,
                               max_position_embeddings=hc.max_position_embeddings, type_vocab_size=getattr(hc, "type_vocab_size", 1),
                               pad_token_id=getattr(hc, "pad_token_id", 1) if getattr(hc, "pad_token_id", 1) is not None else 1,
-                              layer_norm_eps=getattr(hc, "layer_norm_eps", 1e-5))
+                              layer_norm_eps=getattr(hc, "layer_norm_eps", 1e-5),
+                              hidden_dropout_prob=float(getattr(hc, "hidden_dropout_prob", 0.1)),
+                              attention_probs_dropout_prob=float(getattr(hc, "attention_probs_dropout_prob", 0.1)))
         self.engine = E.Tagger(cfg, self.tagset_size, self.start_idx, self.stop_idx, device=flair.device)
+        # dropout streams differ per data-parallel rank (each rank sees different sentences anyway)
+        self.engine.seed_dropout(int(torch.initial_seed() % (2 ** 31)) + 7919 * int(os.environ.get("RANK", "0")))
+        self.engine.word_dropout = float(self.use_word_dropout or 0.0)
         self.engine.load_hf_state_dict(self._emb.model.state_dict())
         g = torch.Generator().manual_seed(int(torch.initial_seed() % (2 ** 31)))
         H = cfg.hidden_size
@@ -101,6 +108,13 @@ class SequenceTagger(flair.nn.Model):
         self.engine.set_param("transitions", tr)
         self._emb.model.source = self.engine
         self._emb.model._state_dict = None  # the arena is the single owner of the weights now
+
+    def train(self, mode: bool = True):
+        """model.train() (finetune_trainer.py:938) switches the HF dropout sites and the tagger's WordDropout on; eval() off"""
+        super().train(mode)
+        if getattr(self, "engine", None) is not None:
+            self.engine.train(bool(mode) and bool(getattr(self._emb, "fine_tune", True)))
+        return self
 
     @property
     def transitions(self):

@@ -49,20 +49,23 @@ def assemble(input_ids, attention_mask, first_idx, tags, lengths, x_idx, pad_id=
     nc = max(1, int(clens.max()) if B else 1)
     crow = np.full((B, nc), -1, np.int32)
     ctags = np.zeros((B, nc), np.int32)
+    cpos = np.full((B, nc), -1, np.int32)       # word-token position of each compacted row (WordDropout drops positions)
     for b in range(B):
         k = np.nonzero(keep[b])[0]
         crow[b, :len(k)] = row_idx[b, k]
         ctags[b, :len(k)] = tags[b, k]
+        cpos[b, :len(k)] = k
     return dict(B=B, S=S, ids=ids_f, pos_ids=pos_f, maskbias=maskbias, row_idx=row_idx.reshape(-1), lengths=lengths.astype(np.int32),
                 tags=tags.astype(np.int32), keep=keep, crow_idx=crow.reshape(-1), ctags=ctags, clens=clens,
+                cpos=cpos.reshape(-1), n_tokens=n,
                 input_ids=ids, attention_mask=am, first_idx=first_idx)
 
 
-_DEVICE_KEYS = ("ids", "pos_ids", "maskbias", "row_idx", "lengths", "tags", "crow_idx", "ctags", "clens")
+_DEVICE_KEYS = ("ids", "pos_ids", "maskbias", "row_idx", "lengths", "tags", "crow_idx", "ctags", "clens", "cpos")
 
 
 def to_device(batch, device="cuda"):
-    out = {"B": batch["B"], "S": batch["S"]}
+    out = {"B": batch["B"], "S": batch["S"], "n_tokens": batch["n_tokens"]}
     for k in _DEVICE_KEYS:
         out[k] = torch.from_numpy(np.ascontiguousarray(batch[k])).to(device)
     return out

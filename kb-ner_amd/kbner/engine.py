@@ -25,7 +25,7 @@ class EncoderConfig:
 
     def __init__(self, vocab_size=250002, hidden_size=1024, num_hidden_layers=24, num_attention_heads=16,
                  intermediate_size=4096, max_position_embeddings=514, type_vocab_size=1, pad_token_id=1,
-                 layer_norm_eps=1e-5):
+                 layer_norm_eps=1e-5, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1):
         self.vocab_size = vocab_size
         self.hidden_size = hidden_size
         self.num_hidden_layers = num_hidden_layers
@@ -35,6 +35,8 @@ class EncoderConfig:
         self.type_vocab_size = type_vocab_size
         self.pad_token_id = pad_token_id
         self.layer_norm_eps = layer_norm_eps
+        self.hidden_dropout_prob = hidden_dropout_prob  # active only while Tagger.training (model.train())
+        self.attention_probs_dropout_prob = attention_probs_dropout_prob
         if hidden_size != num_attention_heads * 64:
             raise ValueError("kbner attention kernels need head_dim 64 (XLM-R base/large)")
         if hidden_size % 128 or intermediate_size % 128:
@@ -192,6 +194,15 @@ class _Acts:
         self.dpre = [z(Mp, F_) for _ in range(WGRAD_GROUP)]
         self.dqkv = [z(Mp, 3 * H) for _ in range(WGRAD_GROUP)]
         self.dws = z(B, A, S, dt=F32)
+        self._z, self._H = z, H
+        self.dhm = self.dh1m = None
+
+    def drop_buffers(self):
+        """masked copies of dh / dh1 (the dY of the two GEMMs whose outputs were dropped); allocated on first training use"""
+        if self.dhm is None:
+            self.dhm = [self._z(self.Mp, self._H) for _ in range(WGRAD_GROUP)]
+            self.dh1m = [self._z(self.Mp, self._H) for _ in range(WGRAD_GROUP)]
+        return self.dhm, self.dh1m
 
 
 WGRAD_GROUP = 4
@@ -217,6 +228,35 @@ class Tagger:
         self.arena = Arena(tagger_specs(cfg, num_tags), self.device)
         self._acts = {}
         self._saved = None
+        # Dropout (active only while `training`): the encoder's three HF sites (embeddings, attention probabilities,
+        # the two sub-layer outputs) from cfg, plus the tagger's WordDropout (flair/nn.py:166-183: whole token POSITIONS
+        # zeroed across the batch, no rescale).  Masks are counter-based (include/kbner.h): only seeds are stored.
+        self.training = False
+        self.word_dropout = 0.0
+        self.seed_dropout(20220711)
+
+    def seed_dropout(self, seed):
+        import numpy as np
+        self._drop_rng = np.random.default_rng(int(seed))
+
+    def train(self, mode=True):
+        self.training = bool(mode)
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def _site_seeds(self):
+        """per forward: (embedding site, [(attention, attn-output, ffn-output) per layer]) as (seed, thresh) pairs"""
+        cfg = self.cfg
+        L = cfg.num_hidden_layers
+        th = ops.drop_thresh(cfg.hidden_dropout_prob) if self.training else 0
+        ta = ops.drop_thresh(cfg.attention_probs_dropout_prob) if self.training else 0
+        if not (th or ta):
+            return ops.NO_DROP, [(ops.NO_DROP, ops.NO_DROP, ops.NO_DROP)] * L
+        sd = self._drop_rng.integers(0, 2 ** 32, size=1 + 3 * L, dtype="uint64")
+        emb = (int(sd[0]), th)
+        return emb, [((int(sd[1 + 3 * l]), ta), (int(sd[2 + 3 * l]), th), (int(sd[3 + 3 * l]), th)) for l in range(L)]
 
     # ---------------------------------------------------------------- parameters
     def init_random(self, seed=20220711, std=0.02):
@@ -286,44 +326,52 @@ class Tagger:
         ac = self.acts(B, S)
         Mp = ac.Mp
         eps = cfg.layer_norm_eps
+        d_emb, d_layers = self._site_seeds()
         ops.embed_ln_fwd(ids, pos_ids, a.param("emb.word"), a.param("emb.pos"), a.param("emb.type")[0], a.param("emb.ln.g"),
-                         a.param("emb.ln.b"), eps, ac.h0, ac.x[0], ac.emb_mean, ac.emb_rstd)
+                         a.param("emb.ln.b"), eps, ac.h0, ac.x[0], ac.emb_mean, ac.emb_rstd, drop=d_emb)
         for l in range(L):
             p = "l%d." % l
             x = ac.x[l]
+            d_att, d_o, d_f = d_layers[l]
             ops.gemm(GEMM_NT, x, a.bf(p + "qkv.weight"), Mp, 3 * H, H, C=ac.qkv[l], bias=a.param(p + "qkv.bias"), epi=EPI_BIAS)
-            ops.attn_fwd(ac.qkv[l], maskbias, ac.ctx[l], ac.lse[l], B, S, H, A)
+            ops.attn_fwd(ac.qkv[l], maskbias, ac.ctx[l], ac.lse[l], B, S, H, A, drop=d_att)
             ops.gemm(GEMM_NT, ac.ctx[l], a.bf(p + "o.weight"), Mp, H, H, C=ac.h1[l], bias=a.param(p + "o.bias"), addend=x,
-                     epi=EPI_BIAS | EPI_ADD)
+                     epi=EPI_BIAS | EPI_ADD, drop=d_o)
             ops.ln_fwd(ac.h1[l], a.param(p + "ln1.g"), a.param(p + "ln1.b"), eps, ac.x1[l], ac.st1[l][0], ac.st1[l][1])
             ops.gemm(GEMM_NT, ac.x1[l], a.bf(p + "ffn1.weight"), Mp, F_, H, C=ac.act[l], out2=ac.pre[l],
                      bias=a.param(p + "ffn1.bias"), epi=EPI_BIAS | EPI_GELU)
             ops.gemm(GEMM_NT, ac.act[l], a.bf(p + "ffn2.weight"), Mp, H, F_, C=ac.h2[l], bias=a.param(p + "ffn2.bias"),
-                     addend=ac.x1[l], epi=EPI_BIAS | EPI_ADD)
+                     addend=ac.x1[l], epi=EPI_BIAS | EPI_ADD, drop=d_f)
             ops.ln_fwd(ac.h2[l], a.param(p + "ln2.g"), a.param(p + "ln2.b"), eps, ac.x[l + 1], ac.st2[l][0], ac.st2[l][1])
-        self._enc_saved = (ids, pos_ids, maskbias, B, S)
+        self._enc_saved = (ids, pos_ids, maskbias, B, S, d_emb, d_layers)
         return ac.x[L]
 
     def encoder_backward(self, dx_top):
         """dx_top bf16 [Mp,H] = d loss / d last hidden state; accumulates into arena.g."""
         cfg, a = self.cfg, self.arena
         H, F_, A, L = cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads, cfg.num_hidden_layers
-        ids, pos_ids, maskbias, B, S = self._enc_saved
+        ids, pos_ids, maskbias, B, S, d_emb, d_layers = self._enc_saved
         ac = self.acts(B, S)
         Mp = ac.Mp
         dx = dx_top
         pending = []
+        dropping = any(d[1][1] for d in d_layers)
+        dhm_ring, dh1m_ring = ac.drop_buffers() if dropping else (ac.dh, ac.dh1)
         for l in range(L - 1, -1, -1):
             p = "l%d." % l
             r = l % WGRAD_GROUP
             dh, dh1, dpre, dqkv = ac.dh[r], ac.dh1[r], ac.dpre[r], ac.dqkv[r]
+            d_att, d_o, d_f = d_layers[l]
+            # with hidden dropout the sub-layer GEMMs see dY = mask * dh (dhm / dh1m); the residual branch keeps dh / dh1
+            dhm = dhm_ring[r] if d_f[1] else dh
+            dh1m = dh1m_ring[r] if d_o[1] else dh1
             # LN2 backward; fused: d ffn2.bias = column sums of dh
             ops.ln_bwd(dx, ac.h2[l], ac.st2[l][0], ac.st2[l][1], a.param(p + "ln2.g"), dh, a.grad(p + "ln2.g"),
-                       a.grad(p + "ln2.b"), a.grad(p + "ffn2.bias"))
+                       a.grad(p + "ln2.b"), a.grad(p + "ffn2.bias"), dhm=dhm if d_f[1] else None, drop=d_f)
             # FFN down dgrad: dpre = (dh W2) * gelu'(pre)
             # (its column sums = d ffn1.bias are accumulated by the same epilogue when the 256^2 kernel runs)
             fused = Mp % 256 == 0 and F_ % 256 == 0
-            ops.gemm(GEMM_NN, dh, a.bf(p + "ffn2.weight"), Mp, F_, H, C=dpre, aux=ac.pre[l],
+            ops.gemm(GEMM_NN, dhm, a.bf(p + "ffn2.weight"), Mp, F_, H, C=dpre, aux=ac.pre[l],
                      epi=EPI_DGELU | (EPI_COLSUM if fused else 0), colsum=a.grad(p + "ffn1.bias") if fused else None)
             # FFN up
             if not fused:
@@ -331,24 +379,24 @@ class Tagger:
             ops.gemm(GEMM_NN, dpre, a.bf(p + "ffn1.weight"), Mp, H, F_, C=ac.dx1, addend=dh, epi=EPI_ADD)
             # LN1 backward; fused: d o.bias
             ops.ln_bwd(ac.dx1, ac.h1[l], ac.st1[l][0], ac.st1[l][1], a.param(p + "ln1.g"), dh1, a.grad(p + "ln1.g"),
-                       a.grad(p + "ln1.b"), a.grad(p + "o.bias"))
+                       a.grad(p + "ln1.b"), a.grad(p + "o.bias"), dhm=dh1m if d_o[1] else None, drop=d_o)
             # attention output projection
-            ops.gemm(GEMM_NN, dh1, a.bf(p + "o.weight"), Mp, H, H, C=ac.dctx)
+            ops.gemm(GEMM_NN, dh1m, a.bf(p + "o.weight"), Mp, H, H, C=ac.dctx)
             # attention core
-            ops.attn_bwd(ac.qkv[l], ac.ctx[l], ac.dctx, maskbias, ac.lse[l], ac.dws, dqkv, B, S, H, A)
+            ops.attn_bwd(ac.qkv[l], ac.ctx[l], ac.dctx, maskbias, ac.lse[l], ac.dws, dqkv, B, S, H, A, drop=d_att)
             # QKV projection
             ops.colsum(dqkv, a.grad(p + "qkv.bias"))
             ops.gemm(GEMM_NN, dqkv, a.bf(p + "qkv.weight"), Mp, H, 3 * H, C=ac.dx, addend=dh1, epi=EPI_ADD)
             # weight gradients dW += dY^T X are deferred and launched for WGRAD_GROUP layers at once
             # (no split-K, no atomics; the dY buffers rotate so they stay live until the group is flushed)
-            pending += [(dh, ac.act[l], H, F_, p + "ffn2.weight"), (dpre, ac.x1[l], F_, H, p + "ffn1.weight"),
-                        (dh1, ac.ctx[l], H, H, p + "o.weight"), (dqkv, ac.x[l], 3 * H, H, p + "qkv.weight")]
+            pending += [(dhm, ac.act[l], H, F_, p + "ffn2.weight"), (dpre, ac.x1[l], F_, H, p + "ffn1.weight"),
+                        (dh1m, ac.ctx[l], H, H, p + "o.weight"), (dqkv, ac.x[l], 3 * H, H, p + "qkv.weight")]
             if l % WGRAD_GROUP == 0:
                 self._wgrads(pending, Mp)
                 pending = []
             dx = ac.dx
         ops.embed_ln_bwd(dx, ac.h0, ac.emb_mean, ac.emb_rstd, a.param("emb.ln.g"), ids, pos_ids, a.grad("emb.ln.g"),
-                         a.grad("emb.ln.b"), a.grad("emb.word"), a.grad("emb.pos"), a.grad("emb.type")[0])
+                         a.grad("emb.ln.b"), a.grad("emb.word"), a.grad("emb.pos"), a.grad("emb.type")[0], drop=d_emb)
 
     def _wgrads(self, pairs, Mp):
         a = self.arena
@@ -375,7 +423,16 @@ class Tagger:
         B, S = batch["B"], batch["S"]
         hidden = self.encoder_forward(batch["ids"], batch["pos_ids"], batch["maskbias"], B, S)
         nc = batch["ctags"].shape[1]
-        em, pooled = self.emissions(hidden, batch["crow_idx"], B, nc)
+        crow_idx = batch["crow_idx"]
+        if self.training and self.word_dropout > 0.0 and "cpos" in batch:
+            # WordDropout (flair/nn.py:176-183) on the [n,B,D] sentence tensor: token position k is zeroed for EVERY sentence
+            # of the batch, survivors are not rescaled.  Zero row = gather index -1 (and no gradient scattered back).
+            n_pos = int(batch["n_tokens"])
+            self._last_word_dropped = self._drop_rng.random(n_pos) < self.word_dropout
+            dropped = torch.from_numpy(self._last_word_dropped).to(self.device)
+            cpos = batch["cpos"].long()
+            crow_idx = torch.where(dropped[cpos.clamp(min=0)] & (cpos >= 0), torch.full_like(crow_idx, -1), crow_idx)
+        em, pooled = self.emissions(hidden, crow_idx, B, nc)
         a = self.arena
         trans = a.param("transitions")
         logz, gold, alpha = ops.crf_nll_fwd(em, trans, batch["ctags"], batch["clens"], self.start, self.stop)
@@ -390,7 +447,7 @@ class Tagger:
                                    a.grad("linear.bias"))
             ac = self.acts(B, S)
             ac.dx.zero_()
-            ops.scatter_rows(dpooled, batch["crow_idx"], ac.dx)
+            ops.scatter_rows(dpooled, crow_idx, ac.dx)
             self.encoder_backward(ac.dx)
         return loss[0]
 

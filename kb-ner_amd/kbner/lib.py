@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KBNER_LIB") or os.path.join(_HERE, "libkbner_hip.so")  # KBNER_LIB: experiment builds only
 
 c_int, c_float, c_void_p, c_size_t = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
+U32 = ctypes.c_uint32
 P = c_void_p
 
 # name -> (restype, argtypes) ; must list EVERY symbol include/kbner.h declares
@@ -29,14 +30,15 @@ SIGNATURES = {
     "kbner_colsum": (c_int, [P, P, c_int, c_int, c_int, P]),
     "kbner_ln_fwd": (c_int, [P, P, P, c_float, P, P, P, c_int, c_int, P]),
     "kbner_ln_bwd_ws_floats": (c_int, [c_int]),
-    "kbner_ln_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, c_int, P]),
-    "kbner_embed_ln_fwd": (c_int, [P, P, P, P, P, P, P, c_float, P, P, P, P, c_int, c_int, P]),
-    "kbner_embed_ln_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, P]),
+    "kbner_ln_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, c_int, P, U32, U32, P]),
+    "kbner_embed_ln_fwd": (c_int, [P, P, P, P, P, P, P, c_float, P, P, P, P, c_int, c_int, U32, U32, P]),
+    "kbner_embed_ln_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, U32, U32, P]),
+    "kbner_dropout_mask": (c_int, [P, c_int, c_int, c_int, U32, U32, P]),
     "kbner_gemm_bf16": (c_int, [c_int, P, c_int, P, c_int, c_int, c_int, c_int, P, c_int, P, c_int, P, P, c_int, P, c_int,
-                                P, c_int, c_int, c_int, c_float, P]),
+                                P, c_int, c_int, c_int, c_float, U32, U32, P]),
     "kbner_gemm_bf16_grouped": (c_int, [c_int, c_int, P, P]),
-    "kbner_attn_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
-    "kbner_attn_bwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "kbner_attn_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, U32, U32, P]),
+    "kbner_attn_bwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, U32, U32, P]),
     "kbner_sqnorm_ws_floats": (c_int, []),
     "kbner_grad_sqnorm": (c_int, [P, c_size_t, P, P, c_int, P]),
     "kbner_adamw_hf": (c_int, [P, P, P, P, P, c_size_t, c_size_t, c_float, c_float, c_float, c_float, c_float, P, c_float,
@@ -48,14 +50,15 @@ SIGNATURES = {
 }
 
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
-EPI_BIAS, EPI_GELU, EPI_ADD, EPI_DGELU, EPI_ATOMIC32, EPI_RMW32, EPI_COLSUM = 1, 2, 4, 8, 16, 32, 64
+EPI_BIAS, EPI_GELU, EPI_ADD, EPI_DGELU, EPI_ATOMIC32, EPI_RMW32, EPI_COLSUM, EPI_DROP = 1, 2, 4, 8, 16, 32, 64, 128
 
 
 class GemmProblem(ctypes.Structure):
     """mirror of kbner_gemm_problem (include/kbner.h)"""
     _fields_ = [("A", P), ("B", P), ("C", P), ("C32", P), ("bias", P), ("addend", P), ("aux", P), ("out2", P), ("colsum", P),
                 ("M", c_int), ("N", c_int), ("K", c_int), ("lda", c_int), ("ldb", c_int), ("ldc", c_int), ("ldc32", c_int),
-                ("ldadd", c_int), ("ldaux", c_int), ("ldout2", c_int), ("epi", c_int), ("alpha", c_float)]
+                ("ldadd", c_int), ("ldaux", c_int), ("ldout2", c_int), ("epi", c_int), ("alpha", c_float), ("drop_seed", U32),
+                ("drop_thresh", U32)]
 
 _lib = None
 

@@ -12,6 +12,23 @@ F32 = torch.float32
 I32 = torch.int32
 
 
+NO_DROP = (0, 0)  # (seed, thresh): thresh = 0 disables a dropout site
+
+
+def drop_thresh(p):
+    """dropout probability -> the 32-bit threshold the kernels compare against (include/kbner.h, dropout section)"""
+    if not 0.0 <= p < 1.0:
+        raise L.KbnerError("dropout probability must be in [0, 1)")
+    return min(int(round(p * 4294967296.0)), 0xFFFFFFFF)
+
+
+def dropout_mask(Z, M, N, seed, thresh, device="cuda"):
+    """tests: the multiplier (0 or 1/(1-p)) a site applies, f32[Z,M,N]"""
+    out = torch.empty((Z, M, N), dtype=F32, device=device)
+    L.call("kbner_dropout_mask", ptr(out), Z, M, N, seed, thresh, stream_ptr())
+    return out
+
+
 def _chk(t, dtype, name):
     if t.dtype != dtype or not t.is_cuda or not t.is_contiguous():
         raise L.KbnerError("%s must be a contiguous cuda %s tensor (got %s, cuda=%s, contiguous=%s)"
@@ -119,23 +136,24 @@ def ln_ws(H, device):
     return _LN_WS[key]
 
 
-def ln_bwd(dy, h, mean, rstd, gamma, dh, dgamma, dbeta, dbias=None):
+def ln_bwd(dy, h, mean, rstd, gamma, dh, dgamma, dbeta, dbias=None, dhm=None, drop=NO_DROP):
+    """drop=(seed, thresh) with thresh != 0: also writes dhm = mask * dh / (1-p) (the dY of the GEMM behind the dropout)."""
     M, H = h.shape
     L.call("kbner_ln_bwd", ptr(dy), ptr(h), ptr(mean), ptr(rstd), ptr(gamma), ptr(dh), ptr(dgamma), ptr(dbeta), ptr(dbias),
-           ptr(ln_ws(H, h.device)), M, H, stream_ptr())
+           ptr(ln_ws(H, h.device)), M, H, ptr(dhm), drop[0], drop[1], stream_ptr())
 
 
-def embed_ln_fwd(ids, pos_ids, word, pos, type0, gamma, beta, eps, h0, y, mean, rstd):
+def embed_ln_fwd(ids, pos_ids, word, pos, type0, gamma, beta, eps, h0, y, mean, rstd, drop=NO_DROP):
     _chk(ids, I32, "ids"); _chk(pos_ids, I32, "pos_ids"); _chk(word, F32, "word")
     M, H = ids.numel(), word.shape[1]
     L.call("kbner_embed_ln_fwd", ptr(ids), ptr(pos_ids), ptr(word), ptr(pos), ptr(type0), ptr(gamma), ptr(beta), eps, ptr(h0),
-           ptr(y), ptr(mean), ptr(rstd), M, H, stream_ptr())
+           ptr(y), ptr(mean), ptr(rstd), M, H, drop[0], drop[1], stream_ptr())
 
 
-def embed_ln_bwd(dy, h0, mean, rstd, gamma, ids, pos_ids, dgamma, dbeta, dword, dpos, dtype0):
+def embed_ln_bwd(dy, h0, mean, rstd, gamma, ids, pos_ids, dgamma, dbeta, dword, dpos, dtype0, drop=NO_DROP):
     M, H = ids.numel(), dword.shape[1]
     L.call("kbner_embed_ln_bwd", ptr(dy), ptr(h0), ptr(mean), ptr(rstd), ptr(gamma), ptr(ids), ptr(pos_ids), ptr(dgamma),
-           ptr(dbeta), ptr(dword), ptr(dpos), ptr(dtype0), ptr(ln_ws(H, dy.device)), M, H, stream_ptr())
+           ptr(dbeta), ptr(dword), ptr(dpos), ptr(dtype0), ptr(ln_ws(H, dy.device)), M, H, drop[0], drop[1], stream_ptr())
 
 
 # ---------------------------------------------------------------- GEMM
@@ -147,12 +165,16 @@ def _addr(t):
     return t.data_ptr() if t is not None else None
 
 
-def make_problem(A, B, M, N, K, C=None, C32=None, bias=None, addend=None, aux=None, out2=None, epi=0, alpha=1.0, colsum=None):
+def make_problem(A, B, M, N, K, C=None, C32=None, bias=None, addend=None, aux=None, out2=None, epi=0, alpha=1.0, colsum=None,
+                 drop=NO_DROP):
     _chk(A, BF16, "A"); _chk(B, BF16, "B")
+    if drop[1]:
+        epi |= L.EPI_DROP
     return L.GemmProblem(_addr(A), _addr(B), _addr(C), _addr(C32), _addr(bias), _addr(addend), _addr(aux), _addr(out2), _addr(colsum),
                          M, N, K, A.shape[1], B.shape[1], C.shape[1] if C is not None else 0,
                          C32.shape[1] if C32 is not None else 0, addend.shape[1] if addend is not None else 0,
-                         aux.shape[1] if aux is not None else 0, out2.shape[1] if out2 is not None else 0, epi, alpha)
+                         aux.shape[1] if aux is not None else 0, out2.shape[1] if out2 is not None else 0, epi, alpha,
+                         drop[0], drop[1])
 
 
 def gemm_grouped(layout, problems):
@@ -170,12 +192,14 @@ def gemm_grouped(layout, problems):
 
 
 def gemm(layout, A, B, M, N, K, C=None, C32=None, bias=None, addend=None, aux=None, out2=None, epi=0, splitk=1, alpha=1.0,
-         lda=None, ldb=None, colsum=None):
+         lda=None, ldb=None, colsum=None, drop=NO_DROP):
     """C[M,N] (bf16) or C32[M,N] += (fp32).  A/B are 2-D bf16 tensors in their memory layouts.
     Shapes divisible by 256 go to the 256^2 8-wave kernel, others to the 128^2 kernel."""
     _chk(A, BF16, "A"); _chk(B, BF16, "B")
     if M % 256 == 0 and N % 256 == 0 and splitk == 1 and lda is None and ldb is None and not FORCE_128:
-        return gemm_grouped(layout, [make_problem(A, B, M, N, K, C, C32, bias, addend, aux, out2, epi, alpha, colsum)])
+        return gemm_grouped(layout, [make_problem(A, B, M, N, K, C, C32, bias, addend, aux, out2, epi, alpha, colsum, drop)])
+    if drop[1]:
+        epi |= L.EPI_DROP
     if colsum is not None:
         raise L.KbnerError("EPI_COLSUM needs the 256x256 kernel (M, N % 256 == 0)")
     lda = A.shape[1] if lda is None else lda
@@ -190,20 +214,20 @@ def gemm(layout, A, B, M, N, K, C=None, C32=None, bias=None, addend=None, aux=No
            ptr(bias), ptr(addend), addend.shape[1] if addend is not None else 0,
            ptr(aux), aux.shape[1] if aux is not None else 0,
            ptr(out2), out2.shape[1] if out2 is not None else 0,
-           epi, splitk, alpha, stream_ptr())
+           epi, splitk, alpha, drop[0], drop[1], stream_ptr())
     if hook is not None:
         ev1.record()
         hook.append((ev0, ev1, 2.0 * M * N * K, layout))
 
 
 # ---------------------------------------------------------------- attention
-def attn_fwd(qkv, maskbias, ctx, lse, B, S, H, A):
-    L.call("kbner_attn_fwd", ptr(qkv), ptr(maskbias), ptr(ctx), ptr(lse), B, S, H, A, stream_ptr())
+def attn_fwd(qkv, maskbias, ctx, lse, B, S, H, A, drop=NO_DROP):
+    L.call("kbner_attn_fwd", ptr(qkv), ptr(maskbias), ptr(ctx), ptr(lse), B, S, H, A, drop[0], drop[1], stream_ptr())
 
 
-def attn_bwd(qkv, ctx, dctx, maskbias, lse, dws, dqkv, B, S, H, A):
+def attn_bwd(qkv, ctx, dctx, maskbias, lse, dws, dqkv, B, S, H, A, drop=NO_DROP):
     L.call("kbner_attn_bwd", ptr(qkv), ptr(ctx), ptr(dctx), ptr(maskbias), ptr(lse), ptr(dws), ptr(dqkv), B, S, H, A,
-           stream_ptr())
+           drop[0], drop[1], stream_ptr())
 
 
 # ---------------------------------------------------------------- optimiser

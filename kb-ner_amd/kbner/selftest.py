@@ -60,7 +60,7 @@ def probe_mfma():
 
 
 # ------------------------------------------------------------------ GEMM
-def check_gemm(layout, M, N, K, epi=0, splitk=1, seed=0):
+def check_gemm(layout, M, N, K, epi=0, splitk=1, seed=0, drop_p=0.0):
     g = torch.Generator(device="cpu").manual_seed(seed)
     A = (torch.randn(M, K, generator=g) * 0.5).to(BF16)
     Bm = (torch.randn(N, K, generator=g) * 0.5).to(BF16)
@@ -74,6 +74,9 @@ def check_gemm(layout, M, N, K, epi=0, splitk=1, seed=0):
     if epi & EPI_BIAS:
         ref = ref + bias.double()[None, :]
         kw["bias"] = bias.to(DEV)
+    if drop_p:  # dropout(acc + bias) BEFORE the residual add; reference multiplier from kbner_dropout_mask
+        kw["drop"] = (1234567 + seed, ops.drop_thresh(drop_p))
+        ref = ref * ops.dropout_mask(1, M, N, *kw["drop"])[0].cpu().double()
     if epi & EPI_ADD:
         ref = ref + add.double()
         kw["addend"] = add.to(DEV)
@@ -124,13 +127,15 @@ def check_gemm_grouped(seed=0):
 
 
 # ------------------------------------------------------------------ attention
-def attn_reference(qkv, maskbias, B, S, H, A, dctx=None):
+def attn_reference(qkv, maskbias, B, S, H, A, dctx=None, pmask=None):
     d = H // A
     x = qkv.detach().double().clone().requires_grad_(dctx is not None)
     q, k, v = x[:, :H], x[:, H:2 * H], x[:, 2 * H:]
     sp = lambda t: t.reshape(B, S, A, d).transpose(1, 2)  # noqa: E731
     sc = sp(q) @ sp(k).transpose(-1, -2) / np.sqrt(d) + maskbias.double()[:, None, None, :]
     pr = torch.softmax(sc, dim=-1)
+    if pmask is not None:
+        pr = pr * pmask.double()
     ctx = (pr @ sp(v)).transpose(1, 2).reshape(B * S, H)
     lse = torch.logsumexp(sc, dim=-1)
     if dctx is None:
@@ -139,7 +144,7 @@ def attn_reference(qkv, maskbias, B, S, H, A, dctx=None):
     return ctx.detach(), lse.detach(), x.grad
 
 
-def check_attention(B, S, A, seed=0, ragged=True):
+def check_attention(B, S, A, seed=0, ragged=True, drop_p=0.0):
     H = A * 64
     g = torch.Generator(device="cpu").manual_seed(seed)
     qkv = (torch.randn(B * S, 3 * H, generator=g)).to(BF16)
@@ -149,14 +154,16 @@ def check_attention(B, S, A, seed=0, ragged=True):
         for b in range(B):
             am[b, S - 7 * b - (5 if b else 0):] = 0 if b else 1
     mb = ((1 - am) * -10000.0).float()
-    ctx_ref, lse_ref, dqkv_ref = attn_reference(qkv.float(), mb, B, S, H, A, dctx.float())
+    drop = (424242 + seed, ops.drop_thresh(drop_p)) if drop_p else ops.NO_DROP
+    pmask = ops.dropout_mask(B * A, S, S, *drop).view(B, A, S, S).cpu() if drop_p else None
+    ctx_ref, lse_ref, dqkv_ref = attn_reference(qkv.float(), mb, B, S, H, A, dctx.float(), pmask)
     qd, dd, mbd = qkv.to(DEV), dctx.to(DEV), mb.to(DEV)
     ctx = torch.zeros(B * S, H, dtype=BF16, device=DEV)
     lse = torch.zeros(B, A, S, dtype=F32, device=DEV)
-    ops.attn_fwd(qd, mbd, ctx, lse, B, S, H, A)
+    ops.attn_fwd(qd, mbd, ctx, lse, B, S, H, A, drop=drop)
     dws = torch.zeros(B, A, S, dtype=F32, device=DEV)
     dqkv = torch.zeros(B * S, 3 * H, dtype=BF16, device=DEV)
-    ops.attn_bwd(qd, ctx, dd, mbd, lse, dws, dqkv, B, S, H, A)
+    ops.attn_bwd(qd, ctx, dd, mbd, lse, dws, dqkv, B, S, H, A, drop=drop)
     torch.cuda.synchronize()
     dq = dqkv.cpu().float()
     return {
@@ -169,7 +176,7 @@ def check_attention(B, S, A, seed=0, ragged=True):
 
 
 # ------------------------------------------------------------------ LayerNorm
-def check_layernorm(M, H, seed=0):
+def check_layernorm(M, H, seed=0, drop_p=0.0):
     g = torch.Generator(device="cpu").manual_seed(seed)
     h = (torch.randn(M, H, generator=g) * 2 + 0.3).to(BF16)
     dy = torch.randn(M, H, generator=g).to(BF16)
@@ -190,15 +197,23 @@ def check_layernorm(M, H, seed=0):
     dg = torch.zeros(H, dtype=F32, device=DEV)
     db = torch.zeros(H, dtype=F32, device=DEV)
     dbias = torch.zeros(H, dtype=F32, device=DEV)
-    ops.ln_bwd(dyd, hd, mean, rstd, gd, dh, dg, db, dbias)
+    drop = (99 + seed, ops.drop_thresh(drop_p)) if drop_p else ops.NO_DROP
+    dhm = torch.zeros(M, H, dtype=BF16, device=DEV) if drop_p else None
+    ops.ln_bwd(dyd, hd, mean, rstd, gd, dh, dg, db, dbias, dhm=dhm, drop=drop)
     torch.cuda.synchronize()
-    return {
+    res = {
         "y": rel_l2(y.cpu().float(), y_ref.detach()),
         "dh": rel_l2(dh.cpu().float(), hr.grad),
         "dgamma": rel_l2(dg.cpu(), gr.grad),
         "dbeta": rel_l2(db.cpu(), br.grad),
-        "dbias": rel_l2(dbias.cpu(), hr.grad.sum(0)),
     }
+    if drop_p:  # dhm = mask * dh (the dropped branch's dY); dbias sums the masked rows
+        mref = hr.grad * ops.dropout_mask(1, M, H, *drop)[0].cpu().double()
+        res["dhm"] = rel_l2(dhm.cpu().float(), mref)
+        res["dbias"] = rel_l2(dbias.cpu(), mref.sum(0))
+    else:
+        res["dbias"] = rel_l2(dbias.cpu(), hr.grad.sum(0))
+    return res
 
 
 # ------------------------------------------------------------------ CRF
@@ -272,14 +287,65 @@ def oracle_params(tg, round_gemm=True):
     return sd
 
 
-def check_step():
-    """One micro-batch fwd+bwd on the HIP path vs the oracle's autograd (fp32 CPU)."""
+def dropout_masks_of(tg, B, S):
+    """The multipliers the last training-mode forward applied, rebuilt from its saved seeds with kbner_dropout_mask."""
+    cfg = tg.cfg
+    H, A = cfg.hidden_size, cfg.num_attention_heads
+    M = B * S
+    d_emb, d_layers = tg._enc_saved[5], tg._enc_saved[6]
+    hid = lambda d: ops.dropout_mask(1, tg.acts(B, S).Mp, H, d[0], d[1])[0, :M].view(B, S, H).cpu()  # noqa: E731
+    masks = {}
+    if d_emb[1]:
+        masks["emb"] = hid(d_emb)
+    for i, (d_att, d_o, d_f) in enumerate(d_layers):
+        if d_att[1]:
+            masks[("attn", i)] = ops.dropout_mask(B * A, S, S, d_att[0], d_att[1]).view(B, A, S, S).cpu()
+        if d_o[1]:
+            masks[("o", i)] = hid(d_o)
+        if d_f[1]:
+            masks[("ffn", i)] = hid(d_f)
+    return masks
+
+
+def check_dropout_mask(p=0.1, Z=3, M=512, N=512, seed=12345):
+    """statistics of the counter-based mask: keep rate, row / column keep-rate spread, replay determinism, seed sensitivity"""
+    th = ops.drop_thresh(p)
+    m = ops.dropout_mask(Z, M, N, seed, th)
+    m2 = ops.dropout_mask(Z, M, N, seed, th)
+    m3 = ops.dropout_mask(Z, M, N, seed + 1, th)
+    torch.cuda.synchronize()
+    keep = (m > 0).float()
+    vals = torch.unique(m).cpu().tolist()
+    k3 = (m3 > 0).float()
+    # correlation between the masks of two seeds and between adjacent rows / columns of one mask
+    def corr(a, b):
+        a, b = a.flatten() - a.mean(), b.flatten() - b.mean()
+        return float((a @ b) / (a.norm() * b.norm() + 1e-30))
+    return {"keep_rate": float(keep.mean()), "values": vals, "scale": 1.0 / (1.0 - p),
+            "row_rate_min": float(keep.mean(2).min()), "row_rate_max": float(keep.mean(2).max()),
+            "col_rate_min": float(keep.mean(1).min()), "col_rate_max": float(keep.mean(1).max()),
+            "replay_equal": bool(torch.equal(m, m2)), "seed_corr": corr(keep, k3),
+            "adj_row_corr": corr(keep[:, 1:], keep[:, :-1]), "adj_col_corr": corr(keep[:, :, 1:], keep[:, :, :-1])}
+
+
+def check_step(dropout=False, H=128, A=2, F_=256):
+    """One micro-batch fwd+bwd on the HIP path vs the oracle's autograd (fp32 CPU).  dropout=True: training mode with
+    p=0.1 at every encoder site + WordDropout 0.1; the oracle is fed the very masks the kernels generated."""
     from oracle import encoder as oenc
     from oracle import train_step as ots
-    cfg, tg, b, (start, stop, x_idx) = tiny_setup()
+    cfg, tg, b, (start, stop, x_idx) = tiny_setup(H=H, A=A, F_=F_)
     bd = kb.to_device(b, DEV)
+    masks, word_keep = None, None
+    if dropout:
+        tg.train(True)
+        tg.word_dropout = 0.1
+        tg.seed_dropout(7)
     loss = tg.forward_loss(bd, loss_scale=1.0, backward=True)
     torch.cuda.synchronize()
+    if dropout:
+        masks = dropout_masks_of(tg, b["B"], b["S"])
+        word_keep = torch.from_numpy(~tg._last_word_dropped)
+        tg.train(False)
     ocfg = oenc.EncoderConfig(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers,
                               num_attention_heads=cfg.num_attention_heads, intermediate_size=cfg.intermediate_size,
                               max_position_embeddings=cfg.max_position_embeddings)
@@ -287,10 +353,15 @@ def check_step():
     ob = dict(input_ids=torch.from_numpy(b["input_ids"]), attention_mask=torch.from_numpy(b["attention_mask"]),
               first_idx=torch.from_numpy(b["first_idx"]), tags=torch.from_numpy(b["tags"].astype(np.int64)),
               lengths=torch.from_numpy(b["lengths"].astype(np.int64)))
-    oloss, oem = ots.tagger_forward_loss(params, ocfg, ob, start, stop, x_idx)
+    oloss, oem = ots.tagger_forward_loss(params, ocfg, ob, start, stop, x_idx, masks=masks, word_keep=word_keep)
     oloss.backward()
     res = {"loss_hip": float(loss), "loss_oracle": float(oloss), "loss_rel": abs(float(loss) - float(oloss)) / abs(float(oloss))}
-    # hidden / emissions parity (forward only, all tokens)
+    if dropout:
+        res["n_sites"] = len(masks)
+        res["word_dropped"] = int((~word_keep).sum())
+        with torch.no_grad():
+            oem = ots.tagger_forward_loss(params, ocfg, ob, start, stop, x_idx)[1]
+    # hidden / emissions parity (forward only, all tokens; evaluation mode)
     em = tg.forward_features(bd)
     torch.cuda.synchronize()
     n = b["first_idx"].shape[1]

@@ -103,9 +103,16 @@ def position_ids_from_input_ids(input_ids, pad_id):
     return torch.cumsum(m, dim=1) * m + pad_id
 
 
-def encoder_forward(params, cfg, input_ids, attention_mask, return_all=False):
+def encoder_forward(params, cfg, input_ids, attention_mask, return_all=False, masks=None):
     """input_ids int64[B,S], attention_mask {0,1}[B,S] -> last hidden state f32[B,S,H]
-    (== hidden_states[-1], the only layer the path uses: `layers: '-1'`)."""
+    (== hidden_states[-1], the only layer the path uses: `layers: '-1'`).
+
+    masks (training-mode dropout, transformers 3.0.0 modeling_bert: BertEmbeddings.forward dropout after the LayerNorm,
+    BertSelfAttention `attention_probs = self.dropout(attention_probs)`, BertSelfOutput / BertOutput dense -> dropout ->
+    LayerNorm(h + input)): optional dict of explicit MULTIPLIERS (0 or 1/(1-p)) so a test can feed the exact mask the
+    HIP kernels regenerate from their seeds: "emb" [B,S,H], ("attn", i) [B,A,S,S], ("o", i) / ("ffn", i) [B,S,H]."""
+    masks = masks or {}
+    mul = lambda t, key: t * masks[key] if key in masks else t  # noqa: E731
     H, A = cfg.hidden_size, cfg.num_attention_heads
     d = H // A
     B, S = input_ids.shape
@@ -115,6 +122,7 @@ def encoder_forward(params, cfg, input_ids, attention_mask, return_all=False):
          + params["embeddings.position_embeddings.weight"][pos]
          + params["embeddings.token_type_embeddings.weight"][0])
     x = F.layer_norm(x, (H,), params["embeddings.LayerNorm.weight"], params["embeddings.LayerNorm.bias"], eps)
+    x = mul(x, "emb")
     ext = (1.0 - attention_mask.to(x.dtype))[:, None, None, :] * -10000.0
     hs = [x]
     for i in range(cfg.num_hidden_layers):
@@ -126,13 +134,13 @@ def encoder_forward(params, cfg, input_ids, attention_mask, return_all=False):
         k = k.view(B, S, A, d).transpose(1, 2)
         v = v.view(B, S, A, d).transpose(1, 2)
         sc = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(d) + ext
-        pr = torch.softmax(sc, dim=-1)
+        pr = mul(torch.softmax(sc, dim=-1), ("attn", i))
         c = torch.matmul(pr, v).transpose(1, 2).reshape(B, S, H)
-        o = F.linear(c, params[p + "attention.output.dense.weight"], params[p + "attention.output.dense.bias"])
+        o = mul(F.linear(c, params[p + "attention.output.dense.weight"], params[p + "attention.output.dense.bias"]), ("o", i))
         x = F.layer_norm(o + x, (H,), params[p + "attention.output.LayerNorm.weight"],
                          params[p + "attention.output.LayerNorm.bias"], eps)
         h = F.gelu(F.linear(x, params[p + "intermediate.dense.weight"], params[p + "intermediate.dense.bias"]))
-        o = F.linear(h, params[p + "output.dense.weight"], params[p + "output.dense.bias"])
+        o = mul(F.linear(h, params[p + "output.dense.weight"], params[p + "output.dense.bias"]), ("ffn", i))
         x = F.layer_norm(o + x, (H,), params[p + "output.LayerNorm.weight"], params[p + "output.LayerNorm.bias"], eps)
         hs.append(x)
     if return_all:

@@ -19,7 +19,7 @@ def test_build_and_symbols():
         assert hasattr(handle, name), "missing export: " + name
     # the binding lists exactly the header's symbols
     assert declared == set(lib.SIGNATURES), (declared ^ set(lib.SIGNATURES))
-    assert handle.kbner_abi_version() == 1
+    assert handle.kbner_abi_version() == 2
 
 
 def test_product_path_never_imports_oracle():

@@ -191,3 +191,53 @@ def test_full_step_vs_oracle(st):
     assert r["grad_min_cos"] > 0.98 and r["grad_worst_rel"] < 0.15, r
     assert r["grad_linear.weight"] < 5e-2 and r["grad_transitions"] < 5e-2, r
     assert r["viterbi_equal"], r
+
+
+# ------------------------------------------------------------------ dropout (training mode)
+def test_dropout_mask_statistics(st):
+    """counter-based mask: exact keep probability in expectation, no visible row/column structure, replayable from the seed"""
+    r = st.check_dropout_mask(p=0.1, Z=3, M=512, N=512)
+    assert abs(r["keep_rate"] - 0.9) < 2e-3, r                       # 786k samples: sigma = 3.4e-4
+    assert sorted(r["values"]) == pytest.approx([0.0, 1.0 / 0.9], rel=1e-6), r
+    assert r["row_rate_min"] > 0.82 and r["row_rate_max"] < 0.97, r   # 512 samples per row: sigma = 0.013
+    assert r["col_rate_min"] > 0.82 and r["col_rate_max"] < 0.97, r
+    assert r["replay_equal"], r
+    assert abs(r["seed_corr"]) < 5e-3 and abs(r["adj_row_corr"]) < 5e-3 and abs(r["adj_col_corr"]) < 5e-3, r
+
+
+@pytest.mark.parametrize("force128", [False, True])
+def test_gemm_dropout_epilogue(st, force128):
+    """C = dropout(A.B^T + bias) + addend on both GEMM kernels against the materialised mask"""
+    from kbner import ops
+    ops.FORCE_128 = force128
+    try:
+        assert st.check_gemm(0, 512, 256, 128, 1 | 4, 1, drop_p=0.1) < 6e-3
+        assert st.check_gemm(0, 256, 512, 192, 1, 1, seed=3, drop_p=0.5) < 6e-3
+    finally:
+        ops.FORCE_128 = False
+
+
+@pytest.mark.parametrize("B,S,A", [(2, 128, 2), (2, 512, 2), (3, 320, 1)])
+def test_attention_dropout(st, B, S, A):
+    """forward and both backward kernels replay the same probability mask"""
+    r = st.check_attention(B, S, A, ragged=True, drop_p=0.1)
+    assert r["ctx"] < 1.5e-2 and r["lse"] < 2e-2, r
+    assert r["dq"] < 3e-2 and r["dk"] < 3e-2 and r["dv"] < 3e-2, r
+
+
+@pytest.mark.parametrize("M,H", [(256, 128), (512, 1024)])
+def test_layernorm_backward_dropout_replay(st, M, H):
+    r = st.check_layernorm(M, H, drop_p=0.1)
+    assert r["dh"] < 1e-2 and r["dhm"] < 1e-2 and r["dbias"] < 2e-2, r
+
+
+@pytest.mark.parametrize("H,A,F_", [(128, 2, 256), (256, 4, 512)])
+def test_full_step_with_dropout_vs_oracle(st, H, A, F_):
+    """training-mode micro-batch (all three encoder dropout sites + WordDropout) vs the oracle given the same masks;
+    (256,4,512) runs the sub-layer GEMMs on the 256x256 kernel, (128,2,256) on the 128x128 one"""
+    r = st.check_step(dropout=True, H=H, A=A, F_=F_)
+    assert r["n_sites"] == 1 + 3 * 2, r
+    assert r["loss_rel"] < 3e-2, r
+    assert r["emissions_rel"] < 3e-2, r
+    assert r["grad_min_cos"] > 0.97 and r["grad_worst_rel"] < 0.2, r
+    assert r["grad_linear.weight"] < 5e-2 and r["grad_transitions"] < 5e-2, r
