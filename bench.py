@@ -86,8 +86,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--micro-batch", type=int, default=32)
-    ap.add_argument("--accum", type=int, default=4)
+    ap.add_argument("--micro-batch", type=int, default=128)
+    ap.add_argument("--accum", type=int, default=1)
     ap.add_argument("--seq-len", type=int, default=512)
     ap.add_argument("--model", default="large", choices=["large", "base"])
     ap.add_argument("--no-cpu-baseline", action="store_true")

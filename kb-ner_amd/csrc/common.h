@@ -85,6 +85,43 @@ static __device__ __forceinline__ void gelu_parts(float x, float& cdf, float& e)
   const float erf_abs = 1.0f - poly * e;
   cdf = 0.5f * (1.0f + copysignf(erf_abs, x));
 }
+// Two elements at a time on the packed fp32 pipe (v_pk_fma_f32 / v_pk_mul_f32: 2 lanes-worth per issue): the GEMM
+// epilogues that apply GELU / GELU' are VALU-bound (128 elements per lane per 256x256 tile), so halving the issue
+// count of the polynomial part is worth ~10 % of those GEMMs.  Same A&S 7.1.26 arithmetic as gelu_parts, refactored so
+// that no copysign is needed for the forward:  x*cdf = 0.5 x + |x| (0.5 - 0.5 p e).
+typedef float f2v __attribute__((ext_vector_type(2)));
+static __device__ __forceinline__ f2v splat2(float a) { return (f2v){a, a}; }
+// h = 0.5 - 0.5 * poly(t) * e  (= 0.5 * erf(|x| / sqrt 2)),  e = exp(-x^2 / 2)
+static __device__ __forceinline__ void gelu_half_erf2(f2v x, f2v ax, f2v& h, f2v& e) {
+  const f2v d = ax * splat2(0.3275911f * 0.70710678118654752f) + splat2(1.0f);
+  const f2v t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+  const f2v a = (x * x) * splat2(-0.5f * 1.4426950408889634f);
+  e = (f2v){__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+  f2v p = t * splat2(0.5f * 1.061405429f) + splat2(0.5f * -1.453152027f);
+  p = p * t + splat2(0.5f * 1.421413741f);
+  p = p * t + splat2(0.5f * -0.284496736f);
+  p = p * t + splat2(0.5f * 0.254829592f);
+  p = p * t;
+  h = splat2(0.5f) - p * e;
+}
+static __device__ __forceinline__ f2v gelu2(f2v x) {
+  const f2v ax = {fabsf(x[0]), fabsf(x[1])};
+  f2v h, e;
+  gelu_half_erf2(x, ax, h, e);
+  return x * splat2(0.5f) + ax * h;
+}
+static __device__ __forceinline__ f2v gelu_grad2(f2v x) {
+  const f2v ax = {fabsf(x[0]), fabsf(x[1])};
+  f2v h, e;
+  gelu_half_erf2(x, ax, h, e);
+  const f2v sh = {copysignf(h[0], x[0]), copysignf(h[1], x[1])};
+  return (x * e) * splat2(0.39894228040143268f) + (sh + splat2(0.5f));
+}
+// packed bf16 pair (one dword) <-> f2v
+static __device__ __forceinline__ f2v unpack2bf(uint32_t w) {
+  return (f2v){__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)};
+}
+
 static __device__ __forceinline__ float gelu_f(float x) {
   float cdf, e;
   gelu_parts(x, cdf, e);

@@ -370,8 +370,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GroupArgs ga) {
         const uint32_t w[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          v[2 * r] *= gelu_grad_f(__uint_as_float(w[r] << 16));
-          v[2 * r + 1] *= gelu_grad_f(__uint_as_float(w[r] & 0xffff0000u));
+          const f2v gg = gelu_grad2(unpack2bf(w[r]));
+          v[2 * r] *= gg[0];
+          v[2 * r + 1] *= gg[1];
         }
       }
       if (epi & EPI_GELU) {
@@ -386,8 +387,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GroupArgs ga) {
         const uint32_t w[4] = {pu.x, pu.y, pu.z, pu.w};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          v[2 * r] = gelu_f(__uint_as_float(w[r] << 16));
-          v[2 * r + 1] = gelu_f(__uint_as_float(w[r] & 0xffff0000u));
+          const f2v gg = gelu2(unpack2bf(w[r]));
+          v[2 * r] = gg[0];
+          v[2 * r + 1] = gg[1];
         }
       }
       uint4 o;
