@@ -187,9 +187,20 @@ def main():
             d[1] += s_ev.elapsed_time(e_ev)
             d[2] += 1
         ach = tot_fl / (tot_ms * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": "gemm_kernel<A_KS,B_KS> (bf16 MFMA 16x16x32, all 3 layouts)",
+        # HBM-side bytes per launch of the same kernel family, from the committed rocprofv3 PMC passes of THIS command at its
+        # default configuration (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE; tools/pmc_traffic.py); None otherwise
+        traffic, traffic_src = None, None
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1_c_hbm_traffic.json")
+        if args.model == "large" and B == 128 and S == 512 and os.path.exists(tpath):
+            ks = [v for k, v in json.load(open(tpath))["kernels"].items() if "gemm256_kernel" in k]
+            n = sum(v["launches"] for v in ks)
+            if n:
+                traffic = round(sum(v["launches"] * v["hbm_bytes_per_launch"] for v in ks) / n)
+                traffic_src = "profiles/round1_c_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch)"
+        roofline = {"bound": "mfma", "kernel": "gemm256_kernel<A_KS,B_KS> (bf16 MFMA 16x16x32, 256x256x64 tiles, all 3 layouts)",
                     "achieved": round(ach, 2), "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
+                    "frac": round(ach / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                    "algorithmic_flops_per_launch": round(tot_fl / max(len(recs), 1)),
                     "launches_per_step": len(recs), "gemm_ms_per_step": round(tot_ms, 3),
                     "by_layout": {("NT_fwd", "NN_dgrad", "TN_wgrad")[k]: {"tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 2),
                                                                               "ms": round(v[1], 3), "launches": v[2]}
