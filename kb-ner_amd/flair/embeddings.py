@@ -227,7 +227,8 @@ class TransformerWordEmbeddings(TokenEmbeddings):
         return counts
 
     def tokenize_sentence(self, sentence):
-        """-> (ids incl. <s>/</s>, first_idx per word token (-1 = no sub-token))"""
+        """-> (encoder rows [ids incl. <s>/</s>] -- one per sliding window --, window of each word token's first sub-token,
+        its position inside that row (-1 = no sub-token))"""
         words = [self._eos_text if t.text == "<EOS>" else t.text for t in sentence]
         text = " ".join(words)
         pieces = self.tokenizer.tokenize(text)
@@ -244,35 +245,75 @@ class TransformerWordEmbeddings(TokenEmbeddings):
                 pos += c
             pieces = kept
             counts = [min(c, self.maximum_subtoken_length) for c in counts]
-        ids = self.tokenizer.convert_tokens_to_ids(pieces)
-        budget = self.max_subtokens_sequence_length - 2
-        if len(ids) > budget:
-            raise NotImplementedError("sentence of %d sub-tokens exceeds the single %d window; the sliding-window path "
-                                      "(flair/embeddings.py:3203-3227,3292-3299) is not on the MI355X hot path yet"
-                                      % (len(ids), self.max_subtokens_sequence_length))
-        first, pos = [], self.begin_offset
+        ids = list(self.tokenizer.convert_tokens_to_ids(pieces))
+        windows, where = self.split_windows(len(ids))
+        first_row, first, g = [], [], 0
         for c in counts:
-            first.append(pos if c > 0 else -1)
-            pos += c
-        return [self._bos_id] + list(ids) + [self._eos_id], first
+            if c > 0:
+                w, pos = where(g)
+                first_row.append(w)
+                first.append(pos)
+            else:
+                first_row.append(0)
+                first.append(-1)
+            g += c
+        rows = [[self._bos_id] + ids[lo:hi] + [self._eos_id] for lo, hi in windows]
+        return rows, first_row, first
+
+    def split_windows(self, n_ids):
+        """Sliding windows over a sentence of n_ids content sub-tokens (flair/embeddings.py:3203-3227: encode_plus with
+        max_length = max_subtokens_sequence_length, stride, return_overflowing_tokens -- every window holds up to
+        max_length-2 content ids and the next one restarts `stride` ids before the previous one's end) and the seam rule
+        of :3292-3299 (drop the last 1 + stride//2 positions of the accumulated states and the first 1 + stride//2 of the
+        next window, then index the concatenation).  Returns ([(lo, hi) content range per window], where) with
+        where(g) -> (window, position inside the window's row incl. <s>) for content position g."""
+        W = self.max_subtokens_sequence_length - 2
+        st = self.stride
+        off = self.begin_offset
+        if n_ids <= W:
+            return [(0, n_ids)], (lambda g: (0, g + off))
+        if not self.allow_long_sentences or st <= 0:
+            return [(0, W)], (lambda g: (0, g + off) if g < W else (0, -1))  # truncated: no window covers g
+        if st % 2 or st >= W:
+            raise NotImplementedError("sliding window needs an even stride < max_subtokens_sequence_length - 2")
+        starts = [0]
+        while starts[-1] + W < n_ids:
+            starts.append(starts[-1] + W - st)
+        windows = [(lo, min(lo + W, n_ids)) for lo in starts]
+        half = st // 2
+
+        def where(g):
+            for w, lo in enumerate(starts):
+                if w == len(starts) - 1 or g < lo + W - half:
+                    return w, g - lo + off
+            raise AssertionError
+
+        return windows, where
 
     def prepare_batch(self, sentences):
-        """numpy integer batch: input_ids / attention_mask [B,S0] (padded with 0 like the reference), first_idx [B,n] (-1 pad),
-        lengths [B]."""
+        """numpy integer batch: input_ids / attention_mask [R,S0] (R >= B encoder rows: a sentence longer than one window
+        contributes several; padded with 0 like the reference), first_idx [B,n] (position inside the row, -1 pad),
+        lengths [B], first_row [B,n] (which encoder row holds each word token's first sub-token)."""
         toks = [self.tokenize_sentence(s) for s in sentences]
         B = len(toks)
-        S0 = max(len(t[0]) for t in toks)
+        R = sum(len(t[0]) for t in toks)
+        S0 = max(len(r) for t in toks for r in t[0])
         n = max(len(s) for s in sentences)
-        ids = np.zeros((B, S0), np.int64)
-        am = np.zeros((B, S0), np.int64)
+        ids = np.zeros((R, S0), np.int64)
+        am = np.zeros((R, S0), np.int64)
         first = np.full((B, n), -1, np.int64)
+        first_row = np.zeros((B, n), np.int64)
         lengths = np.zeros(B, np.int64)
-        for b, (i, f) in enumerate(toks):
-            ids[b, :len(i)] = i
-            am[b, :len(i)] = 1
+        r0 = 0
+        for b, (rows, fr, f) in enumerate(toks):
+            for j, r in enumerate(rows):
+                ids[r0 + j, :len(r)] = r
+                am[r0 + j, :len(r)] = 1
             first[b, :len(f)] = f
+            first_row[b, :len(f)] = np.asarray(fr, np.int64) + r0
             lengths[b] = len(sentences[b])
-        return ids, am, first, lengths
+            r0 += len(rows)
+        return ids, am, first, lengths, first_row
 
     def _add_embeddings_internal(self, sentences):
         """stores the integer batch on the BatchedData (or returns it); the tagger's engine turns it into features"""

@@ -154,9 +154,9 @@ class SequenceTagger(flair.nn.Model):
         name = self._emb.name
         feats = getattr(sentences, "features", None)
         if feats is not None and name in feats and isinstance(feats[name], tuple):
-            ids, am, first, lengths = feats[name]
+            ids, am, first, lengths, first_row = feats[name]
         else:
-            ids, am, first, lengths = self._emb.prepare_batch(sentences)
+            ids, am, first, lengths, first_row = self._emb.prepare_batch(sentences)
         n = first.shape[1]
         tags = np.zeros((len(sentences), n), np.int64)
         for b, s in enumerate(sentences):
@@ -166,7 +166,7 @@ class SequenceTagger(flair.nn.Model):
                 tags[b, :min(n, len(t))] = t[:n]
             else:
                 tags[b, :len(s)] = [self.tag_dictionary.get_idx_for_item(tok.get_tag(self.tag_type).value) for tok in s]
-        hb = kb.assemble(ids, am, first, tags, lengths, self.x_idx)
+        hb = kb.assemble(ids, am, first, tags, lengths, self.x_idx, first_row=first_row)
         return hb, kb.to_device(hb, flair.device)
 
     # ------------------------------------------------------------------ forward / loss

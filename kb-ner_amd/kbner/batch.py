@@ -14,35 +14,37 @@ def round_up(x, m):
     return (x + m - 1) // m * m
 
 
-def assemble(input_ids, attention_mask, first_idx, tags, lengths, x_idx, pad_id=1, s_multiple=64):
-    """input_ids/attention_mask int[B,S0]; first_idx int[B,n] (sub-token position of each word token's
-    first piece, -1 = none/padding); tags int[B,n]; lengths int[B] (word tokens per sentence).
-    Returns a dict of numpy arrays (see to_device)."""
+def assemble(input_ids, attention_mask, first_idx, tags, lengths, x_idx, pad_id=1, s_multiple=64, first_row=None):
+    """input_ids/attention_mask int[R,S0] (R encoder rows; R == B unless sentences were split into sliding windows);
+    first_idx int[B,n] (sub-token position of each word token's first piece inside its row, -1 = none/padding);
+    first_row int[B,n] (encoder row of that piece; default: row b); tags int[B,n]; lengths int[B] (word tokens per
+    sentence).  Returns a dict of numpy arrays (see to_device)."""
     input_ids = np.asarray(input_ids, np.int64)
     attention_mask = np.asarray(attention_mask, np.int64)
     first_idx = np.asarray(first_idx, np.int64)
     tags = np.asarray(tags, np.int64)
     lengths = np.asarray(lengths, np.int64)
-    B, S0 = input_ids.shape
+    R, S0 = input_ids.shape
+    B = first_idx.shape[0]
     n = first_idx.shape[1]
     S = max(64, round_up(S0, s_multiple))
     if S > 512:
         raise ValueError("sequence length %d exceeds the encoder's 512-position window" % S0)
-    ids = np.zeros((B, S), np.int64)            # the reference pads ids with 0 and the mask with 0 (:3247-3260)
-    am = np.zeros((B, S), np.int64)
+    ids = np.zeros((R, S), np.int64)            # the reference pads ids with 0 and the mask with 0 (:3247-3260)
+    am = np.zeros((R, S), np.int64)
     ids[:, :S0] = input_ids
     am[:, :S0] = attention_mask
     nz = (ids != pad_id).astype(np.int64)       # RoBERTa position ids from ids != pad (transformers modeling_roberta)
     pos = np.cumsum(nz, axis=1) * nz + pad_id
-    M = B * S
+    M = R * S
     Mp = round_up(M, 256)
     ids_f = np.zeros(Mp, np.int32)
     pos_f = np.full(Mp, pad_id, np.int32)
     ids_f[:M] = ids.reshape(-1)
     pos_f[:M] = pos.reshape(-1)
     maskbias = ((1 - am) * -10000.0).astype(np.float32)
-    base = (np.arange(B, dtype=np.int64) * S)[:, None]
-    row_idx = np.where(first_idx >= 0, base + first_idx, -1).astype(np.int32)
+    rows = np.arange(B, dtype=np.int64)[:, None] if first_row is None else np.asarray(first_row, np.int64)
+    row_idx = np.where(first_idx >= 0, rows * S + first_idx, -1).astype(np.int32)
     valid = np.arange(n)[None, :] < lengths[:, None]
     keep = valid & (tags != x_idx) if x_idx is not None else valid
     clens = keep.sum(axis=1).astype(np.int32)
@@ -55,7 +57,7 @@ def assemble(input_ids, attention_mask, first_idx, tags, lengths, x_idx, pad_id=
         crow[b, :len(k)] = row_idx[b, k]
         ctags[b, :len(k)] = tags[b, k]
         cpos[b, :len(k)] = k
-    return dict(B=B, S=S, ids=ids_f, pos_ids=pos_f, maskbias=maskbias, row_idx=row_idx.reshape(-1), lengths=lengths.astype(np.int32),
+    return dict(B=B, R=R, S=S, ids=ids_f, pos_ids=pos_f, maskbias=maskbias, row_idx=row_idx.reshape(-1), lengths=lengths.astype(np.int32),
                 tags=tags.astype(np.int32), keep=keep, crow_idx=crow.reshape(-1), ctags=ctags, clens=clens,
                 cpos=cpos.reshape(-1), n_tokens=n,
                 input_ids=ids, attention_mask=am, first_idx=first_idx)
@@ -65,7 +67,7 @@ _DEVICE_KEYS = ("ids", "pos_ids", "maskbias", "row_idx", "lengths", "tags", "cro
 
 
 def to_device(batch, device="cuda"):
-    out = {"B": batch["B"], "S": batch["S"], "n_tokens": batch["n_tokens"]}
+    out = {"B": batch["B"], "R": batch.get("R", batch["B"]), "S": batch["S"], "n_tokens": batch["n_tokens"]}
     for k in _DEVICE_KEYS:
         out[k] = torch.from_numpy(np.ascontiguousarray(batch[k])).to(device)
     return out

@@ -421,7 +421,8 @@ class Tagger:
         sequence_tagger_model.py:2499-2506) and, if `backward`, the full backward pass accumulating
         loss_scale * d loss into arena.g.  Returns the loss as a 0-d device tensor (no host sync)."""
         B, S = batch["B"], batch["S"]
-        hidden = self.encoder_forward(batch["ids"], batch["pos_ids"], batch["maskbias"], B, S)
+        R = batch.get("R", B)  # encoder rows (> B when long sentences were split into sliding windows)
+        hidden = self.encoder_forward(batch["ids"], batch["pos_ids"], batch["maskbias"], R, S)
         nc = batch["ctags"].shape[1]
         crow_idx = batch["crow_idx"]
         if self.training and self.word_dropout > 0.0 and "cpos" in batch:
@@ -445,7 +446,7 @@ class Tagger:
                                     a.grad("transitions"))
             dpooled = ops.head_bwd(demit.view(B * nc, self.T), pooled, a.param("linear.weight"), a.grad("linear.weight"),
                                    a.grad("linear.bias"))
-            ac = self.acts(B, S)
+            ac = self.acts(R, S)
             ac.dx.zero_()
             ops.scatter_rows(dpooled, crow_idx, ac.dx)
             self.encoder_backward(ac.dx)
@@ -454,7 +455,7 @@ class Tagger:
     def forward_features(self, batch):
         """FastSequenceTagger.forward (sequence_tagger_model.py:844): emissions for ALL word tokens."""
         B, S = batch["B"], batch["S"]
-        hidden = self.encoder_forward(batch["ids"], batch["pos_ids"], batch["maskbias"], B, S)
+        hidden = self.encoder_forward(batch["ids"], batch["pos_ids"], batch["maskbias"], batch.get("R", B), S)
         n = batch["row_idx"].numel() // B
         em, _ = self.emissions(hidden, batch["row_idx"], B, n)
         return em

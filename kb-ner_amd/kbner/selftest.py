@@ -399,6 +399,78 @@ def check_step(dropout=False, H=128, A=2, F_=256):
     return res
 
 
+def check_windows(W=64, stride=32, n_content=150, H=128, A=2, F_=256, V=512, T=29, seed=11):
+    """A sentence longer than one window (flair/embeddings.py:3203-3227,3292-3299) next to a short one: the HIP path
+    gathers each word token from (window row, position); the oracle STITCHES the window states with the reference's seam
+    rule and walks the concatenation.  Both must agree on loss / emissions."""
+    from oracle import encoder as oenc
+    from oracle import train_step as ots
+    rng = np.random.default_rng(seed)
+    cfg = engine.EncoderConfig(vocab_size=V, hidden_size=H, num_hidden_layers=2, num_attention_heads=A, intermediate_size=F_,
+                               max_position_embeddings=W + 2)
+    start, stop, x_idx = 27, 28, 9
+    tg = engine.Tagger(cfg, T, start, stop, device=DEV)
+    tg.init_random(seed=seed, std=0.08)
+    Wc = W - 2
+    content = rng.integers(5, V, size=n_content)
+    starts = [0]
+    while starts[-1] + Wc < n_content:
+        starts.append(starts[-1] + Wc - stride)
+    rows = [[0] + list(content[lo:lo + Wc]) + [2] for lo in starts]
+    short = [0] + list(rng.integers(5, V, size=20)) + [2]
+    all_rows = [short] + rows
+    S0 = max(len(r) for r in all_rows)
+    ids = np.zeros((len(all_rows), S0), np.int64)
+    am = np.zeros_like(ids)
+    for i, r in enumerate(all_rows):
+        ids[i, :len(r)], am[i, :len(r)] = r, 1
+    # word tokens: every 1-3 sub-tokens; positions in CONTENT coordinates
+    def words(n):
+        f, g = [], 0
+        while g < n:
+            f.append(g)
+            g += int(rng.choice([1, 2, 3], p=[0.6, 0.3, 0.1]))
+        return f
+    f_short, f_long = words(20), words(n_content)
+    n = max(len(f_short), len(f_long))
+    first = np.full((2, n), -1, np.int64)
+    frow = np.zeros((2, n), np.int64)
+    first[0, :len(f_short)] = np.asarray(f_short) + 1
+    half = stride // 2
+    for k, g in enumerate(f_long):
+        for w, lo in enumerate(starts):
+            if w == len(starts) - 1 or g < lo + Wc - half:
+                frow[1, k], first[1, k] = 1 + w, g - lo + 1
+                break
+    lengths = np.asarray([len(f_short), len(f_long)])
+    tags = rng.integers(1, 9, size=(2, n))
+    b = kb.assemble(ids, am, first, tags, lengths, x_idx, first_row=frow)
+    bd = kb.to_device(b, DEV)
+    loss = tg.forward_loss(bd, backward=False)
+    em = tg.forward_features(bd)
+    torch.cuda.synchronize()
+    # oracle: per-row encoder, reference stitching, first sub-token by walking the stitched sequence
+    ocfg = oenc.EncoderConfig(vocab_size=V, hidden_size=H, num_hidden_layers=2, num_attention_heads=A, intermediate_size=F_,
+                              max_position_embeddings=W + 2)
+    params = oracle_params(tg)
+    with torch.no_grad():
+        hid = oenc.encoder_forward(params, ocfg, torch.from_numpy(b["input_ids"]), torch.from_numpy(b["attention_mask"]))
+        stitched = oenc.stitch_windows([hid[1 + w, :len(rows[w])] for w in range(len(rows))], stride)
+        assert stitched.shape[0] == n_content + 2
+        pooled = torch.zeros(2, n, H)
+        pooled[0, :len(f_short)] = hid[0, torch.as_tensor(f_short) + 1]
+        pooled[1, :len(f_long)] = stitched[torch.as_tensor(f_long) + 1]
+        oem = torch.nn.functional.linear(pooled, params["linear.weight"], params["linear.bias"])
+        ob = dict(input_ids=torch.from_numpy(b["input_ids"]), attention_mask=torch.from_numpy(b["attention_mask"]),
+                  first_idx=torch.from_numpy(first), first_row=torch.from_numpy(frow), tags=torch.from_numpy(tags.astype(np.int64)),
+                  lengths=torch.from_numpy(lengths.astype(np.int64)))
+        oloss, oem2 = ots.tagger_forward_loss(params, ocfg, ob, start, stop, x_idx)
+    valid = torch.from_numpy(first >= 0)
+    return {"windows": len(rows), "emissions_rel": rel_l2(em.cpu()[valid], oem[valid]),
+            "oracle_gather_vs_stitch": rel_l2(oem2[valid], oem[valid]),
+            "loss_rel": abs(float(loss) - float(oloss)) / abs(float(oloss))}
+
+
 def check_adamw(n=4096 + 64, seed=0):
     from oracle import optim as oopt
     rng = np.random.default_rng(seed)

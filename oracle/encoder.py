@@ -148,12 +148,25 @@ def encoder_forward(params, cfg, input_ids, attention_mask, return_all=False, ma
     return x
 
 
-def gather_first_subtoken(hidden, first_idx):
+def stitch_windows(window_states, stride):
+    """Seam rule for a sentence encoded as several overlapping windows (flair/embeddings.py:3292-3299): drop the last
+    1 + stride//2 positions of the states accumulated so far (</s> + half the overlap) and the first 1 + stride//2 of
+    the next window (<s> + the other half), concatenate.  window_states: list of f32[S_w,H] (real positions only)."""
+    acc = window_states[0]
+    for nxt in window_states[1:]:
+        acc = torch.cat((acc[:-1 - stride // 2], nxt[1 + stride // 2:]), 0)
+    return acc
+
+
+def gather_first_subtoken(hidden, first_idx, first_row=None):
     """first-subtoken pooling (flair/embeddings.py:3288-3345 with pooling_operation 'first') +
-    assign_batch_features zero padding (:108-124).  hidden f32[B,S,H]; first_idx int64[B,n] holds
+    assign_batch_features zero padding (:108-124).  hidden f32[R,S,H]; first_idx int64[B,n] holds
     the subtoken position of each word token's first piece, or -1 for padding / tokens with zero
-    subtokens (-> zero vector, :3306-3308).  Returns f32[B,n,H]."""
-    B, S, H = hidden.shape
-    idx = first_idx.clamp(min=0)
-    out = torch.gather(hidden, 1, idx[:, :, None].expand(-1, -1, H))
+    subtokens (-> zero vector, :3306-3308); first_row int64[B,n] the encoder row it lives in (default b:
+    one row per sentence; differs when long sentences were split into windows).  Returns f32[B,n,H]."""
+    R, S, H = hidden.shape
+    B = first_idx.shape[0]
+    rows = torch.arange(B)[:, None] if first_row is None else first_row
+    flat = (rows * S + first_idx.clamp(min=0)).reshape(-1)
+    out = hidden.reshape(R * S, H)[flat].reshape(B, -1, H)
     return out * (first_idx >= 0).to(hidden.dtype)[:, :, None]

@@ -49,7 +49,7 @@ def tagger_forward_loss(params, cfg, batch, start, stop, x_idx, masks=None, word
     masks: explicit encoder dropout multipliers (encoder_forward); word_keep: bool[n], flair.nn.WordDropout's per-POSITION
     mask (flair/nn.py:176-183: one Bernoulli per token position shared by the whole batch, no rescale)."""
     hidden = enc.encoder_forward(params, cfg, batch["input_ids"], batch["attention_mask"], masks=masks)
-    pooled = enc.gather_first_subtoken(hidden, batch["first_idx"])
+    pooled = enc.gather_first_subtoken(hidden, batch["first_idx"], batch.get("first_row"))
     if word_keep is not None:
         pooled = pooled * word_keep.to(pooled.dtype)[None, :, None]
     emis = F.linear(pooled, params["linear.weight"], params["linear.bias"])

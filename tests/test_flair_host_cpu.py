@@ -4,6 +4,7 @@ tests/test_utils.py:41-94 Metric) and golden vectors captured from the reference
 import json
 import os
 
+import numpy as np
 import pytest
 
 from flair.data import Dictionary, Label, Sentence, iob2, iob_iobes
@@ -140,13 +141,58 @@ def test_eos_token_and_first_subtoken_index(tmp_path):
     d = tiny_assets.build_model_dir(str(tmp_path / "m"))
     emb = TransformerWordEmbeddings(model=d, layers="-1", pooling_operation="first", fine_tune=True)
     s = Sentence("alice visited berlin <EOS> the museum")
-    ids, first = emb.tokenize_sentence(s)
+    rows, first_row, first = emb.tokenize_sentence(s)
+    assert len(rows) == 1 and set(first_row) == {0}          # fits one window
+    ids = rows[0]
     assert ids[0] == 0 and ids[-1] == 2                      # <s> ... </s>
     assert ids.count(2) == 2                                 # the <EOS> word token became the tokenizer's eos id
     assert first[0] == 1 and all(b > a for a, b in zip(first, first[1:]))
-    ids_np, am, fi, lengths = emb.prepare_batch([s, Sentence("bob")])
+    ids_np, am, fi, lengths, frow = emb.prepare_batch([s, Sentence("bob")])
     assert ids_np.shape == am.shape and am[1].sum() < am[0].sum() and ids_np[1, am[1].sum():].sum() == 0   # padded with 0
     assert fi.shape == (2, 6) and list(lengths) == [6, 1] and (fi[1, 1:] == -1).all()
+    assert (frow[0] == 0).all() and frow[1, 0] == 1
+
+
+@pytest.mark.parametrize("n_words", [40, 75, 140, 260])
+def test_sliding_window_matches_reference_stitching(tmp_path, n_words):
+    """Sentences longer than one window: the (row, position) our batch gathers each word token's first sub-token from must
+    be the element the reference reaches by concatenating window states with its seam rule
+    (flair/embeddings.py:3292-3299: acc[:-1-stride//2] ++ next[1+stride//2:]) and walking sub-token counts from offset 1."""
+    import tiny_assets
+    from flair.embeddings import TransformerWordEmbeddings
+    d = tiny_assets.build_model_dir(str(tmp_path / "m"))
+    emb = TransformerWordEmbeddings(model=d, layers="-1", pooling_operation="first", fine_tune=True)
+    emb.max_subtokens_sequence_length, emb.stride = 64, 32          # small windows keep the test fast; same arithmetic
+    rng = np.random.default_rng(n_words)
+    words = [str(w) for w in rng.choice(tiny_assets.WORDS, size=n_words)]
+    s = Sentence(" ".join(words))
+    rows, first_row, first = emb.tokenize_sentence(s)
+    pieces = emb.tokenizer.tokenize(" ".join(words))
+    counts = emb.reconstruct_tokens_from_subtokens(list(s), pieces)
+    content = emb.tokenizer.convert_tokens_to_ids(pieces)
+    W, st = 62, 32
+    # the windows encode_plus(max_length=64, stride=32, return_overflowing_tokens=True) yields, re-fed with its overflow
+    exp_rows, rest = [], list(content)
+    while rest:
+        exp_rows.append([0] + rest[:W] + [2])
+        rest = rest[W - st:] if len(rest) > W else None
+    assert rows == exp_rows
+    assert len(rows) > 1 or len(content) <= W
+    # reference stitching on "hidden states" that name their own (row, position)
+    acc = [(0, p) for p in range(len(rows[0]))]
+    for r in range(1, len(rows)):
+        acc = acc[:-1 - st // 2] + [(r, p) for p in range(len(rows[r]))][1 + st // 2:]
+    assert len(acc) == len(content) + 2                              # the seams neither drop nor duplicate a sub-token
+    start = 1
+    for k, c in enumerate(counts):
+        if c == 0:
+            assert first[k] == -1
+            continue
+        assert (first_row[k], first[k]) == acc[start], (k, first_row[k], first[k], acc[start])
+        assert rows[first_row[k]][first[k]] == content[start - 1]     # and that element really is the token's first piece
+        start += c
+    ids_np, am, fi, lengths, frow = emb.prepare_batch([Sentence("bob"), s])
+    assert ids_np.shape[0] == 1 + len(rows) and (frow[1, :len(s)] >= 1).all() and frow[0, 0] == 0
 
 
 def test_column_corpus_and_loader(tmp_path):
@@ -174,3 +220,42 @@ def test_column_corpus_and_loader(tmp_path):
     order = [id(b) for b in loader.data]
     loader.reshuffle()
     assert sorted(order) == sorted(id(b) for b in loader.data)            # batch membership fixed, only order changes
+
+
+def test_context_file_format_writer_validator_and_reader(tmp_path):
+    """write a knowledge-augmented CoNLL file with the reference's convention and budget rule, validate it,
+    and read it back through ColumnCorpus (context B-X -> S-X, comment lines skipped)."""
+    import tiny_assets
+    from flair.datasets import ColumnCorpus
+    from kbner import context_format as cf
+    tok = tiny_assets.build_tokenizer_dir(str(tmp_path / "tok"))
+    count = lambda text: len(tok.tokenize(text))  # noqa: E731
+    rng = np.random.default_rng(0)
+    sents = []
+    for i in range(12):
+        words = [str(w) for w in rng.choice(tiny_assets.WORDS, size=int(rng.integers(3, 9)))]
+        ner = ["O"] * len(words)
+        ner[0] = "B-LOC"
+        ctx = [" ".join(str(w) for w in rng.choice(tiny_assets.WORDS, size=int(rng.integers(5, 60)))) for _ in range(int(rng.integers(0, 6)))]
+        sents.append(dict(id="s%d" % i, tokens=[(w, "_", "_", t) for w, t in zip(words, ner)], contexts=ctx))
+    folder = tmp_path / "c"
+    folder.mkdir()
+    for name in ("train.txt", "dev.txt", "test.txt"):
+        cf.write_file(str(folder / name), sents, count, length_limit=64)
+    st = cf.validate_file(str(folder / "train.txt"), count, length_limit=64)
+    assert st["sentences"] == 12 and st["over_budget"] == 0 and 0 < st["max_subtokens"] <= 64
+    assert 0 < st["with_context"] < 12                      # sentences without retrievals carry no <EOS>
+    # budget rule: a context that does not fit is skipped, a later shorter one may still be taken
+    used = cf.select_contexts(10, ["a " * 30, "b c", "d " * 40, "e"], lambda t: len(t.split()), length_limit=24)
+    assert used == ["b c", "e"]
+    corpus = ColumnCorpus(str(folder), {0: "text", 1: "pos", 2: "upos", 3: "ner"}, tag_to_bioes="ner", comment_symbol="# id")
+    assert len(corpus.train) == 12
+    for s in corpus.train:
+        texts = [t.text for t in s]
+        if "<EOS>" in texts:
+            k = texts.index("<EOS>")
+            assert all(t.get_tag("ner").value == "S-X" for t in s.tokens[k:])
+    bad = folder / "bad.txt"
+    bad.write_text("berlin _ _ B-LOC\n<EOS> B-X B-X B-X\nfoo _ _ O\n\n")
+    with pytest.raises(cf.FormatError):
+        cf.validate_file(str(bad))

@@ -241,3 +241,12 @@ def test_full_step_with_dropout_vs_oracle(st, H, A, F_):
     assert r["emissions_rel"] < 3e-2, r
     assert r["grad_min_cos"] > 0.97 and r["grad_worst_rel"] < 0.2, r
     assert r["grad_linear.weight"] < 5e-2 and r["grad_transitions"] < 5e-2, r
+
+
+@pytest.mark.parametrize("n_content", [100, 150, 230])
+def test_sliding_window_sentence_vs_oracle_stitching(st, n_content):
+    """a sentence longer than one encoder window: (row, position) gather == the reference's stitched-states indexing"""
+    r = st.check_windows(n_content=n_content)
+    assert r["windows"] >= 2, r
+    assert r["oracle_gather_vs_stitch"] < 1e-6, r      # index arithmetic: exact
+    assert r["emissions_rel"] < 3e-2 and r["loss_rel"] < 3e-2, r
