@@ -45,6 +45,12 @@ int kbner_crf_nll_bwd(const float* emit, const float* trans, const int* tags, co
                       const float* logz, const float* dloss, int B, int n, int T, int start, int stop, float* demit,
                       float* dtrans, void* stream);
 
+/* token marginals p_i(t) = softmax_t(alpha_i + beta_i): the predict_posterior branch of _obtain_labels (:1182-1192 =
+ * _forward_alg(distill_mode=True) :1329 + _backward_alg :1396-1470).  alpha / logz come from kbner_crf_nll_fwd (its tags
+ * argument may be all zeros).  marg f32[B,n,T], rows at or past lens[b] are zero-filled. */
+int kbner_crf_posterior(const float* emit, const float* trans, const int* lens, const float* alpha, const float* logz, int B,
+                        int n, int T, int start, int stop, float* marg, void* stream);
+
 /* ---------------- row moves: pooling, compaction, emission head ---------------- */
 /* first-subtoken pooling + assign_batch_features (flair/embeddings.py:3288-3345,108-124) and the remove_x
  * compaction loop (sequence_tagger_model.py:2474-2488) as ONE gather: out[r] = idx[r] >= 0 ? src[idx[r]] : 0 */

@@ -157,6 +157,10 @@ __global__ __launch_bounds__(64) void crf_nll_fwd_kernel(const float* __restrict
 // ------------------------------------------------------------------------------------------
 // NLL backward: d/d emit and d/d trans of sum_b dloss[b] * (logZ_b - gold_b)
 // ------------------------------------------------------------------------------------------
+// POSTERIOR = true reuses the same beta scan to emit the token marginals p_i(t) = softmax_t(alpha_i[t] + beta_i[t]) instead of
+// gradients (SequenceTagger._obtain_labels' predict_posterior branch, sequence_tagger_model.py:1182-1192, which adds
+// _forward_alg(distill_mode=True) and _backward_alg :1396-1470): demit receives the marginals, tags / dloss / dtrans are unused.
+template <bool POSTERIOR>
 __global__ __launch_bounds__(64) void crf_nll_bwd_kernel(const float* __restrict__ emit, const float* __restrict__ trans,
                                                          const int* __restrict__ tags, const int* __restrict__ lens,
                                                          const float* __restrict__ alpha, const float* __restrict__ logz,
@@ -172,7 +176,7 @@ __global__ __launch_bounds__(64) void crf_nll_bwd_kernel(const float* __restrict
   const int b = blockIdx.x;
   const int t = threadIdx.x;
   const int L = lens[b];
-  const float w = dloss[b];
+  const float w = POSTERIOR ? 1.0f : dloss[b];
   const float lz = logz[b];
   for (int i = t; i < T * T; i += 64) sT[(i / T) * TP + (i % T)] = trans[i];
   for (int i = t; i < T * TP; i += 64) sD[i] = 0.0f;
@@ -180,7 +184,7 @@ __global__ __launch_bounds__(64) void crf_nll_bwd_kernel(const float* __restrict
   const float* e = emit + (size_t)b * n * T;
   const float* al = alpha + (size_t)b * (n + 1) * T;
   float* de = demit + (size_t)b * n * T;
-  const int* tg = tags + (size_t)b * n;
+  const int* tg = POSTERIOR ? nullptr : tags + (size_t)b * n;
   for (int i = L * T + t; i < n * T; i += 64) de[i] = 0.0f;
   // beta_L = trans[STOP,:]; terminal marginal into d trans[STOP,:]
   if (t < T) {
@@ -204,9 +208,9 @@ __global__ __launch_bounds__(64) void crf_nll_bwd_kernel(const float* __restrict
       for (int f = 0; f < T; ++f) {
         const float p = expf(base + row[f] + sa[f]);
         rs += p;
-        drow[f] += w * p;
+        if (!POSTERIOR) drow[f] += w * p;
       }
-      de[(size_t)i * T + t] = w * rs - ((tg[i] == t) ? w : 0.0f);
+      de[(size_t)i * T + t] = POSTERIOR ? rs : w * rs - ((tg[i] == t) ? w : 0.0f);
       // role "from" = t: beta_i[t] = lse_to(emit[to] + trans[to,t] + beta_{i+1}[to])
       float m = -INFINITY;
       for (int u = 0; u < T; ++u) m = fmaxf(m, se[u] + sT[u * TP + t] + sb[u]);
@@ -218,6 +222,7 @@ __global__ __launch_bounds__(64) void crf_nll_bwd_kernel(const float* __restrict
     if (t < T) sb[t] = nb;
     __syncthreads();
   }
+  if (POSTERIOR) return;
   // gold path: -w on each used transition
   if (t == 0) {
     int prev = start;
@@ -277,8 +282,20 @@ int kbner_crf_nll_bwd(const float* emit, const float* trans, const int* tags, co
   KBNER_CHECK_ARG(start >= 0 && start < T && stop >= 0 && stop < T);
   if (B == 0) return 0;
   const size_t lds = (size_t)(2 * T * (T | 1) + 3 * 64) * 4;
-  hipLaunchKernelGGL(crf_nll_bwd_kernel, dim3(B), dim3(64), lds, (hipStream_t)stream, emit, trans, tags, lens, alpha, logz,
+  hipLaunchKernelGGL(crf_nll_bwd_kernel<false>, dim3(B), dim3(64), lds, (hipStream_t)stream, emit, trans, tags, lens, alpha, logz,
                      dloss, n, T, start, stop, demit, dtrans);
+  KBNER_LAUNCH_RET();
+}
+
+// token marginals from the alpha / logZ that kbner_crf_nll_fwd saved: marg f32[B,n,T] (rows >= lens[b] are zero)
+int kbner_crf_posterior(const float* emit, const float* trans, const int* lens, const float* alpha, const float* logz, int B,
+                        int n, int T, int start, int stop, float* marg, void* stream) {
+  KBNER_CHECK_ARG(B >= 0 && n >= 0 && T > 0 && T <= CRF_MAXT);
+  KBNER_CHECK_ARG(start >= 0 && start < T && stop >= 0 && stop < T);
+  if (B == 0) return 0;
+  const size_t lds = (size_t)(2 * T * (T | 1) + 3 * 64) * 4;
+  hipLaunchKernelGGL(crf_nll_bwd_kernel<true>, dim3(B), dim3(64), lds, (hipStream_t)stream, emit, trans, (const int*)nullptr, lens,
+                     alpha, logz, (const float*)nullptr, n, T, start, stop, marg, (float*)nullptr);
   KBNER_LAUNCH_RET();
 }
 

@@ -27,7 +27,7 @@ START_TAG: str = "<START>"
 STOP_TAG: str = "<STOP>"
 
 _UNSUPPORTED_TRUE = ("use_mfvi", "use_rnn", "use_cnn", "distill_crf", "crf_attention", "biaf_attention", "use_language_attention",
-                     "distill_posterior", "posterior_constraint", "predict_posterior", "enhanced_crf", "use_transition_attention",
+                     "distill_posterior", "posterior_constraint", "enhanced_crf", "use_transition_attention",
                      "relearn_embeddings", "map_embeddings", "embedding_selector", "use_rl", "multi_view_training")
 
 
@@ -57,6 +57,7 @@ class SequenceTagger(flair.nn.Model):
         self.remove_x = remove_x
         self.use_word_dropout = word_dropout  # flair.nn.WordDropout on the token features while training (engine.word_dropout)
         self.use_dropout, self.use_locked_dropout = 0.0, 0.0
+        self.predict_posterior = bool(kwargs.get("predict_posterior", False))  # marginal (forward-backward) decoding
         self.config = config
         self.target_languages = target_languages
         self.use_decoder_timer = use_decoder_timer
@@ -217,6 +218,23 @@ class SequenceTagger(flair.nn.Model):
         from kbner import ops
         B, n, T = feature.shape
         keep = self.mask.bool().cpu().numpy() if self.mask is not None else np.ones((B, n), bool)
+        if getattr(self, "predict_posterior", False):
+            # :1182-1192,1212-1218: marginals softmax(alpha + beta) over the WHOLE token sequence (no S-X compaction);
+            # positions self.mask zeroes get the all-zero score row, i.e. a uniform distribution and tag index 0
+            full = torch.tensor([len(s) for s in sentences], dtype=torch.int32, device=feature.device)
+            marg = ops.crf_posterior(feature.contiguous(), self.engine.arena.param("transitions"), full, self.start_idx,
+                                     self.stop_idx).cpu().numpy()
+            out = []
+            for b, s in enumerate(sentences):
+                row = []
+                for i in range(len(s)):
+                    if keep[b, i]:
+                        k = int(marg[b, i].argmax())
+                        row.append(Label(self.tag_dictionary.get_item_for_index(k), float(marg[b, i, k])))
+                    else:
+                        row.append(Label(self.tag_dictionary.get_item_for_index(0), 1.0 / T))
+                out.append(row)
+            return out, []
         lens = keep.sum(1).astype(np.int32)
         nc = max(1, int(lens.max()))
         idx = torch.from_numpy(_compact_index(keep, nc)).to(feature.device)

@@ -69,6 +69,18 @@ def crf_nll_bwd(emit, trans, tags, lens, alpha, logz, dloss, start, stop, dtrans
     return demit
 
 
+def crf_posterior(emit, trans, lens, start, stop):
+    """token marginals f32[B,n,T] (zero rows past lens) -- _obtain_labels' predict_posterior branch"""
+    _chk(emit, F32, "emit"); _chk(trans, F32, "trans"); _chk(lens, I32, "lens")
+    B, n, T = emit.shape
+    zeros = torch.zeros((B, n), dtype=I32, device=emit.device)
+    logz, _, alpha = crf_nll_fwd(emit, trans, zeros, lens, start, stop)
+    marg = torch.empty_like(emit)
+    L.call("kbner_crf_posterior", ptr(emit), ptr(trans), ptr(lens), ptr(alpha), ptr(logz), B, n, T, start, stop, ptr(marg),
+           stream_ptr())
+    return marg
+
+
 # ---------------------------------------------------------------- rows / head
 def gather_rows(src, idx, out=None):
     _chk(src, BF16, "src"); _chk(idx, I32, "idx")

@@ -81,6 +81,39 @@ def test_yaml_to_trained_model(workdir):
     w0 = nxt.model.state_dict()["encoder.layer.0.output.dense.weight"]
     w1 = student.engine.hf_state_dict()["encoder.layer.0.output.dense.weight"].cpu()
     assert torch.allclose(w0, w1)
+    # posterior (forward-backward marginal) decoding: same API, per-token probabilities in (0, 1]
+    student.predict_posterior = True
+    try:
+        batch = dl[0]
+        feats = student.forward(batch)
+        labels, _ = student._obtain_labels(feats, batch)
+        assert [len(x) for x in labels] == [len(sn) for sn in batch]
+        assert all(0.0 < lab.score <= 1.0 for row in labels for lab in row)
+    finally:
+        student.predict_posterior = False
+    # a test sentence longer than one encoder window goes through the sliding-window path (dev/test files are written
+    # with max_len=999 by kb/context_process.py:999-1000): same tags for the real tokens as with one big window
+    emb = student.embeddings.embeddings[0] if hasattr(student.embeddings, "embeddings") else student.embeddings
+    from flair.data import Sentence
+    import tiny_assets
+    rng = np.random.default_rng(5)
+    long_s = Sentence("alice visited berlin <EOS> " + " ".join(str(w) for w in rng.choice(tiny_assets.WORDS, size=150)))
+    for t in long_s:
+        t.add_tag("ner", "O")
+    old = (emb.max_subtokens_sequence_length, emb.stride)
+    try:
+        student.eval()
+        f_one = student.forward([long_s]).clone()
+        emb.max_subtokens_sequence_length, emb.stride = 128, 64
+        rows, frow, _ = emb.tokenize_sentence(long_s)
+        assert len(rows) >= 2 and max(frow) == len(rows) - 1
+        f_win = student.forward([long_s])
+        assert f_win.shape == f_one.shape
+        assert torch.isfinite(f_win).all()
+        labels, _ = student._obtain_labels(f_win, [long_s])
+        assert len(labels[0]) == len(long_s)
+    finally:
+        emb.max_subtokens_sequence_length, emb.stride = old
 
 
 def test_full_size_invariants():

@@ -250,3 +250,20 @@ def test_sliding_window_sentence_vs_oracle_stitching(st, n_content):
     assert r["windows"] >= 2, r
     assert r["oracle_gather_vs_stitch"] < 1e-6, r      # index arithmetic: exact
     assert r["emissions_rel"] < 3e-2 and r["loss_rel"] < 3e-2, r
+
+
+def test_crf_posterior_vs_reference_golden(st, golden_dir):
+    """kbner_crf_posterior (token marginals from alpha+beta) against the reference's own predict_posterior vectors"""
+    import torch
+    from kbner import ops
+    g = np.load(os.path.join(golden_dir, "posterior.npz"))
+    trans, start, stop = torch.from_numpy(g["trans"]).cuda(), int(g["start"]), int(g["stop"])
+    for c in range(int(g["n_cases"])):
+        feats, lens = g["c%d_feats" % c], g["c%d_lens" % c]
+        n = feats.shape[1]
+        valid = np.arange(n)[None, :] < lens[:, None]
+        marg = ops.crf_posterior(torch.from_numpy(feats).cuda(), trans, torch.from_numpy(lens.astype(np.int32)).cuda(), start, stop)
+        marg = marg.cpu().numpy()
+        assert np.abs(marg[valid] - g["c%d_dist" % c][valid]).max() < 5e-5
+        assert np.array_equal(marg.argmax(-1)[valid], g["c%d_idx" % c][valid])   # posterior-decoded tags: identical
+        assert np.abs(marg[valid].sum(-1) - 1.0).max() < 1e-4 and not marg[~valid].any()
