@@ -159,3 +159,46 @@ def test_full_size_invariants():
     ops.gemm(0, (x.float() * 2).to(torch.bfloat16), w, M, 4096, H, C=y2)
     torch.cuda.synchronize()
     assert float((y2.float() - 2 * y1.float()).abs().max()) <= 2e-2 * float(y1.float().abs().max())
+
+
+def _run_bench(extra_env, launcher, args):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.update(extra_env)
+    cmd = [sys.executable] + launcher + [os.path.join(root, "bench.py")] + args
+    r = subprocess.run(cmd, cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode(errors="replace")[-2000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines            # exactly ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_contract_single_gpu():
+    """bench.py's CLI / JSON contract on a small configuration (base model, 2 sentences): keys, types, roofline + cpu_baseline"""
+    d = _run_bench({}, [], ["--gpus", "1", "--steps", "2", "--warmup", "1", "--model", "base", "--micro-batch", "2", "--accum", "2",
+                            "--cpu-sentences", "1"])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["unit"] == "sentences/sec" and d["value"] > 0
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["higher_is_better"] is True and d["data"] == "synthetic"
+    assert abs(d["value"] - 4 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-2       # value = global batch / step time
+    rf = d["roofline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and "sample" in cb
+
+
+def test_bench_two_ranks_one_gpu_functional():
+    """the N>1 launch line of the contract (torch.distributed.run, one process per rank) on the single GPU of this box, with
+    the gloo escape hatch for the gradient all-reduce: rendezvous, per-rank shards, max-over-ranks timing, rank-0 JSON"""
+    d = _run_bench({"KBNER_DIST_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0"},
+                   ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                    "--master-port", "29531"],
+                   ["--gpus", "2", "--steps", "2", "--warmup", "1", "--model", "base", "--micro-batch", "2", "--accum", "1",
+                    "--no-roofline"])
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 4 and d["value"] > 0
+    assert "cpu_baseline" not in d           # rank 0 at N=1 only
