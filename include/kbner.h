@@ -133,9 +133,10 @@ int kbner_gemm_bf16_grouped(int layout, int nprob, const kbner_gemm_problem* pro
 /* drop_*: attention-probability dropout, element (i,j) = (bh*S + query, bh*S + key) with bh = b*A + head */
 int kbner_attn_fwd(const kbner_bf16* qkv, const float* maskbias, kbner_bf16* ctx, float* lse, int B, int S, int H, int A,
                    uint32_t drop_seed, uint32_t drop_thresh, void* stream);
+/* dbias_qkv f32[3H] (nullable): += column sums of dqkv, i.e. the fused QKV projection's bias gradient */
 int kbner_attn_bwd(const kbner_bf16* qkv, const kbner_bf16* ctx, const kbner_bf16* dctx, const float* maskbias,
                    const float* lse, float* Dws, kbner_bf16* dqkv, int B, int S, int H, int A, uint32_t drop_seed,
-                   uint32_t drop_thresh, void* stream);
+                   uint32_t drop_thresh, float* dbias_qkv, void* stream);
 
 /* ---------------- optimiser (transformers==3.0.0 AdamW + clip_grad_norm_, finetune_trainer.py:1010,1018) ------------- */
 int kbner_sqnorm_ws_floats(void);

@@ -304,6 +304,33 @@ __global__ __launch_bounds__(256) void attn_rowdot_kernel(const bf16_t* __restri
   D[((size_t)b * A + h) * S + s] = acc;
 }
 
+// Column sums of a [16 rows x 64 cols] output fragment set accumulated over a workgroup's passes: the bias gradient of the
+// fused QKV projection (d qkv.bias = column sums of dQ | dK | dV), so no separate pass re-reads the 3H-wide dqkv.
+// acc[db][r] is this lane's running sum for column db*16 + g*4 + r (rows li); reduce over li, over the 8 waves, one atomic
+// per column per workgroup.
+static __device__ __forceinline__ void flush_colsum(f4v (&acc)[4], float (*red)[64], float* __restrict__ out, int wid, int lane,
+                                                    int tid) {
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float x = acc[db][r];
+      x += __shfl_xor(x, 1, 64);
+      x += __shfl_xor(x, 2, 64);
+      x += __shfl_xor(x, 4, 64);
+      x += __shfl_xor(x, 8, 64);
+      if ((lane & 15) == 0) red[wid][db * 16 + (lane >> 4) * 4 + r] = x;
+    }
+  __syncthreads();
+  if (tid < 64) {
+    float t = 0.0f;
+#pragma unroll
+    for (int w = 0; w < AT_NW; ++w) t += red[w][tid];
+    atomicAdd(out + tid, t);
+  }
+  __syncthreads();
+}
+
 // ------------------------------------------------------------------------------------------
 // backward: dQ   (owner = query rows; panels K, V)
 // ------------------------------------------------------------------------------------------
@@ -314,8 +341,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(const bf16_t* __res
                                                              const float* __restrict__ maskbias, const float* __restrict__ lse,
                                                              const float* __restrict__ Dv, bf16_t* __restrict__ dqkv, int S,
                                                              int H, int A, float scale, int rpw, uint32_t drop_seed,
-                                                             uint32_t drop_thresh) {
+                                                             uint32_t drop_thresh, float* __restrict__ dbias) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ float red[AT_NW][64];
   unsigned char* sK = smem;
   unsigned char* sV = smem + AT_MAXS * 128;
   float* sMask = reinterpret_cast<float*>(smem + 2 * AT_MAXS * 128);
@@ -327,6 +355,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(const bf16_t* __res
   const bf16_t* base = qkv + (size_t)b * S * ld + h * AT_D;
   const uint32_t bhS = (uint32_t)((b * A + h) * S);
   const float dscale = DROP ? drop_scale(drop_thresh) : 1.0f;
+  f4v bsum[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db) bsum[db] = (f4v){0.f, 0.f, 0.f, 0.f};
   stage_panel(base + H, ld, S, sK, wid, lane);
   stage_panel(base + 2 * H, ld, S, sV, wid, lane);
   for (int i = tid; i < S; i += 512) {
@@ -413,8 +444,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(const bf16_t* __res
       u.x = pack2bf(dq[db][0] * scale, dq[db][1] * scale);
       u.y = pack2bf(dq[db][2] * scale, dq[db][3] * scale);
       *reinterpret_cast<uint2*>(orow + db * 16 + g * 4) = u;
+      bsum[db] += dq[db] * scale;
     }
   }
+  if (dbias != nullptr) flush_colsum(bsum, red, dbias + h * AT_D, wid, lane, tid);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -425,8 +458,12 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
                                                               const float* __restrict__ maskbias, const float* __restrict__ lse,
                                                               const float* __restrict__ Dv, bf16_t* __restrict__ dqkv, int S,
                                                               int H, int A, float scale, int rpw, uint32_t drop_seed,
-                                                              uint32_t drop_thresh) {
+                                                              uint32_t drop_thresh, float* __restrict__ dbias) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ float red[AT_NW][64];
+  f4v bsk[4], bsv[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db) bsk[db] = bsv[db] = (f4v){0.f, 0.f, 0.f, 0.f};
   unsigned char* sQ = smem;
   unsigned char* sO = smem + AT_MAXS * 128;
   float* sL = reinterpret_cast<float*>(smem + 2 * AT_MAXS * 128);
@@ -541,7 +578,13 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
       w.x = pack2bf(dv[db][0], dv[db][1]);
       w.y = pack2bf(dv[db][2], dv[db][3]);
       *reinterpret_cast<uint2*>(vrow + db * 16 + g * 4) = w;
+      bsk[db] += dk[db] * scale;
+      bsv[db] += dv[db];
     }
+  }
+  if (dbias != nullptr) {
+    flush_colsum(bsk, red, dbias + H + h * AT_D, wid, lane, tid);
+    flush_colsum(bsv, red, dbias + 2 * H + h * AT_D, wid, lane, tid);
   }
 }
 
@@ -584,7 +627,7 @@ static int launch_attn_fwd(const bf16_t* qkv, const float* maskbias, bf16_t* ctx
 
 template <bool DROP>
 static int launch_attn_bwd(const bf16_t* qkv, const bf16_t* dctx, const float* maskbias, const float* lse, const float* Dws,
-                           bf16_t* dqkv, int B, int S, int H, int A, uint32_t seed, uint32_t thresh, hipStream_t s) {
+                           bf16_t* dqkv, int B, int S, int H, int A, uint32_t seed, uint32_t thresh, float* dbias, hipStream_t s) {
   static bool once = false;
   if (!once) {
     int r = set_lds(reinterpret_cast<const void*>(attn_bwd_dq_kernel<DROP>), AT_LDS_BYTES);
@@ -596,9 +639,9 @@ static int launch_attn_bwd(const bf16_t* qkv, const bf16_t* dctx, const float* m
   const int rpw = pick_rpw(B, S, A);
   const dim3 grid((S + rpw - 1) / rpw, A, B);
   hipLaunchKernelGGL(attn_bwd_dq_kernel<DROP>, grid, dim3(512), AT_LDS_BYTES, s, qkv, dctx, maskbias, lse, Dws, dqkv, S, H, A,
-                     0.125f, rpw, seed, thresh);
+                     0.125f, rpw, seed, thresh, dbias);
   hipLaunchKernelGGL(attn_bwd_dkv_kernel<DROP>, grid, dim3(512), AT_LDS_BYTES, s, qkv, dctx, maskbias, lse, Dws, dqkv, S, H, A,
-                     0.125f, rpw, seed, thresh);
+                     0.125f, rpw, seed, thresh, dbias);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }
@@ -624,16 +667,17 @@ int kbner_attn_fwd(const bf16_t* qkv, const float* maskbias, bf16_t* ctx, float*
   }
 }
 
-// dctx bf16 [B*S,H] (dO) ; ctx (O) ; lse ; Dws f32 [B,A,S] workspace ; dqkv bf16 [B*S,3H] out
+// dctx bf16 [B*S,H] (dO) ; ctx (O) ; lse ; Dws f32 [B,A,S] workspace ; dqkv bf16 [B*S,3H] out ;
+// dbias_qkv f32 [3H] (nullable): += column sums of dqkv = the QKV projection's bias gradient
 int kbner_attn_bwd(const bf16_t* qkv, const bf16_t* ctx, const bf16_t* dctx, const float* maskbias, const float* lse,
                    float* Dws, bf16_t* dqkv, int B, int S, int H, int A, uint32_t drop_seed, uint32_t drop_thresh,
-                   void* stream) {
+                   float* dbias_qkv, void* stream) {
   KBNER_CHECK_ARG(B > 0 && A > 0 && H == A * AT_D && S % 64 == 0 && S >= 64 && S <= AT_MAXS);
   hipStream_t s = (hipStream_t)stream;
   const int n = B * S * A;
   hipLaunchKernelGGL(attn_rowdot_kernel, dim3((n + 255) / 256), dim3(256), 0, s, dctx, ctx, Dws, B, S, H, A);
-  if (drop_thresh) return launch_attn_bwd<true>(qkv, dctx, maskbias, lse, Dws, dqkv, B, S, H, A, drop_seed, drop_thresh, s);
-  return launch_attn_bwd<false>(qkv, dctx, maskbias, lse, Dws, dqkv, B, S, H, A, drop_seed, drop_thresh, s);
+  if (drop_thresh) return launch_attn_bwd<true>(qkv, dctx, maskbias, lse, Dws, dqkv, B, S, H, A, drop_seed, drop_thresh, dbias_qkv, s);
+  return launch_attn_bwd<false>(qkv, dctx, maskbias, lse, Dws, dqkv, B, S, H, A, drop_seed, drop_thresh, dbias_qkv, s);
 }
 
 }  // extern "C"

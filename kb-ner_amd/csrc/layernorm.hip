@@ -38,6 +38,32 @@ static __device__ __forceinline__ void load_row_bf16(const bf16_t* __restrict__ 
   }
 }
 
+// raw (unconverted) row image: lets the backward kernel fetch row r+stride while it reduces row r
+template <int NCH>
+struct RowRaw {
+  uint4 v[NCH];
+};
+template <int NCH>
+static __device__ __forceinline__ void load_row_raw(const bf16_t* __restrict__ p, int H, int lane, RowRaw<NCH>& r) {
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int h0 = (lane + 64 * c) * 8;
+    r.v[c] = (h0 < H) ? *reinterpret_cast<const uint4*>(p + h0) : make_uint4(0u, 0u, 0u, 0u);
+  }
+}
+template <int NCH>
+static __device__ __forceinline__ void unpack_row(const RowRaw<NCH>& raw, RowF<NCH>& r) {
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const uint32_t w[4] = {raw.v[c].x, raw.v[c].y, raw.v[c].z, raw.v[c].w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      r.v[c][2 * j] = __uint_as_float(w[j] << 16);
+      r.v[c][2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u);
+    }
+  }
+}
+
 template <int NCH>
 static __device__ __forceinline__ void store_row_bf16(bf16_t* __restrict__ p, int H, int lane, const RowF<NCH>& r) {
 #pragma unroll
@@ -219,12 +245,28 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
 #pragma unroll
     for (int j = 0; j < 8; ++j) ag.v[c][j] = ab.v[c][j] = ah.v[c][j] = 0.0f;
   const float invH = 1.0f / (float)H;
+  // one row ahead: the loads of row r + nwave are in flight while row r is reduced and stored
+  RowRaw<NCH> xraw, draw;
+  float mean_n = 0.0f, rstd_n = 0.0f;
+  if (wave < M) {
+    load_row_raw<NCH>(h + (size_t)wave * H, H, lane, xraw);
+    load_row_raw<NCH>(dy + (size_t)wave * H, H, lane, draw);
+    mean_n = mean_i[wave];
+    rstd_n = rstd_i[wave];
+  }
   for (int r = wave; r < M; r += nwave) {
     RowF<NCH> x, d;
-    load_row_bf16<NCH>(h + (size_t)r * H, H, lane, x);
-    load_row_bf16<NCH>(dy + (size_t)r * H, H, lane, d);
+    unpack_row<NCH>(xraw, x);
+    unpack_row<NCH>(draw, d);
+    const float mean = mean_n, rstd = rstd_n;
+    const int rn = r + nwave;
+    if (rn < M) {
+      load_row_raw<NCH>(h + (size_t)rn * H, H, lane, xraw);
+      load_row_raw<NCH>(dy + (size_t)rn * H, H, lane, draw);
+      mean_n = mean_i[rn];
+      rstd_n = rstd_i[rn];
+    }
     if (EMBED && drop_thresh) drop_row<NCH>(d, ck, drop_seed, drop_thresh, dscale, r);
-    const float mean = mean_i[r], rstd = rstd_i[r];
     float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {

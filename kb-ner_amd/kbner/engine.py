@@ -382,10 +382,10 @@ class Tagger:
                        a.grad(p + "ln1.b"), a.grad(p + "o.bias"), dhm=dh1m if d_o[1] else None, drop=d_o)
             # attention output projection
             ops.gemm(GEMM_NN, dh1m, a.bf(p + "o.weight"), Mp, H, H, C=ac.dctx)
-            # attention core
-            ops.attn_bwd(ac.qkv[l], ac.ctx[l], ac.dctx, maskbias, ac.lse[l], ac.dws, dqkv, B, S, H, A, drop=d_att)
+            # attention core (+ d qkv.bias = column sums of dqkv, accumulated inside the kernels)
+            ops.attn_bwd(ac.qkv[l], ac.ctx[l], ac.dctx, maskbias, ac.lse[l], ac.dws, dqkv, B, S, H, A, drop=d_att,
+                         dbias=a.grad(p + "qkv.bias"))
             # QKV projection
-            ops.colsum(dqkv, a.grad(p + "qkv.bias"))
             ops.gemm(GEMM_NN, dqkv, a.bf(p + "qkv.weight"), Mp, H, 3 * H, C=ac.dx, addend=dh1, epi=EPI_ADD)
             # weight gradients dW += dY^T X are deferred and launched for WGRAD_GROUP layers at once
             # (no split-K, no atomics; the dY buffers rotate so they stay live until the group is flushed)

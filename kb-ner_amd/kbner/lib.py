@@ -39,7 +39,7 @@ SIGNATURES = {
                                 P, c_int, c_int, c_int, c_float, U32, U32, P]),
     "kbner_gemm_bf16_grouped": (c_int, [c_int, c_int, P, P]),
     "kbner_attn_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, U32, U32, P]),
-    "kbner_attn_bwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, U32, U32, P]),
+    "kbner_attn_bwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, U32, U32, P, P]),
     "kbner_sqnorm_ws_floats": (c_int, []),
     "kbner_grad_sqnorm": (c_int, [P, c_size_t, P, P, c_int, P]),
     "kbner_adamw_hf": (c_int, [P, P, P, P, P, c_size_t, c_size_t, c_float, c_float, c_float, c_float, c_float, P, c_float,

@@ -237,9 +237,10 @@ def attn_fwd(qkv, maskbias, ctx, lse, B, S, H, A, drop=NO_DROP):
     L.call("kbner_attn_fwd", ptr(qkv), ptr(maskbias), ptr(ctx), ptr(lse), B, S, H, A, drop[0], drop[1], stream_ptr())
 
 
-def attn_bwd(qkv, ctx, dctx, maskbias, lse, dws, dqkv, B, S, H, A, drop=NO_DROP):
+def attn_bwd(qkv, ctx, dctx, maskbias, lse, dws, dqkv, B, S, H, A, drop=NO_DROP, dbias=None):
+    """dbias f32[3H] (optional): accumulates the column sums of dqkv (= d qkv.bias) inside the kernels"""
     L.call("kbner_attn_bwd", ptr(qkv), ptr(ctx), ptr(dctx), ptr(maskbias), ptr(lse), ptr(dws), ptr(dqkv), B, S, H, A,
-           drop[0], drop[1], stream_ptr())
+           drop[0], drop[1], ptr(dbias), stream_ptr())
 
 
 # ---------------------------------------------------------------- optimiser

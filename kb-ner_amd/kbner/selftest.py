@@ -163,10 +163,15 @@ def check_attention(B, S, A, seed=0, ragged=True, drop_p=0.0):
     ops.attn_fwd(qd, mbd, ctx, lse, B, S, H, A, drop=drop)
     dws = torch.zeros(B, A, S, dtype=F32, device=DEV)
     dqkv = torch.zeros(B * S, 3 * H, dtype=BF16, device=DEV)
-    ops.attn_bwd(qd, ctx, dd, mbd, lse, dws, dqkv, B, S, H, A, drop=drop)
+    dbias = torch.zeros(3 * H, dtype=F32, device=DEV)
+    ops.attn_bwd(qd, ctx, dd, mbd, lse, dws, dqkv, B, S, H, A, drop=drop, dbias=dbias)
     torch.cuda.synchronize()
     dq = dqkv.cpu().float()
+    bias_ref = dqkv_ref.sum(0)
     return {
+        # fused d qkv.bias = column sums of dqkv; the K third is ~0 by construction (softmax shift invariance), so it is
+        # compared on the absolute scale of the Q / V thirds
+        "dbias": float((dbias.cpu().double() - bias_ref).abs().max() / (bias_ref.abs().max() + 1e-30)),
         "ctx": rel_l2(ctx.cpu().float(), ctx_ref),
         "lse": float((lse.cpu().double() - lse_ref).abs().max()),
         "dq": rel_l2(dq[:, :H], dqkv_ref[:, :H]),

@@ -78,6 +78,7 @@ def test_attention(st, B, S, A, ragged):
     # bf16 probabilities / outputs: ~1e-2 relative in L2
     assert r["ctx"] < 1.5e-2 and r["lse"] < 2e-2, r
     assert r["dq"] < 3e-2 and r["dk"] < 3e-2 and r["dv"] < 3e-2, r
+    assert r["dbias"] < 2e-2, r                        # qkv bias gradient accumulated inside the backward kernels
 
 
 @pytest.mark.parametrize("M,H", [(256, 128), (300, 768), (512, 1024)])

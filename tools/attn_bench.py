@@ -29,5 +29,6 @@ def timeit(fn):
 f = 4.0 * S * S * 64 * A * B
 t = timeit(lambda: ops.attn_fwd(qkv, mb, ctx, lse, B, S, H, A))
 print("fwd  %8.1f us  %7.1f TFLOP/s (2 matmuls)" % (t * 1e3, f / t / 1e9))
-t = timeit(lambda: ops.attn_bwd(qkv, ctx, dctx, mb, lse, dws, dqkv, B, S, H, A))
+dbias = torch.zeros(3 * H, device=qkv.device)
+t = timeit(lambda: ops.attn_bwd(qkv, ctx, dctx, mb, lse, dws, dqkv, B, S, H, A, dbias=dbias))
 print("bwd  %8.1f us  %7.1f TFLOP/s (7 matmuls executed; %.1f counting the 5 algorithmic)" % (t * 1e3, 3.5 * f / t / 1e9, 2.5 * f / t / 1e9))
