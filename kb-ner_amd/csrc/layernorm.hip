@@ -217,6 +217,18 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int* __restrict
   }
 }
 
+template <int NCH>
+static __device__ __forceinline__ void flush_row_atomic(float* __restrict__ dst, int H, int lane, const RowF<NCH>& r) {
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int h0 = (lane + 64 * c) * 8;
+    if (h0 < H) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) atomicAdd(dst + h0 + j, r.v[c][j]);
+    }
+  }
+}
+
 // Backward.  EMBED: additionally scatter-add dh into the embedding-table gradients (fp32 atomics:
 // token ids repeat) and accumulate sum_rows dh into dtype0 through the dbias path.
 template <int NCH, bool EMBED>
@@ -245,6 +257,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
 #pragma unroll
     for (int j = 0; j < 8; ++j) ag.v[c][j] = ab.v[c][j] = ah.v[c][j] = 0.0f;
   const float invH = 1.0f / (float)H;
+  RowF<NCH> pacc;  // EMBED: running position-embedding gradient of the current run of equal position ids
+  int pcur = -1;
   // one row ahead: the loads of row r + nwave are in flight while row r is reduced and stored
   RowRaw<NCH> xraw, draw;
   float mean_n = 0.0f, rstd_n = 0.0f;
@@ -301,20 +315,34 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
       for (int j = 0; j < 8; ++j) ah.v[c][j] += d.v[c][j];
     if (EMBED) {
       float* dw = dword + (size_t)ids[r] * H;
-      float* dp = dpos + (size_t)pos_ids[r] * H;
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
         const int h0 = (lane + 64 * c) * 8;
         if (h0 < H) {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            atomicAdd(dw + h0 + j, d.v[c][j]);
-            atomicAdd(dp + h0 + j, d.v[c][j]);
-          }
+          for (int j = 0; j < 8; ++j) atomicAdd(dw + h0 + j, d.v[c][j]);
         }
       }
+      // Position rows repeat B times per step (514 rows shared by every sentence): with the grid a multiple of the sentence
+      // length a wave's successive rows r, r + nwave, ... are the SAME position of different sentences, so their
+      // gradients are summed in registers and flushed once per run of equal ids instead of once per token
+      // (B-fold fewer atomics on B-way contended addresses); any other id pattern just flushes more often.
+      const int p = pos_ids[r];
+      if (p != pcur) {
+        if (pcur >= 0) flush_row_atomic<NCH>(dpos + (size_t)pcur * H, H, lane, pacc);
+        pcur = p;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) pacc.v[c][j] = 0.0f;
+      }
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pacc.v[c][j] += d.v[c][j];
     }
   }
+  if (EMBED && pcur >= 0) flush_row_atomic<NCH>(dpos + (size_t)pcur * H, H, lane, pacc);
   // Column sums: combine the block's 4 waves in LDS, then write the block's partial row to the workspace with plain
   // coalesced stores; ln_colreduce_kernel sums the partial rows.  (Per-block global atomics -- 3 x H per block -- were
   // the bottleneck of this kernel: with enough blocks to hide HBM latency they outnumber the useful traffic.)
