@@ -181,6 +181,163 @@ static __device__ __forceinline__ void pick_tile(const GroupArgs& ga, int id, in
   n0 = (r / gm) * T2;
 }
 
+// Epilogue of one 256x256 tile, instantiated per flag set (EPI_CT; -1 = generic runtime flags for uncommon
+// combinations).  With runtime flags every (row-fragment, column-half) step is a chain of ~10 scalar branches and its
+// own basic block: ~160 branches per tile cost more than the arithmetic they guard (3.6 us of a 32-us tile measured
+// with s_memtime stamps), and the residual / GELU' operand loads cannot be hoisted out of their block, so each one
+// exposes a full memory latency.  Here the flags fold at compile time, the operand loads of row fragment mi+1 are
+// issued before fragment mi is processed, and sched_barriers keep the compiler from interleaving all eight fragments
+// (which spills).
+template <int EPI_CT>
+static __device__ __forceinline__ void epilogue256(const GemmProblem& g, f4v (&acc)[8][4], int m0, int n0, int wm, int wn,
+                                                   int lane) {
+  const int epi = EPI_CT >= 0 ? EPI_CT : g.epi;
+  const float alpha = g.alpha;
+  const int gq = lane >> 4;
+  const int ncol = n0 + wn * 64 + gq * 8;  // + q * 32: the 8 contiguous columns this lane owns in column-half q
+  const int mrow = m0 + wm * 128 + (lane & 15);
+  float csum[2][8];
+  float bq[2][8];  // this lane's 16 bias values, loaded once per tile
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      csum[q][r] = 0.0f;
+      bq[q][r] = 0.0f;
+    }
+  const bool drop = (epi & EPI_DROP) != 0;
+  const float dscale = drop_scale(g.drop_thresh);
+  if (drop) {
+    // the 16 column keys of this lane live in csum's registers (EPI_DROP excludes EPI_COLSUM): no extra VGPRs
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int r = 0; r < 8; ++r) csum[q][r] = __uint_as_float(drop_colkey(g.drop_seed, (uint32_t)(ncol + q * 32 + r)));
+  }
+  if (epi & EPI_BIAS) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const float* bp = g.bias + ncol + q * 32;
+      const float4 b0 = *reinterpret_cast<const float4*>(bp);
+      const float4 b1 = *reinterpret_cast<const float4*>(bp + 4);
+      bq[q][0] = b0.x; bq[q][1] = b0.y; bq[q][2] = b0.z; bq[q][3] = b0.w;
+      bq[q][4] = b1.x; bq[q][5] = b1.y; bq[q][6] = b1.z; bq[q][7] = b1.w;
+    }
+  }
+  // operand tile (residual addend or saved pre-activation) of the row fragment about to be processed, one fragment ahead
+  const bool has_in = (epi & (EPI_ADD | EPI_DGELU)) != 0;
+  const bf16_t* inp = (epi & EPI_ADD) ? g.addend : g.aux;
+  const int ldin = (epi & EPI_ADD) ? g.ldadd : g.ldaux;
+  uint4 nxt_in[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+  if (has_in) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) nxt_in[q] = *reinterpret_cast<const uint4*>(inp + (size_t)mrow * ldin + ncol + q * 32);
+  }
+#pragma unroll
+  for (int mi = 0; mi < 8; ++mi) {
+    const int m = mrow + mi * 16;
+    const uint32_t rk = drop ? drop_rowkey(g.drop_seed, (uint32_t)m) : 0u;
+    uint4 cur_in[2] = {nxt_in[0], nxt_in[1]};
+    if (has_in && mi + 1 < 8) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        nxt_in[q] = *reinterpret_cast<const uint4*>(inp + (size_t)(m + 16) * ldin + ncol + q * 32);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int n = ncol + q * 32;
+      float v[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = acc[mi][2 * q][r] * alpha;
+        v[4 + r] = acc[mi][2 * q + 1][r] * alpha;
+      }
+      if (epi & EPI_RMW32) {
+        float4* c = reinterpret_cast<float4*>(g.C32 + (size_t)m * g.ldc32 + n);
+        float4 o0 = c[0], o1 = c[1];
+        o0.x += v[0]; o0.y += v[1]; o0.z += v[2]; o0.w += v[3];
+        o1.x += v[4]; o1.y += v[5]; o1.z += v[6]; o1.w += v[7];
+        c[0] = o0;
+        c[1] = o1;
+        continue;
+      }
+      if (epi & EPI_ATOMIC32) {
+        float* c = g.C32 + (size_t)m * g.ldc32 + n;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) atomicAdd(c + r, v[r]);
+        continue;
+      }
+      if (epi & EPI_BIAS) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] += bq[q][r];
+      }
+      if (drop) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = drop_keep(rk, __float_as_uint(csum[q][r]), g.drop_thresh) ? v[r] * dscale : 0.0f;
+      }
+      const uint32_t w_in[4] = {cur_in[q].x, cur_in[q].y, cur_in[q].z, cur_in[q].w};
+      if (epi & EPI_ADD) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[2 * r] += __uint_as_float(w_in[r] << 16);
+          v[2 * r + 1] += __uint_as_float(w_in[r] & 0xffff0000u);
+        }
+      }
+      if (epi & EPI_DGELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const f2v gg = gelu_grad2(unpack2bf(w_in[r]));
+          v[2 * r] *= gg[0];
+          v[2 * r + 1] *= gg[1];
+        }
+      }
+      if (epi & EPI_GELU) {
+        // the saved pre-activation is the bf16-rounded value; gelu is applied to that same value so
+        // backward's gelu'(pre) sees exactly what forward activated
+        uint4 pu;
+        pu.x = pack2bf(v[0], v[1]);
+        pu.y = pack2bf(v[2], v[3]);
+        pu.z = pack2bf(v[4], v[5]);
+        pu.w = pack2bf(v[6], v[7]);
+        *reinterpret_cast<uint4*>(g.out2 + (size_t)m * g.ldout2 + n) = pu;
+        const uint32_t w[4] = {pu.x, pu.y, pu.z, pu.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const f2v gg = gelu2(unpack2bf(w[r]));
+          v[2 * r] = gg[0];
+          v[2 * r + 1] = gg[1];
+        }
+      }
+      uint4 o;
+      o.x = pack2bf(v[0], v[1]);
+      o.y = pack2bf(v[2], v[3]);
+      o.z = pack2bf(v[4], v[5]);
+      o.w = pack2bf(v[6], v[7]);
+      *reinterpret_cast<uint4*>(g.C + (size_t)m * g.ldc + n) = o;
+      if (epi & EPI_COLSUM) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) csum[q][r] += v[r];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (epi & EPI_COLSUM) {
+    // this wave's 128 rows: 8 in registers (mi), 16 across the lanes of a group (xor-shuffle), then one atomic per column
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        float x = csum[q][r];
+        x += __shfl_xor(x, 1, 64);
+        x += __shfl_xor(x, 2, 64);
+        x += __shfl_xor(x, 4, 64);
+        x += __shfl_xor(x, 8, 64);
+        if ((lane & 15) == 0) atomicAdd(g.colsum + ncol + q * 32 + r, x);
+      }
+  }
+}
+
 template <bool A_KS, bool B_KS>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GroupArgs ga) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -289,134 +446,21 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GroupArgs ga) {
     pick_tile(ga, id, total, g, mm, nn);
   }
   const int epi = g.epi;
-  const float alpha = g.alpha;
-  const int gq = lane >> 4;
-  float csum[2][8];
-  float bq[2][8];  // this lane's 16 bias values, loaded once per tile (not once per row fragment)
-#pragma unroll
-  for (int q = 0; q < 2; ++q)
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      csum[q][r] = 0.0f;
-      bq[q][r] = 0.0f;
+  // forward (NT) tiles take the specialised epilogues; for the dgrad layout (whose transpose-read B operand leaves fewer
+  // free registers) the specialised GELU' / residual variants spill and measured slower in situ than the generic one
+  if (!B_KS) {
+    switch (epi) {
+      case 0: epilogue256<0>(g, acc, m0, n0, wm, wn, lane); break;
+      case EPI_BIAS: epilogue256<EPI_BIAS>(g, acc, m0, n0, wm, wn, lane); break;
+      case EPI_BIAS | EPI_GELU: epilogue256<(EPI_BIAS | EPI_GELU)>(g, acc, m0, n0, wm, wn, lane); break;
+      case EPI_BIAS | EPI_ADD: epilogue256<(EPI_BIAS | EPI_ADD)>(g, acc, m0, n0, wm, wn, lane); break;
+      case EPI_BIAS | EPI_ADD | EPI_DROP: epilogue256<(EPI_BIAS | EPI_ADD | EPI_DROP)>(g, acc, m0, n0, wm, wn, lane); break;
+      default: epilogue256<-1>(g, acc, m0, n0, wm, wn, lane); break;
     }
-  const bool drop = (epi & EPI_DROP) != 0;
-  const float dscale = drop_scale(g.drop_thresh);
-  if (drop) {
-    // the 16 column keys of this lane live in csum's registers (EPI_DROP excludes EPI_COLSUM): no extra VGPRs
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-      for (int r = 0; r < 8; ++r)
-        csum[q][r] = __uint_as_float(drop_colkey(g.drop_seed, (uint32_t)(n0 + wn * 64 + q * 32 + gq * 8 + r)));
-  }
-  if (epi & EPI_BIAS) {
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const float* bp = g.bias + n0 + wn * 64 + q * 32 + gq * 8;
-      const float4 b0 = *reinterpret_cast<const float4*>(bp);
-      const float4 b1 = *reinterpret_cast<const float4*>(bp + 4);
-      bq[q][0] = b0.x; bq[q][1] = b0.y; bq[q][2] = b0.z; bq[q][3] = b0.w;
-      bq[q][4] = b1.x; bq[q][5] = b1.y; bq[q][6] = b1.z; bq[q][7] = b1.w;
-    }
-  }
-#pragma unroll
-  for (int mi = 0; mi < 8; ++mi) {
-    const int m = m0 + wm * 128 + mi * 16 + (lane & 15);
-    const uint32_t rk = drop ? drop_rowkey(g.drop_seed, (uint32_t)m) : 0u;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int n = n0 + wn * 64 + q * 32 + gq * 8;  // 8 contiguous columns owned by this lane
-      float v[8];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        v[r] = acc[mi][2 * q][r] * alpha;
-        v[4 + r] = acc[mi][2 * q + 1][r] * alpha;
-      }
-      if (epi & EPI_RMW32) {
-        float4* c = reinterpret_cast<float4*>(g.C32 + (size_t)m * g.ldc32 + n);
-        float4 o0 = c[0], o1 = c[1];
-        o0.x += v[0]; o0.y += v[1]; o0.z += v[2]; o0.w += v[3];
-        o1.x += v[4]; o1.y += v[5]; o1.z += v[6]; o1.w += v[7];
-        c[0] = o0;
-        c[1] = o1;
-        continue;
-      }
-      if (epi & EPI_ATOMIC32) {
-        float* c = g.C32 + (size_t)m * g.ldc32 + n;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) atomicAdd(c + r, v[r]);
-        continue;
-      }
-      if (epi & EPI_BIAS) {
-#pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] += bq[q][r];
-      }
-      if (drop) {
-#pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] = drop_keep(rk, __float_as_uint(csum[q][r]), g.drop_thresh) ? v[r] * dscale : 0.0f;
-      }
-      if (epi & EPI_ADD) {
-        const uint4 u = *reinterpret_cast<const uint4*>(g.addend + (size_t)m * g.ldadd + n);
-        const uint32_t w[4] = {u.x, u.y, u.z, u.w};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          v[2 * r] += __uint_as_float(w[r] << 16);
-          v[2 * r + 1] += __uint_as_float(w[r] & 0xffff0000u);
-        }
-      }
-      if (epi & EPI_DGELU) {
-        const uint4 u = *reinterpret_cast<const uint4*>(g.aux + (size_t)m * g.ldaux + n);
-        const uint32_t w[4] = {u.x, u.y, u.z, u.w};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const f2v gg = gelu_grad2(unpack2bf(w[r]));
-          v[2 * r] *= gg[0];
-          v[2 * r + 1] *= gg[1];
-        }
-      }
-      if (epi & EPI_GELU) {
-        // the saved pre-activation is the bf16-rounded value; gelu is applied to that same value so
-        // backward's gelu'(pre) sees exactly what forward activated
-        uint4 pu;
-        pu.x = pack2bf(v[0], v[1]);
-        pu.y = pack2bf(v[2], v[3]);
-        pu.z = pack2bf(v[4], v[5]);
-        pu.w = pack2bf(v[6], v[7]);
-        *reinterpret_cast<uint4*>(g.out2 + (size_t)m * g.ldout2 + n) = pu;
-        const uint32_t w[4] = {pu.x, pu.y, pu.z, pu.w};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const f2v gg = gelu2(unpack2bf(w[r]));
-          v[2 * r] = gg[0];
-          v[2 * r + 1] = gg[1];
-        }
-      }
-      uint4 o;
-      o.x = pack2bf(v[0], v[1]);
-      o.y = pack2bf(v[2], v[3]);
-      o.z = pack2bf(v[4], v[5]);
-      o.w = pack2bf(v[6], v[7]);
-      *reinterpret_cast<uint4*>(g.C + (size_t)m * g.ldc + n) = o;
-      if (!drop) {
-#pragma unroll
-        for (int r = 0; r < 8; ++r) csum[q][r] += v[r];
-      }
-    }
-  }
-  if (epi & EPI_COLSUM) {
-    // this wave's 128 rows: 8 in registers (mi), 16 across the lanes of a group (xor-shuffle), then one atomic per column
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        float x = csum[q][r];
-        x += __shfl_xor(x, 1, 64);
-        x += __shfl_xor(x, 2, 64);
-        x += __shfl_xor(x, 4, 64);
-        x += __shfl_xor(x, 8, 64);
-        if ((lane & 15) == 0) atomicAdd(g.colsum + n0 + wn * 64 + q * 32 + gq * 8 + r, x);
-      }
+  } else if (A_KS && epi == EPI_RMW32) {
+    epilogue256<EPI_RMW32>(g, acc, m0, n0, wm, wn, lane);
+  } else {
+    epilogue256<-1>(g, acc, m0, n0, wm, wn, lane);
   }
   if (!has_next) break;
   pend = (epi & EPI_ATOMIC32) ? 0 : ((epi & (EPI_GELU | EPI_RMW32)) ? 32 : 16);
