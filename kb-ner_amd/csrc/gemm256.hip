@@ -338,6 +338,16 @@ static __device__ __forceinline__ void epilogue256(const GemmProblem& g, f4v (&a
   }
 }
 
+// -DG2_TRACE (tools/gemm_trace.sh, never the product build): wave 0 stamps s_memtime at tile start / main-loop end /
+// epilogue end so tools/gemm_trace.py can split a persistent workgroup's time per tile.
+#ifdef G2_TRACE
+__device__ unsigned long long g2_trace[256 * 32 * 4];
+#define G2_T(slot)                                                                        \
+  if (threadIdx.x == 0 && tile_no < 32) g2_trace[(blockIdx.x * 32 + tile_no) * 4 + (slot)] = __builtin_readcyclecounter();
+#else
+#define G2_T(slot)
+#endif
+
 template <bool A_KS, bool B_KS>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GroupArgs ga) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -361,7 +371,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GroupArgs ga) {
     stage256<B_KS, true>(g0.B, g0.ldb, n00, 0, smem + TILE2_BYTES, wid, lane);
   }
 
+  int tile_no = 0;
+  (void)tile_no;
   for (;;) {
+  G2_T(0)
   // (the problem descriptor is re-read from kernarg where it is needed -- main loop, next-tile prefetch, epilogue --
   // instead of being carried in ~30 SGPRs across the MFMA loop, which spilled)
   int m0, n0, nt, lda, ldb;
@@ -440,6 +453,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GroupArgs ga) {
     G2_MM(a1, b1, 3);
   }
 
+  G2_T(1)
   GemmProblem g;
   {
     int mm, nn;
@@ -462,6 +476,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GroupArgs ga) {
   } else {
     epilogue256<-1>(g, acc, m0, n0, wm, wn, lane);
   }
+  G2_T(2)
+  ++tile_no;
   if (!has_next) break;
   pend = (epi & EPI_ATOMIC32) ? 0 : ((epi & (EPI_GELU | EPI_RMW32)) ? 32 : 16);
   id = id_next;
@@ -512,6 +528,12 @@ struct kbner_gemm_problem {
   uint32_t drop_seed;
   uint32_t drop_thresh;
 };
+
+#ifdef G2_TRACE
+extern "C" int kbner_debug_read_trace(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g2_trace), sizeof(unsigned long long) * 256 * 32 * 4);
+}
+#endif
 
 extern "C" {
 
