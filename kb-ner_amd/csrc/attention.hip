@@ -228,8 +228,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const bf16_t* __restri
         a[1] = __builtin_amdgcn_exp2f(a[1] - mx);
         a[2] = __builtin_amdgcn_exp2f(a[2] - mx);
         a[3] = __builtin_amdgcn_exp2f(a[3] - mx);
-        sum += (a[0] + a[1]) + (a[2] + a[3]);
         if (DROP) {
+          sum += (a[0] + a[1]) + (a[2] + a[3]);  // normaliser of the UNdropped softmax
           const uint4 ck = *reinterpret_cast<const uint4*>(sCk + f * 16 + g * 4);
           a[0] = drop_keep(rk, ck.x, drop_thresh) ? a[0] : 0.0f;
           a[1] = drop_keep(rk, ck.y, drop_thresh) ? a[1] : 0.0f;
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const bf16_t* __restri
         }
         st[f] = a;
       }
-      sum = group4_sum(sum);
+      if (DROP) sum = group4_sum(sum);
     }
     if (!v_ready) {  // first pass only (uniform): V is needed from here on
       wait_vm(0);
@@ -246,13 +246,19 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const bf16_t* __restri
       v_ready = true;
     }
     if (active) {
-      const float inv = dscale / sum;
-      f4v o[4];
+      // The softmax VALU work bounds this kernel, so two per-probability operations are moved off the vector pipe: the
+      // UNnormalised exponentials (all <= 1) go to the P.V MFMAs and the 16 outputs are scaled by 1/sum instead of the
+      // 4*NKB probabilities, and (without dropout) the row sums come from one extra MFMA per key chunk against an all-ones
+      // A fragment -- the sum of exactly the bf16 probabilities that multiply V.
+      f4v o[4], osum = (f4v){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int db = 0; db < 4; ++db) o[db] = (f4v){0.f, 0.f, 0.f, 0.f};
+      const s8v ones_s = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+      const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_s);
 #pragma unroll
       for (int kc = 0; kc < NKB / 2; ++kc) {
-        const bf16x8 pb = pack_b(st[2 * kc] * inv, st[2 * kc + 1] * inv);
+        const bf16x8 pb = pack_b(st[2 * kc], st[2 * kc + 1]);
+        if (!DROP) osum = MFMA(ones, pb, osum);
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
           const unsigned char* a = vb[db] + kc * 4096;
@@ -265,12 +271,14 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const bf16_t* __restri
         }
       }
       // O^T fragment: lane holds O[q0+li][db*16 + g*4 .. +3]
+      if (!DROP) sum = osum[0];  // every row of ones.P^T holds the column (= query) sums
+      const float inv = dscale / sum;
       bf16_t* orow = ctx + (size_t)(b * S + q0 + li) * H + h * AT_D;
 #pragma unroll
       for (int db = 0; db < 4; ++db) {
         uint2 u;
-        u.x = pack2bf(o[db][0], o[db][1]);
-        u.y = pack2bf(o[db][2], o[db][3]);
+        u.x = pack2bf(o[db][0] * inv, o[db][1] * inv);
+        u.y = pack2bf(o[db][2] * inv, o[db][3] * inv);
         *reinterpret_cast<uint2*>(orow + db * 16 + g * 4) = u;
       }
       if (g == 0) lse[((size_t)b * A + h) * S + q0 + li] = (mx + __log2f(sum)) * 0.6931471805599453f;
@@ -393,11 +401,13 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(const bf16_t* __res
   S0 = MFMA(kc_at(pK.kc[1], (CO)), qf1, S0);             \
   S1 = MFMA(kc_at(pK.kc[0], (CO) + 2048), qf0, zero4);   \
   S1 = MFMA(kc_at(pK.kc[1], (CO) + 2048), qf1, S1);      \
-  P0 = MFMA(kc_at(pV.kc[0], (CO)), do0, zero4);          \
+  P0 = MFMA(kc_at(pV.kc[0], (CO)), do0, pinit);          \
   P0 = MFMA(kc_at(pV.kc[1], (CO)), do1, P0);             \
-  P1 = MFMA(kc_at(pV.kc[0], (CO) + 2048), do0, zero4);   \
+  P1 = MFMA(kc_at(pV.kc[0], (CO) + 2048), do0, pinit);   \
   P1 = MFMA(kc_at(pV.kc[1], (CO) + 2048), do1, P1)
     const f4v zero4 = (f4v){0.f, 0.f, 0.f, 0.f};
+    // without dropout the dP accumulators START at -D (one query per lane): dS = P * (dP - D) loses its subtraction
+    const f4v pinit = DROP ? zero4 : (f4v){-d_q, -d_q, -d_q, -d_q};
     f4v s0, s1, p0, p1;
     DQ_SP(s0, s1, p0, p1, 0);
     for (int kc = 0; kc < nkc; ++kc) {
@@ -428,8 +438,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(const bf16_t* __res
           dp0 = drop_keep(rk, ck0[r], drop_thresh) ? dp0 * dscale : 0.0f;
           dp1 = drop_keep(rk, ck1[r], drop_thresh) ? dp1 * dscale : 0.0f;
         }
-        ds0[r] = pr0 * (dp0 - d_q);
-        ds1[r] = pr1 * (dp1 - d_q);
+        ds0[r] = DROP ? pr0 * (dp0 - d_q) : pr0 * dp0;
+        ds1[r] = DROP ? pr1 * (dp1 - d_q) : pr1 * dp1;
       }
       const bf16x8 dsb = pack_b(ds0, ds1);
 #pragma unroll
@@ -482,7 +492,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
   const float dscale = DROP ? drop_scale(drop_thresh) : 1.0f;
   for (int i = tid; i < S; i += 512) {
     sL[i] = lse[sbase + i] * 1.4426950408889634f;  // log2 domain
-    sD[i] = Dv[sbase + i];
+    sD[i] = -Dv[sbase + i];  // negated: the dP accumulators start at -D (no-dropout variant), dS = P * (dP + (-D)) otherwise
     if (DROP) sRk[i] = drop_rowkey(drop_seed, bhS + (uint32_t)i);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -507,14 +517,15 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
       dk[db] = (f4v){0.f, 0.f, 0.f, 0.f};
       dv[db] = (f4v){0.f, 0.f, 0.f, 0.f};
     }
+#define nd_at(CO, off) (*reinterpret_cast<const f4v*>(sD + ((CO) >> 7) + (off) + g * 4))
 #define DKV_SP(S0, S1, P0, P1, CO)                \
   S0 = MFMA(kc_at(pQ.kc[0], (CO)), kf0, zero4);          \
   S0 = MFMA(kc_at(pQ.kc[1], (CO)), kf1, S0);             \
   S1 = MFMA(kc_at(pQ.kc[0], (CO) + 2048), kf0, zero4);   \
   S1 = MFMA(kc_at(pQ.kc[1], (CO) + 2048), kf1, S1);      \
-  P0 = MFMA(kc_at(pO.kc[0], (CO)), vf0, zero4);          \
+  P0 = MFMA(kc_at(pO.kc[0], (CO)), vf0, DROP ? zero4 : nd_at((CO), 0));  \
   P0 = MFMA(kc_at(pO.kc[1], (CO)), vf1, P0);             \
-  P1 = MFMA(kc_at(pO.kc[0], (CO) + 2048), vf0, zero4);   \
+  P1 = MFMA(kc_at(pO.kc[0], (CO) + 2048), vf0, DROP ? zero4 : nd_at((CO), 16)); \
   P1 = MFMA(kc_at(pO.kc[1], (CO) + 2048), vf1, P1)
     const f4v zero4 = (f4v){0.f, 0.f, 0.f, 0.f};
     f4v s0, s1, p0, p1;
@@ -553,8 +564,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
           dp0 = k0_ ? dp0 * dscale : 0.0f;
           dp1 = k1_ ? dp1 * dscale : 0.0f;
         }
-        ds0[r] = e0 * (dp0 - da[r]);
-        ds1[r] = e1 * (dp1 - dbv[r]);
+        ds0[r] = DROP ? e0 * (dp0 + da[r]) : e0 * dp0;   // da / dbv hold -D
+        ds1[r] = DROP ? e1 * (dp1 + dbv[r]) : e1 * dp1;
       }
       const bf16x8 pb = pack_b(pr0, pr1);
       const bf16x8 dsb = pack_b(ds0, ds1);
@@ -566,6 +577,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
       s0 = n0; s1 = n1; p0 = m0_; p1 = m1_;
     }
 #undef DKV_SP
+#undef nd_at
     bf16_t* krow = dqkv + (size_t)(b * S + k0 + li) * ld + H + h * AT_D;
     bf16_t* vrow = krow + H;
 #pragma unroll
