@@ -159,6 +159,24 @@ def test_full_size_invariants():
     ops.gemm(0, (x.float() * 2).to(torch.bfloat16), w, M, 4096, H, C=y2)
     torch.cuda.synchronize()
     assert float((y2.float() - 2 * y1.float()).abs().max()) <= 2e-2 * float(y1.float().abs().max())
+    # attention at full size: with V == 1 every output equals the row sum of the softmax = 1 (ragged key mask included);
+    # with probability dropout the outputs are unbiased: E[mask / (1-p)] = 1
+    B, S, A = 4, 512, 16
+    Hh = A * 64
+    qkv = (torch.randn(B * S, 3 * Hh, device="cuda") * 0.5).to(torch.bfloat16)
+    qkv[:, 2 * Hh:] = 1.0
+    am = torch.ones(B, S, device="cuda")
+    am[1, 300:] = 0
+    mb = ((1 - am) * -10000.0).float().contiguous()
+    ctx = torch.zeros(B * S, Hh, dtype=torch.bfloat16, device="cuda")
+    lse = torch.zeros(B, A, S, device="cuda")
+    ops.attn_fwd(qkv, mb, ctx, lse, B, S, Hh, A)
+    torch.cuda.synchronize()
+    assert float((ctx.float() - 1.0).abs().max()) < 1e-2
+    ctx_d = torch.zeros_like(ctx)
+    ops.attn_fwd(qkv, mb, ctx_d, lse, B, S, Hh, A, drop=(2024, ops.drop_thresh(0.1)))
+    torch.cuda.synchronize()
+    assert abs(float(ctx_d.float().mean()) - 1.0) < 5e-3 and float(ctx_d.float().std()) > 1e-3
 
 
 def _run_bench(extra_env, launcher, args):
