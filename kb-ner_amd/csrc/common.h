@@ -117,6 +117,16 @@ static __device__ __forceinline__ f2v gelu_grad2(f2v x) {
   const f2v sh = {copysignf(h[0], x[0]), copysignf(h[1], x[1])};
   return (x * e) * splat2(0.39894228040143268f) + (sh + splat2(0.5f));
 }
+// gelu(x) and gelu'(x) together (they share exp(-x^2/2) and the erf): the forward GEMM epilogue stores the derivative
+// (bf16) next to the activation, so the backward epilogue is one multiply instead of a second erf evaluation
+static __device__ __forceinline__ void gelu_both2(f2v x, f2v& y, f2v& dy) {
+  const f2v ax = {fabsf(x[0]), fabsf(x[1])};
+  f2v h, e;
+  gelu_half_erf2(x, ax, h, e);
+  y = x * splat2(0.5f) + ax * h;
+  const f2v sh = {copysignf(h[0], x[0]), copysignf(h[1], x[1])};
+  dy = (x * e) * splat2(0.39894228040143268f) + (sh + splat2(0.5f));
+}
 // packed bf16 pair (one dword) <-> f2v
 static __device__ __forceinline__ f2v unpack2bf(uint32_t w) {
   return (f2v){__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)};

@@ -21,9 +21,9 @@
 #include "common.h"
 
 #define EPI_BIAS 1     // + bias[n]
-#define EPI_GELU 2     // out2 = pre-activation (bf16), C = gelu(pre)
+#define EPI_GELU 2     // C = gelu(pre), out2 = gelu'(pre) (bf16)
 #define EPI_ADD 4      // + addend[m,n] (bf16)
-#define EPI_DGELU 8    // * gelu'(aux[m,n])
+#define EPI_DGELU 8    // * aux[m,n]  (aux = the gelu'(pre) the forward epilogue stored)
 #define EPI_ATOMIC32 16  // atomicAdd into C32 (fp32), no bf16 output
 #define EPI_DROP 128     // dropout on (acc*alpha + bias) before the residual add
 
@@ -208,22 +208,22 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
       }
       if (epi & EPI_DGELU) {
         const uint2 u = *reinterpret_cast<const uint2*>(g.aux + (size_t)m * g.ldaux + n);
-        v[0] *= gelu_grad_f(__uint_as_float(u.x << 16));
-        v[1] *= gelu_grad_f(__uint_as_float(u.x & 0xffff0000u));
-        v[2] *= gelu_grad_f(__uint_as_float(u.y << 16));
-        v[3] *= gelu_grad_f(__uint_as_float(u.y & 0xffff0000u));
+        // aux holds gelu'(pre), stored by the forward EPI_GELU epilogue
+        v[0] *= __uint_as_float(u.x << 16);
+        v[1] *= __uint_as_float(u.x & 0xffff0000u);
+        v[2] *= __uint_as_float(u.y << 16);
+        v[3] *= __uint_as_float(u.y & 0xffff0000u);
       }
       if (epi & EPI_GELU) {
-        // the saved pre-activation is the bf16-rounded value; gelu is applied to that same value so
-        // backward's gelu'(pre) sees exactly what forward activated
-        uint2 pu;
-        pu.x = pack2bf(v[0], v[1]);
-        pu.y = pack2bf(v[2], v[3]);
-        *reinterpret_cast<uint2*>(g.out2 + (size_t)m * g.ldout2 + n) = pu;
-        v[0] = gelu_f(__uint_as_float(pu.x << 16));
-        v[1] = gelu_f(__uint_as_float(pu.x & 0xffff0000u));
-        v[2] = gelu_f(__uint_as_float(pu.y << 16));
-        v[3] = gelu_f(__uint_as_float(pu.y & 0xffff0000u));
+        // C = gelu(pre), out2 = gelu'(pre), both evaluated at the bf16-rounded pre-activation (same as gemm256.hip)
+        f2v y0, d0, y1, d1;
+        gelu_both2(unpack2bf(pack2bf(v[0], v[1])), y0, d0);
+        gelu_both2(unpack2bf(pack2bf(v[2], v[3])), y1, d1);
+        uint2 du;
+        du.x = pack2bf(d0[0], d0[1]);
+        du.y = pack2bf(d1[0], d1[1]);
+        *reinterpret_cast<uint2*>(g.out2 + (size_t)m * g.ldout2 + n) = du;
+        v[0] = y0[0]; v[1] = y0[1]; v[2] = y1[0]; v[3] = y1[1];
       }
       uint2 o;
       o.x = pack2bf(v[0], v[1]);

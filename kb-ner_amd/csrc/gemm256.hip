@@ -12,7 +12,7 @@
 #include "common.h"
 
 #define EPI_BIAS 1
-#define EPI_GELU 2
+#define EPI_GELU 2   // C = gelu(pre), out2 = gelu'(pre) (bf16): what the backward EPI_DGELU multiplies by
 #define EPI_ADD 4
 #define EPI_DGELU 8
 #define EPI_ATOMIC32 16
@@ -284,30 +284,28 @@ static __device__ __forceinline__ void epilogue256(const GemmProblem& g, f4v (&a
           v[2 * r + 1] += __uint_as_float(w_in[r] & 0xffff0000u);
         }
       }
-      if (epi & EPI_DGELU) {
+      if (epi & EPI_DGELU) {  // aux holds gelu'(pre), stored by the forward EPI_GELU epilogue
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const f2v gg = gelu_grad2(unpack2bf(w_in[r]));
+          const f2v gg = unpack2bf(w_in[r]);
           v[2 * r] *= gg[0];
           v[2 * r + 1] *= gg[1];
         }
       }
       if (epi & EPI_GELU) {
-        // the saved pre-activation is the bf16-rounded value; gelu is applied to that same value so
-        // backward's gelu'(pre) sees exactly what forward activated
-        uint4 pu;
-        pu.x = pack2bf(v[0], v[1]);
-        pu.y = pack2bf(v[2], v[3]);
-        pu.z = pack2bf(v[4], v[5]);
-        pu.w = pack2bf(v[6], v[7]);
-        *reinterpret_cast<uint4*>(g.out2 + (size_t)m * g.ldout2 + n) = pu;
-        const uint32_t w[4] = {pu.x, pu.y, pu.z, pu.w};
+        // C = gelu(pre), out2 = gelu'(pre), both evaluated at the bf16-rounded pre-activation
+        uint4 du;
+        uint32_t dw[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const f2v gg = gelu2(unpack2bf(w[r]));
-          v[2 * r] = gg[0];
-          v[2 * r + 1] = gg[1];
+          f2v y, dy;
+          gelu_both2(unpack2bf(pack2bf(v[2 * r], v[2 * r + 1])), y, dy);
+          v[2 * r] = y[0];
+          v[2 * r + 1] = y[1];
+          dw[r] = pack2bf(dy[0], dy[1]);
         }
+        du.x = dw[0]; du.y = dw[1]; du.z = dw[2]; du.w = dw[3];
+        *reinterpret_cast<uint4*>(g.out2 + (size_t)m * g.ldout2 + n) = du;
       }
       uint4 o;
       o.x = pack2bf(v[0], v[1]);

@@ -8,7 +8,7 @@ Data layout in HBM (sized for 288 GB: everything stays resident, nothing is reco
     so clip-norm and AdamW are single streaming launches.  GEMM weights come first and have a
     bf16 "shadow" (what MFMA reads), rewritten by the AdamW kernel itself.
   * activations are token-major bf16 [M_pad, width] (M = B*S padded to 128 rows); per layer the
-    engine keeps x, qkv, ctx, h1, x1, pre, act, h2 (+ fp32 LN stats, softmax lse) for backward.
+    engine keeps x, qkv, ctx, h1, x1, gelu'(pre), act, h2 (+ fp32 LN stats, softmax lse) for backward.
 """
 import math
 
@@ -178,7 +178,7 @@ class _Acts:
         self.lse = [z(B, A, S, dt=F32) for _ in range(L)]
         self.h1 = [z(Mp, H) for _ in range(L)]
         self.x1 = [z(Mp, H) for _ in range(L)]
-        self.pre = [z(Mp, F_) for _ in range(L)]
+        self.dact = [z(Mp, F_) for _ in range(L)]  # gelu'(pre-activation), saved by the FFN-up epilogue for backward
         self.act = [z(Mp, F_) for _ in range(L)]
         self.h2 = [z(Mp, H) for _ in range(L)]
         self.st1 = [(z(Mp, dt=F32), z(Mp, dt=F32)) for _ in range(L)]
@@ -338,7 +338,7 @@ class Tagger:
             ops.gemm(GEMM_NT, ac.ctx[l], a.bf(p + "o.weight"), Mp, H, H, C=ac.h1[l], bias=a.param(p + "o.bias"), addend=x,
                      epi=EPI_BIAS | EPI_ADD, drop=d_o)
             ops.ln_fwd(ac.h1[l], a.param(p + "ln1.g"), a.param(p + "ln1.b"), eps, ac.x1[l], ac.st1[l][0], ac.st1[l][1])
-            ops.gemm(GEMM_NT, ac.x1[l], a.bf(p + "ffn1.weight"), Mp, F_, H, C=ac.act[l], out2=ac.pre[l],
+            ops.gemm(GEMM_NT, ac.x1[l], a.bf(p + "ffn1.weight"), Mp, F_, H, C=ac.act[l], out2=ac.dact[l],
                      bias=a.param(p + "ffn1.bias"), epi=EPI_BIAS | EPI_GELU)
             ops.gemm(GEMM_NT, ac.act[l], a.bf(p + "ffn2.weight"), Mp, H, F_, C=ac.h2[l], bias=a.param(p + "ffn2.bias"),
                      addend=ac.x1[l], epi=EPI_BIAS | EPI_ADD, drop=d_f)
@@ -368,10 +368,10 @@ class Tagger:
             # LN2 backward; fused: d ffn2.bias = column sums of dh
             ops.ln_bwd(dx, ac.h2[l], ac.st2[l][0], ac.st2[l][1], a.param(p + "ln2.g"), dh, a.grad(p + "ln2.g"),
                        a.grad(p + "ln2.b"), a.grad(p + "ffn2.bias"), dhm=dhm if d_f[1] else None, drop=d_f)
-            # FFN down dgrad: dpre = (dh W2) * gelu'(pre)
+            # FFN down dgrad: dpre = (dh W2) * gelu'(pre)   (the derivative itself was saved by the forward epilogue)
             # (its column sums = d ffn1.bias are accumulated by the same epilogue when the 256^2 kernel runs)
             fused = Mp % 256 == 0 and F_ % 256 == 0
-            ops.gemm(GEMM_NN, dhm, a.bf(p + "ffn2.weight"), Mp, F_, H, C=dpre, aux=ac.pre[l],
+            ops.gemm(GEMM_NN, dhm, a.bf(p + "ffn2.weight"), Mp, F_, H, C=dpre, aux=ac.dact[l],
                      epi=EPI_DGELU | (EPI_COLSUM if fused else 0), colsum=a.grad(p + "ffn1.bias") if fused else None)
             # FFN up
             if not fused:

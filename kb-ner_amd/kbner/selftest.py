@@ -80,18 +80,16 @@ def check_gemm(layout, M, N, K, epi=0, splitk=1, seed=0, drop_p=0.0):
     if epi & EPI_ADD:
         ref = ref + add.double()
         kw["addend"] = add.to(DEV)
-    if epi & EPI_DGELU:
-        x = aux.double()
-        cdf = 0.5 * (1 + torch.erf(x / np.sqrt(2.0)))
-        pdf = torch.exp(-0.5 * x * x) / np.sqrt(2 * np.pi)
-        ref = ref * (cdf + x * pdf)
+    if epi & EPI_DGELU:  # aux is the saved derivative: plain multiply
+        ref = ref * aux.double()
         kw["aux"] = aux.to(DEV)
     out2 = None
     if epi & EPI_GELU:
         out2 = torch.zeros(M, N, dtype=BF16, device=DEV)
         kw["out2"] = out2
         pre = ref.float().to(BF16).double()
-        ref_pre = ref
+        cdf = 0.5 * (1 + torch.erf(pre / np.sqrt(2.0)))
+        ref_pre = cdf + pre * torch.exp(-0.5 * pre * pre) / np.sqrt(2 * np.pi)   # out2 = gelu'(pre)
         ref = torch.nn.functional.gelu(pre)
     if epi & (EPI_ATOMIC32 | EPI_RMW32):
         C32 = torch.full((M, N), 1.0, dtype=F32, device=DEV)
