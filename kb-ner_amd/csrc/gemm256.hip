@@ -55,6 +55,7 @@ struct GroupArgs {
 #define BK2 64
 #define TILE2_BYTES 32768
 #define STAGE2_BYTES 65536
+#define G2_LDS_BYTES (2 * STAGE2_BYTES + 8 * 4096)  // two operand stages + two 2-KiB epilogue transpose buffers per wave
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void glb_cvoid;
@@ -190,7 +191,7 @@ static __device__ __forceinline__ void pick_tile(const GroupArgs& ga, int id, in
 // (which spills).
 template <int EPI_CT>
 static __device__ __forceinline__ void epilogue256(const GemmProblem& g, f4v (&acc)[8][4], int m0, int n0, int wm, int wn,
-                                                   int lane) {
+                                                   int lane, unsigned char* scr) {
   const int epi = EPI_CT >= 0 ? EPI_CT : g.epi;
   const float alpha = g.alpha;
   const int gq = lane >> 4;
@@ -224,6 +225,17 @@ static __device__ __forceinline__ void epilogue256(const GemmProblem& g, f4v (&a
       bq[q][4] = b1.x; bq[q][5] = b1.y; bq[q][6] = b1.z; bq[q][7] = b1.w;
     }
   }
+  // bf16 outputs leave through a 2-KiB per-wave LDS transpose (two buffers: C and out2): in the MFMA layout a store
+  // instruction covers 16 rows x 64 B, which the memory pipe retires at ~34 GB/s per CU; re-read as 8 rows x 128 B (8
+  // consecutive lanes per cache line) it retires at ~98 GB/s (tools/micro/store_pattern.hip)
+  // (specialised forward epilogues only: on the dgrad layout the direct stores measured marginally better in situ)
+  const bool lds_out = EPI_CT >= 0 && !(EPI_CT & (EPI_RMW32 | EPI_ATOMIC32));
+  const int wr_row = lane & 15;
+  unsigned char* scr_w[2] = {scr + wr_row * 128 + (((0 * 4 + gq) ^ (wr_row & 7)) << 4),
+                             scr + wr_row * 128 + (((1 * 4 + gq) ^ (wr_row & 7)) << 4)};
+  const int rd_row = lane >> 3, rd_chunk = lane & 7;
+  const unsigned char* scr_r = scr + rd_row * 128 + ((rd_chunk ^ (rd_row & 7)) << 4);
+  const size_t rd_off = (size_t)(m0 + wm * 128 + rd_row) * 1;  // row index; scaled by the leading dimension at the store
   // operand tile (residual addend or saved pre-activation) of the row fragment about to be processed, one fragment ahead
   const bool has_in = (epi & (EPI_ADD | EPI_DGELU)) != 0;
   const bf16_t* inp = (epi & EPI_ADD) ? g.addend : g.aux;
@@ -305,17 +317,33 @@ static __device__ __forceinline__ void epilogue256(const GemmProblem& g, f4v (&a
           dw[r] = pack2bf(dy[0], dy[1]);
         }
         du.x = dw[0]; du.y = dw[1]; du.z = dw[2]; du.w = dw[3];
-        *reinterpret_cast<uint4*>(g.out2 + (size_t)m * g.ldout2 + n) = du;
+        if (lds_out) *reinterpret_cast<uint4*>(scr_w[q] + 2048) = du;
+        else *reinterpret_cast<uint4*>(g.out2 + (size_t)m * g.ldout2 + n) = du;
       }
       uint4 o;
       o.x = pack2bf(v[0], v[1]);
       o.y = pack2bf(v[2], v[3]);
       o.z = pack2bf(v[4], v[5]);
       o.w = pack2bf(v[6], v[7]);
-      *reinterpret_cast<uint4*>(g.C + (size_t)m * g.ldc + n) = o;
+      if (lds_out) *reinterpret_cast<uint4*>(scr_w[q]) = o;
+      else *reinterpret_cast<uint4*>(g.C + (size_t)m * g.ldc + n) = o;
       if (epi & EPI_COLSUM) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) csum[q][r] += v[r];
+      }
+    }
+    if (lds_out) {
+      const uint4 h0 = *reinterpret_cast<const uint4*>(scr_r);
+      const uint4 h1 = *reinterpret_cast<const uint4*>(scr_r + 8 * 128);
+      bf16_t* d0 = g.C + (rd_off + mi * 16) * g.ldc + n0 + wn * 64 + rd_chunk * 8;
+      *reinterpret_cast<uint4*>(d0) = h0;
+      *reinterpret_cast<uint4*>(d0 + (size_t)8 * g.ldc) = h1;
+      if (epi & EPI_GELU) {
+        const uint4 e0 = *reinterpret_cast<const uint4*>(scr_r + 2048);
+        const uint4 e1 = *reinterpret_cast<const uint4*>(scr_r + 2048 + 8 * 128);
+        bf16_t* d2 = g.out2 + (rd_off + mi * 16) * g.ldout2 + n0 + wn * 64 + rd_chunk * 8;
+        *reinterpret_cast<uint4*>(d2) = e0;
+        *reinterpret_cast<uint4*>(d2 + (size_t)8 * g.ldout2) = e1;
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -458,21 +486,22 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GroupArgs ga) {
     pick_tile(ga, id, total, g, mm, nn);
   }
   const int epi = g.epi;
+  unsigned char* scr = smem + 2 * STAGE2_BYTES + wid * 4096;
   // forward (NT) tiles take the specialised epilogues; for the dgrad layout (whose transpose-read B operand leaves fewer
   // free registers) the specialised GELU' / residual variants spill and measured slower in situ than the generic one
   if (!B_KS) {
     switch (epi) {
-      case 0: epilogue256<0>(g, acc, m0, n0, wm, wn, lane); break;
-      case EPI_BIAS: epilogue256<EPI_BIAS>(g, acc, m0, n0, wm, wn, lane); break;
-      case EPI_BIAS | EPI_GELU: epilogue256<(EPI_BIAS | EPI_GELU)>(g, acc, m0, n0, wm, wn, lane); break;
-      case EPI_BIAS | EPI_ADD: epilogue256<(EPI_BIAS | EPI_ADD)>(g, acc, m0, n0, wm, wn, lane); break;
-      case EPI_BIAS | EPI_ADD | EPI_DROP: epilogue256<(EPI_BIAS | EPI_ADD | EPI_DROP)>(g, acc, m0, n0, wm, wn, lane); break;
-      default: epilogue256<-1>(g, acc, m0, n0, wm, wn, lane); break;
+      case 0: epilogue256<0>(g, acc, m0, n0, wm, wn, lane, scr); break;
+      case EPI_BIAS: epilogue256<EPI_BIAS>(g, acc, m0, n0, wm, wn, lane, scr); break;
+      case EPI_BIAS | EPI_GELU: epilogue256<(EPI_BIAS | EPI_GELU)>(g, acc, m0, n0, wm, wn, lane, scr); break;
+      case EPI_BIAS | EPI_ADD: epilogue256<(EPI_BIAS | EPI_ADD)>(g, acc, m0, n0, wm, wn, lane, scr); break;
+      case EPI_BIAS | EPI_ADD | EPI_DROP: epilogue256<(EPI_BIAS | EPI_ADD | EPI_DROP)>(g, acc, m0, n0, wm, wn, lane, scr); break;
+      default: epilogue256<-1>(g, acc, m0, n0, wm, wn, lane, scr); break;
     }
   } else if (A_KS && epi == EPI_RMW32) {
-    epilogue256<EPI_RMW32>(g, acc, m0, n0, wm, wn, lane);
+    epilogue256<EPI_RMW32>(g, acc, m0, n0, wm, wn, lane, scr);
   } else {
-    epilogue256<-1>(g, acc, m0, n0, wm, wn, lane);
+    epilogue256<-1>(g, acc, m0, n0, wm, wn, lane, scr);
   }
   G2_T(2)
   ++tile_no;
@@ -487,12 +516,12 @@ static int launch256(const GroupArgs& ga, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<A_KS, B_KS>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE2_BYTES);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES);
     if (e != hipSuccess) return -(int)e;
     attr_set = true;
   }
   const int grid = ga.total_tiles < ga.ncu ? ga.total_tiles : ga.ncu;
-  hipLaunchKernelGGL((gemm256_kernel<A_KS, B_KS>), dim3(grid), dim3(512), 2 * STAGE2_BYTES, stream, ga);
+  hipLaunchKernelGGL((gemm256_kernel<A_KS, B_KS>), dim3(grid), dim3(512), G2_LDS_BYTES, stream, ga);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }
