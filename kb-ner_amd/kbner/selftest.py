@@ -474,6 +474,53 @@ def check_windows(W=64, stride=32, n_content=150, H=128, A=2, F_=256, V=512, T=2
             "loss_rel": abs(float(loss) - float(oloss)) / abs(float(oloss))}
 
 
+def check_train_steps(steps=3, accum=2, lr=2e-4, lr_rate=50.0, t_total=10):
+    """Whole optimiser steps (finetune_trainer.py:876-1023: accumulate -> clip_grad_norm_(5.0) -> HF AdamW with the two lr
+    groups -> linear decay) on the HIP engine vs the oracle trainer from identical parameters and micro-batches."""
+    from oracle import encoder as oenc
+    from oracle import train_step as ots
+    cfg, tg, b0, (start, stop, x_idx) = tiny_setup()
+    batches = [b0] + [tiny_setup(seed=5 + k)[2] for k in range(1, accum)]
+    ocfg = oenc.EncoderConfig(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers,
+                              num_attention_heads=cfg.num_attention_heads, intermediate_size=cfg.intermediate_size,
+                              max_position_embeddings=cfg.max_position_embeddings)
+    p0 = oracle_params(tg, round_gemm=False)
+    tr = ots.OracleTrainer(p0, ocfg, start, stop, x_idx, lr=lr, lr_rate=lr_rate, accum=accum, t_total=t_total)
+    opt = engine.FusedAdamW(tg.arena, lr=lr, lr_rate=lr_rate, t_total=t_total)
+    dev_b = [kb.to_device(b, DEV) for b in batches]
+    ob = [dict(input_ids=torch.from_numpy(b["input_ids"]), attention_mask=torch.from_numpy(b["attention_mask"]),
+               first_idx=torch.from_numpy(b["first_idx"]), tags=torch.from_numpy(b["tags"].astype(np.int64)),
+               lengths=torch.from_numpy(b["lengths"].astype(np.int64))) for b in batches]
+    lh, lo, nh, no = [], [], [], []
+    for _ in range(steps):
+        for k in range(accum):
+            lh.append(float(tg.forward_loss(dev_b[k], loss_scale=1.0 / accum, backward=True)))
+            lo.append(tr.micro_batch(ob[k]))
+        nh.append(float(opt.step().sqrt()))
+        no.append(tr.optimizer_step(max_norm=5.0))
+    torch.cuda.synchronize()
+    p1 = oracle_params(tg, round_gemm=False)
+    res = {"loss_hip": lh, "loss_oracle": lo, "norm_hip": nh, "norm_oracle": no,
+           "loss_rel_max": max(abs(a - b_) / abs(b_) for a, b_ in zip(lh, lo)),
+           "norm_rel_max": max(abs(a - b_) / abs(b_) for a, b_ in zip(nh, no)),
+           "loss_decreased": lh[-accum] < lh[0]}
+    # parameter movement: direction agreement of (after - before) for the tensors that carry most of the update
+    worst = 1.0
+    for k in ("transitions", "linear.weight", "encoder.layer.1.output.dense.weight", "encoder.layer.0.attention.self.value.weight",
+              "embeddings.LayerNorm.weight"):
+        dh = (p1[k] - p0[k]).double().flatten()
+        do = (tr.params[k].detach() - p0[k]).double().flatten()
+        live = do.abs() > 0.2 * do.abs().max()          # Adam's first steps move every weight by ~lr: compare the clear ones
+        c = float((dh[live] @ do[live]) / (dh[live].norm() * do[live].norm() + 1e-30))
+        res["dcos_" + k] = c
+        worst = min(worst, c)
+    res["delta_cos_min"] = worst
+    tmask = p0["transitions"] > -1e11
+    res["transitions_maxabs"] = float((p1["transitions"] - tr.params["transitions"].detach())[tmask].abs().max())
+    res["transitions_moved"] = float((tr.params["transitions"].detach() - p0["transitions"])[tmask].abs().max())
+    return res
+
+
 def check_adamw(n=4096 + 64, seed=0):
     from oracle import optim as oopt
     rng = np.random.default_rng(seed)
@@ -513,3 +560,6 @@ def smoke():
     assert r["loss_rel"] < 3e-2, r
     assert r["grad_min_cos"] > 0.98, r
     assert r["viterbi_equal"], r
+    t = check_train_steps(steps=2)
+    print("smoke train steps:", {k: v for k, v in t.items() if not k.startswith("dcos_")})
+    assert t["loss_rel_max"] < 5e-2 and t["norm_rel_max"] < 1e-1, t

@@ -86,7 +86,7 @@ class OracleTrainer:
     def micro_batch(self, batch):
         loss, _ = tagger_forward_loss(self.params, self.cfg, batch, self.start, self.stop, self.x_idx)
         (loss / self.accum).backward()
-        return float(loss)
+        return float(loss.detach())
 
     @torch.no_grad()
     def optimizer_step(self, max_norm=5.0):

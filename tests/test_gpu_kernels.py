@@ -268,3 +268,14 @@ def test_crf_posterior_vs_reference_golden(st, golden_dir):
         assert np.abs(marg[valid] - g["c%d_dist" % c][valid]).max() < 5e-5
         assert np.array_equal(marg.argmax(-1)[valid], g["c%d_idx" % c][valid])   # posterior-decoded tags: identical
         assert np.abs(marg[valid].sum(-1) - 1.0).max() < 1e-4 and not marg[~valid].any()
+
+
+def test_optimizer_steps_vs_oracle_trainer(st):
+    """three whole optimiser steps (2 accumulated micro-batches, clip 5.0, HF AdamW with the transitions group at lr*lr_rate,
+    linear decay) on the HIP engine vs the oracle trainer: loss trajectory, clip norms, direction of every parameter update"""
+    r = st.check_train_steps(steps=3, accum=2)
+    assert r["loss_rel_max"] < 5e-2, r
+    assert r["norm_rel_max"] < 1e-1, r
+    assert r["loss_decreased"], r
+    assert r["delta_cos_min"] > 0.85, r
+    assert r["transitions_maxabs"] < 0.25 * r["transitions_moved"], r
