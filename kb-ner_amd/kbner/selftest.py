@@ -358,7 +358,8 @@ def check_step(dropout=False, H=128, A=2, F_=256):
               lengths=torch.from_numpy(b["lengths"].astype(np.int64)))
     oloss, oem = ots.tagger_forward_loss(params, ocfg, ob, start, stop, x_idx, masks=masks, word_keep=word_keep)
     oloss.backward()
-    res = {"loss_hip": float(loss), "loss_oracle": float(oloss), "loss_rel": abs(float(loss) - float(oloss)) / abs(float(oloss))}
+    oloss_f = float(oloss.detach())
+    res = {"loss_hip": float(loss), "loss_oracle": oloss_f, "loss_rel": abs(float(loss) - oloss_f) / abs(oloss_f)}
     if dropout:
         res["n_sites"] = len(masks)
         res["word_dropped"] = int((~word_keep).sum())
