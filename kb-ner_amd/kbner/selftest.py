@@ -255,12 +255,12 @@ def check_crf(B, n, T=29, start=27, stop=28, seed=0):
 
 
 # ------------------------------------------------------------------ end-to-end tiny tagger step
-def tiny_setup(B=2, S=64, L=2, H=128, A=2, F_=256, V=512, T=29, seed=5):
+def tiny_setup(B=2, S=64, L=2, H=128, A=2, F_=256, V=512, T=29, seed=5, std=0.08):
     cfg = engine.EncoderConfig(vocab_size=V, hidden_size=H, num_hidden_layers=L, num_attention_heads=A,
                                intermediate_size=F_, max_position_embeddings=S + 2)
     start, stop, x_idx = 27, 28, 9
     tg = engine.Tagger(cfg, T, start, stop, device=DEV)
-    tg.init_random(seed=seed, std=0.08)
+    tg.init_random(seed=seed, std=std)
     b = kb.synthetic_batch(B, S, vocab=V, T=T, x_idx=x_idx, start=start, stop=stop, n_real=6, seed=seed)
     # make it ragged: second sentence shorter
     if B > 1:
@@ -331,12 +331,12 @@ def check_dropout_mask(p=0.1, Z=3, M=512, N=512, seed=12345):
             "adj_row_corr": corr(keep[:, 1:], keep[:, :-1]), "adj_col_corr": corr(keep[:, :, 1:], keep[:, :, :-1])}
 
 
-def check_step(dropout=False, H=128, A=2, F_=256):
+def check_step(dropout=False, H=128, A=2, F_=256, L=2, S=64, V=512, std=0.08):
     """One micro-batch fwd+bwd on the HIP path vs the oracle's autograd (fp32 CPU).  dropout=True: training mode with
     p=0.1 at every encoder site + WordDropout 0.1; the oracle is fed the very masks the kernels generated."""
     from oracle import encoder as oenc
     from oracle import train_step as ots
-    cfg, tg, b, (start, stop, x_idx) = tiny_setup(H=H, A=A, F_=F_)
+    cfg, tg, b, (start, stop, x_idx) = tiny_setup(H=H, A=A, F_=F_, L=L, S=S, V=V, std=std)
     bd = kb.to_device(b, DEV)
     masks, word_keep = None, None
     if dropout:

@@ -220,3 +220,15 @@ def test_bench_two_ranks_one_gpu_functional():
                     "--no-roofline"])
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 4 and d["value"] > 0
     assert "cpu_baseline" not in d           # rank 0 at N=1 only
+
+
+def test_full_size_step_vs_oracle():
+    """BASELINE size for real: XLM-R-large dimensions (L24/H1024/A16/F4096, V=250002), two ragged 512-token sentences, one
+    forward + backward on the HIP path vs the oracle's fp32 autograd on the host CPU (~1 min)."""
+    from kbner import selftest as st
+    r = st.check_step(H=1024, A=16, F_=4096, L=24, S=512, V=250002, std=0.02)
+    assert r["loss_rel"] < 3e-2, r
+    assert r["emissions_rel"] < 5e-2, r
+    assert r["grad_min_cos"] > 0.95 and r["grad_worst_rel"] < 0.3, r
+    assert r["grad_linear.weight"] < 5e-2 and r["grad_transitions"] < 5e-2, r
+    assert r["viterbi_equal"], r
