@@ -120,6 +120,15 @@ static __device__ __forceinline__ float group4_max(float v) {
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 
+static __device__ __forceinline__ float dot8(const bf16x8 a, const bf16x8 b) {
+  const s8v x = __builtin_bit_cast(s8v, a), y = __builtin_bit_cast(s8v, b);
+  float acc = 0.0f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    acc += __uint_as_float(((uint32_t)(uint16_t)x[j]) << 16) * __uint_as_float(((uint32_t)(uint16_t)y[j]) << 16);
+  return acc;
+}
+
 // Hoisted addressing: the XOR swizzle of an LDS row depends only on (row & 15), so every fragment address is a
 // per-lane base (computed once per kernel) plus a tile offset that is a multiple of 2048 bytes.
 struct PanelBases {
@@ -286,32 +295,6 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const bf16_t* __restri
   }
 }
 
-// D[b,h,s] = sum_d dO[m, h*64+d] * O[m, h*64+d]
-__global__ __launch_bounds__(256) void attn_rowdot_kernel(const bf16_t* __restrict__ dctx, const bf16_t* __restrict__ ctx,
-                                                          float* __restrict__ D, int B, int S, int H, int A) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= B * S * A) return;
-  const int h = idx % A;
-  const int m = idx / A;
-  const bf16_t* a = dctx + (size_t)m * H + h * AT_D;
-  const bf16_t* c = ctx + (size_t)m * H + h * AT_D;
-  float acc = 0.0f;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const uint4 ua = *reinterpret_cast<const uint4*>(a + j * 8);
-    const uint4 uc = *reinterpret_cast<const uint4*>(c + j * 8);
-    const uint32_t wa[4] = {ua.x, ua.y, ua.z, ua.w};
-    const uint32_t wc[4] = {uc.x, uc.y, uc.z, uc.w};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      acc += __uint_as_float(wa[k] << 16) * __uint_as_float(wc[k] << 16);
-      acc += __uint_as_float(wa[k] & 0xffff0000u) * __uint_as_float(wc[k] & 0xffff0000u);
-    }
-  }
-  const int b = m / S, s = m % S;
-  D[((size_t)b * A + h) * S + s] = acc;
-}
-
 // Column sums of a [16 rows x 64 cols] output fragment set accumulated over a workgroup's passes: the bias gradient of the
 // fused QKV projection (d qkv.bias = column sums of dQ | dK | dV), so no separate pass re-reads the 3H-wide dqkv.
 // acc[db][r] is this lane's running sum for column db*16 + g*4 + r (rows li); reduce over li, over the 8 waves, one atomic
@@ -344,10 +327,13 @@ static __device__ __forceinline__ void flush_colsum(f4v (&acc)[4], float (*red)[
 // ------------------------------------------------------------------------------------------
 // DROP replays the forward mask: dP_eff = mask * dP / (1-p) before the softmax backward (D = rowdot(dO, O) already
 // contains the dropped probabilities through O).
+// It also produces D[b,h,q] = rowdot(dO, O) (the softmax-backward correction) for its own queries from the dO / O
+// fragments it already needs, and writes it for the dK/dV kernel that runs next: no separate row-dot pass.
 template <bool DROP>
 __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dctx,
+                                                             const bf16_t* __restrict__ ctx,
                                                              const float* __restrict__ maskbias, const float* __restrict__ lse,
-                                                             const float* __restrict__ Dv, bf16_t* __restrict__ dqkv, int S,
+                                                             float* __restrict__ Dv, bf16_t* __restrict__ dqkv, int S,
                                                              int H, int A, float scale, int rpw, uint32_t drop_seed,
                                                              uint32_t drop_thresh, float* __restrict__ dbias) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -379,6 +365,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(const bf16_t* __res
   const float scale2 = scale * 1.4426950408889634f;
   const PanelBases pK = panel_bases(sK, lane), pV = panel_bases(sV, lane);
   const bf16_t* dob = dctx + (size_t)b * S * H + h * AT_D;
+  const bf16_t* ob = ctx + (size_t)b * S * H + h * AT_D;
 #pragma unroll 1
   for (int pass = 0; pass < rpw / 128; ++pass) {
     const int q0 = qt * rpw + wid * (rpw / 8) + pass * 16;
@@ -389,7 +376,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(const bf16_t* __res
     const bf16x8 do1 = glb_frag(dob, H, q0, 1, lane);
     const size_t sidx = ((size_t)b * A + h) * S + q0 + li;
     const float l_q = lse[sidx] * 1.4426950408889634f;  // log2 domain
-    const float d_q = Dv[sidx];
+    // D = sum_d dO[q,d] O[q,d]: each lane group g holds 16 of the 64 d of row q0+li in its two fragments
+    const float d_q = group4_sum(dot8(do0, glb_frag(ob, H, q0, 0, lane)) + dot8(do1, glb_frag(ob, H, q0, 1, lane)));
+    if (g == 0) Dv[sidx] = d_q;
     const uint32_t rk = DROP ? drop_rowkey(drop_seed, bhS + (uint32_t)(q0 + li)) : 0u;
     f4v dq[4];
 #pragma unroll
@@ -638,7 +627,7 @@ static int launch_attn_fwd(const bf16_t* qkv, const float* maskbias, bf16_t* ctx
 }
 
 template <bool DROP>
-static int launch_attn_bwd(const bf16_t* qkv, const bf16_t* dctx, const float* maskbias, const float* lse, const float* Dws,
+static int launch_attn_bwd(const bf16_t* qkv, const bf16_t* ctx, const bf16_t* dctx, const float* maskbias, const float* lse, float* Dws,
                            bf16_t* dqkv, int B, int S, int H, int A, uint32_t seed, uint32_t thresh, float* dbias, hipStream_t s) {
   static bool once = false;
   if (!once) {
@@ -650,7 +639,7 @@ static int launch_attn_bwd(const bf16_t* qkv, const bf16_t* dctx, const float* m
   }
   const int rpw = pick_rpw(B, S, A);
   const dim3 grid((S + rpw - 1) / rpw, A, B);
-  hipLaunchKernelGGL(attn_bwd_dq_kernel<DROP>, grid, dim3(512), AT_LDS_BYTES, s, qkv, dctx, maskbias, lse, Dws, dqkv, S, H, A,
+  hipLaunchKernelGGL(attn_bwd_dq_kernel<DROP>, grid, dim3(512), AT_LDS_BYTES, s, qkv, dctx, ctx, maskbias, lse, Dws, dqkv, S, H, A,
                      0.125f, rpw, seed, thresh, dbias);
   hipLaunchKernelGGL(attn_bwd_dkv_kernel<DROP>, grid, dim3(512), AT_LDS_BYTES, s, qkv, dctx, maskbias, lse, Dws, dqkv, S, H, A,
                      0.125f, rpw, seed, thresh, dbias);
@@ -686,10 +675,8 @@ int kbner_attn_bwd(const bf16_t* qkv, const bf16_t* ctx, const bf16_t* dctx, con
                    float* dbias_qkv, void* stream) {
   KBNER_CHECK_ARG(B > 0 && A > 0 && H == A * AT_D && S % 64 == 0 && S >= 64 && S <= AT_MAXS);
   hipStream_t s = (hipStream_t)stream;
-  const int n = B * S * A;
-  hipLaunchKernelGGL(attn_rowdot_kernel, dim3((n + 255) / 256), dim3(256), 0, s, dctx, ctx, Dws, B, S, H, A);
-  if (drop_thresh) return launch_attn_bwd<true>(qkv, dctx, maskbias, lse, Dws, dqkv, B, S, H, A, drop_seed, drop_thresh, dbias_qkv, s);
-  return launch_attn_bwd<false>(qkv, dctx, maskbias, lse, Dws, dqkv, B, S, H, A, drop_seed, drop_thresh, dbias_qkv, s);
+  if (drop_thresh) return launch_attn_bwd<true>(qkv, ctx, dctx, maskbias, lse, Dws, dqkv, B, S, H, A, drop_seed, drop_thresh, dbias_qkv, s);
+  return launch_attn_bwd<false>(qkv, ctx, dctx, maskbias, lse, Dws, dqkv, B, S, H, A, drop_seed, drop_thresh, dbias_qkv, s);
 }
 
 }  // extern "C"
