@@ -500,6 +500,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GroupArgs ga) {
     }
   } else if (A_KS && epi == EPI_RMW32) {
     epilogue256<EPI_RMW32>(g, acc, m0, n0, wm, wn, lane, scr);
+  } else if (!A_KS && epi == EPI_ADD) {
+    epilogue256<EPI_ADD>(g, acc, m0, n0, wm, wn, lane, scr);
+  } else if (!A_KS && epi == 0) {
+    epilogue256<0>(g, acc, m0, n0, wm, wn, lane, scr);
   } else {
     epilogue256<-1>(g, acc, m0, n0, wm, wn, lane, scr);
   }
