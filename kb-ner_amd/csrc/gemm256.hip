@@ -487,8 +487,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GroupArgs ga) {
   }
   const int epi = g.epi;
   unsigned char* scr = smem + 2 * STAGE2_BYTES + wid * 4096;
-  // forward (NT) tiles take the specialised epilogues; for the dgrad layout (whose transpose-read B operand leaves fewer
-  // free registers) the specialised GELU' / residual variants spill and measured slower in situ than the generic one
+  // forward (NT) tiles take the specialised epilogues; the dgrad layout (whose transpose-read B operand leaves fewer free
+  // registers) only the plain / residual-add ones -- its specialised GELU' + column-sum variant spills and measured
+  // slower in situ than the generic epilogue
   if (!B_KS) {
     switch (epi) {
       case 0: epilogue256<0>(g, acc, m0, n0, wm, wn, lane, scr); break;
