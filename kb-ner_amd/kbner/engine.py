@@ -310,13 +310,25 @@ class Tagger:
         if self.arena.offsets[name] < self.arena.n_shadow:
             self.arena.refresh_shadow()
 
+    ACTS_BUDGET_BYTES = 120 << 30  # resident activation sets (one per (B, S) shape), least-recently-used first out
+
     def acts(self, B, S):
+        """Activation / workspace buffers for a (B, S) shape.  Length-sorted batches cycle through a handful of S values;
+        their buffer sets stay resident (LRU within a byte budget) instead of being re-allocated and zero-filled."""
         key = (B, S)
-        if key not in self._acts:
-            if len(self._acts) >= 2:  # bound resident activation sets
-                self._acts.pop(next(iter(self._acts)))
-            self._acts[key] = _Acts(self.cfg, B, S, self.device)
-        return self._acts[key]
+        if key in self._acts:
+            self._acts[key] = self._acts.pop(key)  # move to the most-recent end
+            return self._acts[key]
+        cfg = self.cfg
+        per_row = 2 * (cfg.num_hidden_layers * (8 * cfg.hidden_size + 2 * cfg.intermediate_size) + 16 * cfg.hidden_size
+                       + 4 * cfg.intermediate_size)
+        need = _round_up(B * S, 256) * per_row
+        while self._acts and sum(a.nbytes for a in self._acts.values()) + need > self.ACTS_BUDGET_BYTES:
+            self._acts.pop(next(iter(self._acts)))
+        ac = _Acts(self.cfg, B, S, self.device)
+        ac.nbytes = need
+        self._acts[key] = ac
+        return ac
 
     # ---------------------------------------------------------------- encoder
     def encoder_forward(self, ids, pos_ids, maskbias, B, S):
