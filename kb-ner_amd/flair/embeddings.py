@@ -227,6 +227,20 @@ class TransformerWordEmbeddings(TokenEmbeddings):
         return counts
 
     def tokenize_sentence(self, sentence):
+        """cached per Sentence object: corpora are static across epochs, and at ~1 ms of tokenizer time per 512-piece
+        sentence re-tokenising every batch would make the host the bottleneck of a 40-ms GPU step"""
+        key = (self.name, self.max_subtokens_sequence_length, self.stride, self.maximum_subtoken_length, len(sentence))
+        cache = getattr(sentence, "_kbner_tok", None)
+        if cache is not None and cache[0] == key:
+            return cache[1]
+        out = self._tokenize_sentence(sentence)
+        try:
+            sentence._kbner_tok = (key, out)
+        except AttributeError:
+            pass
+        return out
+
+    def _tokenize_sentence(self, sentence):
         """-> (encoder rows [ids incl. <s>/</s>] -- one per sliding window --, window of each word token's first sub-token,
         its position inside that row (-1 = no sub-token))"""
         words = [self._eos_text if t.text == "<EOS>" else t.text for t in sentence]
