@@ -194,7 +194,14 @@ class TransformerWordEmbeddings(TokenEmbeddings):
     def _token_text(self, token) -> str:
         """the word token as the tokenizer spells it (its own pieces re-joined, lower-cased): unknown / normalised
         characters then compare equal between the per-token and the per-sentence tokenisation (embeddings.py:3103-3109)"""
-        return "".join(self._strip_markup(p) for p in self.tokenizer.tokenize(token.text)).lower()
+        text = token.text
+        cache = self.__dict__.setdefault("_token_text_cache", {})
+        hit = cache.get(text)
+        if hit is None:
+            hit = "".join(self._strip_markup(p) for p in self.tokenizer.tokenize(text)).lower()
+            if len(cache) < 1_000_000:  # word types, not tokens: bounded by the corpus vocabulary
+                cache[text] = hit
+        return hit
 
     def reconstruct_tokens_from_subtokens(self, tokens, subtokens) -> List[int]:
         """Sub-token count per word token, by re-assembling sub-token text against the word tokens in order.

@@ -1,0 +1,96 @@
+#!/usr/bin/env python
+"""Throughput of the DROP-IN path (YAML-equivalent objects -> ModelFinetuner.train) on a synthetic KB-NER-style corpus with
+~500-sub-token sentences and an XLM-R-large-sized random encoder: shows what the flair mirror's host side (tokenizer cache,
+batch assembly, logging, evaluation) costs on top of the kernels that bench.py times.
+usage: python tools/train_throughput.py [--sentences 512] [--batch 32] [--accum 4] [--model large|base]"""
+import argparse
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "kb-ner_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--sentences", type=int, default=512)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--accum", type=int, default=4)
+    ap.add_argument("--model", default="large", choices=["large", "base"])
+    a = ap.parse_args()
+    import tiny_assets
+    import torch
+    from flair.data import Dictionary
+    from flair.datasets import ColumnCorpus
+    from flair.embeddings import TransformerWordEmbeddings
+    from flair.models import FastSequenceTagger
+    from flair.trainers import ModelFinetuner
+    d = tempfile.mkdtemp(prefix="kbner_tp_")
+    dims = dict(hidden=1024, layers=24, heads=16, inter=4096) if a.model == "large" else dict(hidden=768, layers=12, heads=12, inter=3072)
+    tiny_assets.build_model_dir(os.path.join(d, "enc"), **dims)
+    rng = np.random.default_rng(0)
+    folder = os.path.join(d, "data")
+    os.makedirs(folder)
+
+    def sentence(i):
+        words = [str(w) for w in rng.choice(tiny_assets.WORDS, size=12)]
+        lines = ["# id s%d" % i] + ["%s _ _ %s" % (w, "B-LOC" if k == 3 else "O") for k, w in enumerate(words)]
+        lines.append("<EOS> B-X B-X B-X")
+        lines += ["%s B-X B-X B-X" % w for w in rng.choice(tiny_assets.WORDS, size=int(rng.integers(96, 104)))]
+        return "\n".join(lines) + "\n\n"
+
+    for name, k in (("train.txt", a.sentences), ("dev.txt", 32), ("test.txt", 32)):
+        with open(os.path.join(folder, name), "w") as f:
+            for i in range(k):
+                f.write(sentence(i))
+    cc = ColumnCorpus(folder, {0: "text", 1: "pos", 2: "upos", 3: "ner"}, tag_to_bioes="ner", comment_symbol="# id")
+    td = cc.make_tag_dictionary("ner")
+    from flair.list_data import ListCorpus
+    corpus = ListCorpus(train=[cc.train], dev=[cc.dev], test=[cc.test], targets=["ColumnCorpus-SYN"])
+    emb = TransformerWordEmbeddings(model=os.path.join(d, "enc"), layers="-1", pooling_operation="first", fine_tune=True)
+    toks = [emb.tokenize_sentence(s) for s in list(cc.train)[:64]]
+    lens = [len(t[0][0]) for t in toks]
+    assert max(len(t[0]) for t in toks) == 1, "synthetic sentences must fit one window for this measurement"
+    tagger = FastSequenceTagger(hidden_size=256, embeddings=emb, tag_dictionary=td, tag_type="ner", use_crf=True, use_rnn=False,
+                                remove_x=True, sentence_loss=True, word_dropout=0.1, dropout=0.0, locked_dropout=0.0)
+    trainer = ModelFinetuner(tagger, None, corpus, config={}, distill_mode=False, sentence_level_batch=True)
+    out = {}
+    if os.environ.get("KBNER_PROFILE"):
+        import cProfile
+        import pstats
+        from flair.custom_data_loader import ColumnDataLoader
+        dl = ColumnDataLoader(list(cc.train), a.batch, sentence_level_batch=True)
+        dl.assign_tags("ner", td)
+        tagger.train()
+        for bi in range(4):
+            tagger.forward_backward(dl[bi], loss_scale=0.25)
+        torch.cuda.synchronize()
+        pr = cProfile.Profile()
+        pr.enable()
+        t0 = time.perf_counter()
+        for bi in range(4, 12):
+            tagger.forward_backward(dl[bi], loss_scale=0.25)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        pr.disable()
+        print("forward_backward: %.1f ms per batch of %d" % (dt / 8 * 1e3, a.batch))
+        pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
+        return
+    for epochs in (1, 2):  # epoch 1 warms up (tokenizer cache, buffers); report the second epoch's rate
+        t0 = time.perf_counter()
+        trainer.train(os.path.join(d, "out%d" % epochs), learning_rate=5e-6, mini_batch_size=a.batch, max_epochs=1, lr_rate=10000,
+                      gradient_accumulation_steps=a.accum, embeddings_storage_mode="none", fine_tune_mode=True,
+                      save_final_model=False, train_with_dev=False, monitor_test=False)
+        torch.cuda.synchronize()
+        out[epochs] = time.perf_counter() - t0
+    print({"sub_tokens_per_sentence_mean": float(np.mean(lens)), "sentences": a.sentences, "micro_batch": a.batch, "accumulate": a.accum,
+           "epoch1_s": round(out[1], 2), "epoch2_s": round(out[2], 2),
+           "epoch2_sentences_per_s_incl_dev_eval": round(a.sentences / out[2], 1)})
+
+
+if __name__ == "__main__":
+    main()
