@@ -345,15 +345,15 @@ class Tagger:
             p = "l%d." % l
             x = ac.x[l]
             d_att, d_o, d_f = d_layers[l]
-            ops.gemm(GEMM_NT, x, a.bf(p + "qkv.weight"), Mp, 3 * H, H, C=ac.qkv[l], bias=a.param(p + "qkv.bias"), epi=EPI_BIAS)
+            ops.gemm(GEMM_NT, x, a.bf(p + "qkv.weight"), Mp, 3 * H, H, C=ac.qkv[l], bias=a.param(p + "qkv.bias"), epi=EPI_BIAS, occupancy=True)
             ops.attn_fwd(ac.qkv[l], maskbias, ac.ctx[l], ac.lse[l], B, S, H, A, drop=d_att)
             ops.gemm(GEMM_NT, ac.ctx[l], a.bf(p + "o.weight"), Mp, H, H, C=ac.h1[l], bias=a.param(p + "o.bias"), addend=x,
-                     epi=EPI_BIAS | EPI_ADD, drop=d_o)
+                     epi=EPI_BIAS | EPI_ADD, drop=d_o, occupancy=True)
             ops.ln_fwd(ac.h1[l], a.param(p + "ln1.g"), a.param(p + "ln1.b"), eps, ac.x1[l], ac.st1[l][0], ac.st1[l][1])
             ops.gemm(GEMM_NT, ac.x1[l], a.bf(p + "ffn1.weight"), Mp, F_, H, C=ac.act[l], out2=ac.dact[l],
-                     bias=a.param(p + "ffn1.bias"), epi=EPI_BIAS | EPI_GELU)
+                     bias=a.param(p + "ffn1.bias"), epi=EPI_BIAS | EPI_GELU, occupancy=True)
             ops.gemm(GEMM_NT, ac.act[l], a.bf(p + "ffn2.weight"), Mp, H, F_, C=ac.h2[l], bias=a.param(p + "ffn2.bias"),
-                     addend=ac.x1[l], epi=EPI_BIAS | EPI_ADD, drop=d_f)
+                     addend=ac.x1[l], epi=EPI_BIAS | EPI_ADD, drop=d_f, occupancy=True)
             ops.ln_fwd(ac.h2[l], a.param(p + "ln2.g"), a.param(p + "ln2.b"), eps, ac.x[l + 1], ac.st2[l][0], ac.st2[l][1])
         self._enc_saved = (ids, pos_ids, maskbias, B, S, d_emb, d_layers)
         return ac.x[L]
@@ -382,23 +382,23 @@ class Tagger:
                        a.grad(p + "ln2.b"), a.grad(p + "ffn2.bias"), dhm=dhm if d_f[1] else None, drop=d_f)
             # FFN down dgrad: dpre = (dh W2) * gelu'(pre)   (the derivative itself was saved by the forward epilogue)
             # (its column sums = d ffn1.bias are accumulated by the same epilogue when the 256^2 kernel runs)
-            fused = Mp % 256 == 0 and F_ % 256 == 0
+            fused = ops.uses_256(Mp, F_, occupancy=True)
             ops.gemm(GEMM_NN, dhm, a.bf(p + "ffn2.weight"), Mp, F_, H, C=dpre, aux=ac.dact[l],
-                     epi=EPI_DGELU | (EPI_COLSUM if fused else 0), colsum=a.grad(p + "ffn1.bias") if fused else None)
+                     epi=EPI_DGELU | (EPI_COLSUM if fused else 0), colsum=a.grad(p + "ffn1.bias") if fused else None, occupancy=True)
             # FFN up
             if not fused:
                 ops.colsum(dpre, a.grad(p + "ffn1.bias"))
-            ops.gemm(GEMM_NN, dpre, a.bf(p + "ffn1.weight"), Mp, H, F_, C=ac.dx1, addend=dh, epi=EPI_ADD)
+            ops.gemm(GEMM_NN, dpre, a.bf(p + "ffn1.weight"), Mp, H, F_, C=ac.dx1, addend=dh, epi=EPI_ADD, occupancy=True)
             # LN1 backward; fused: d o.bias
             ops.ln_bwd(ac.dx1, ac.h1[l], ac.st1[l][0], ac.st1[l][1], a.param(p + "ln1.g"), dh1, a.grad(p + "ln1.g"),
                        a.grad(p + "ln1.b"), a.grad(p + "o.bias"), dhm=dh1m if d_o[1] else None, drop=d_o)
             # attention output projection
-            ops.gemm(GEMM_NN, dh1m, a.bf(p + "o.weight"), Mp, H, H, C=ac.dctx)
+            ops.gemm(GEMM_NN, dh1m, a.bf(p + "o.weight"), Mp, H, H, C=ac.dctx, occupancy=True)
             # attention core (+ d qkv.bias = column sums of dqkv, accumulated inside the kernels)
             ops.attn_bwd(ac.qkv[l], ac.ctx[l], ac.dctx, maskbias, ac.lse[l], ac.dws, dqkv, B, S, H, A, drop=d_att,
                          dbias=a.grad(p + "qkv.bias"))
             # QKV projection
-            ops.gemm(GEMM_NN, dqkv, a.bf(p + "qkv.weight"), Mp, H, 3 * H, C=ac.dx, addend=dh1, epi=EPI_ADD)
+            ops.gemm(GEMM_NN, dqkv, a.bf(p + "qkv.weight"), Mp, H, 3 * H, C=ac.dx, addend=dh1, epi=EPI_ADD, occupancy=True)
             # weight gradients dW += dY^T X are deferred and launched for WGRAD_GROUP layers at once
             # (no split-K, no atomics; the dY buffers rotate so they stay live until the group is flushed)
             pending += [(dhm, ac.act[l], H, F_, p + "ffn2.weight"), (dpre, ac.x1[l], F_, H, p + "ffn1.weight"),

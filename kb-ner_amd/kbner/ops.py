@@ -170,6 +170,16 @@ def embed_ln_bwd(dy, h0, mean, rstd, gamma, ids, pos_ids, dgamma, dbeta, dword, 
 
 # ---------------------------------------------------------------- GEMM
 FORCE_128 = False  # tests: force the 128^2 kernel
+# below this many 256x256 tiles a GEMM goes to the 128x128 kernel (4x the tiles): a small micro-batch leaves most of the
+# 256 CUs idle on the big tile
+MIN_TILES_256 = int(__import__("os").environ.get("KBNER_MIN_TILES_256", "100"))
+
+
+def uses_256(M, N, occupancy=False):
+    """whether gemm() runs an (M, N) problem on the 256x256 persistent kernel; occupancy=True (the engine's forward / dgrad
+    calls) additionally sends problems with fewer than MIN_TILES_256 big tiles to the 128x128 kernel"""
+    ok = M % 256 == 0 and N % 256 == 0 and not FORCE_128
+    return ok and (not occupancy or (M // 256) * (N // 256) >= MIN_TILES_256)
 GEMM_HOOK = None  # bench.py sets this to a list to time every GEMM launch with HIP events on the launch stream
 
 
@@ -204,11 +214,11 @@ def gemm_grouped(layout, problems):
 
 
 def gemm(layout, A, B, M, N, K, C=None, C32=None, bias=None, addend=None, aux=None, out2=None, epi=0, splitk=1, alpha=1.0,
-         lda=None, ldb=None, colsum=None, drop=NO_DROP):
+         lda=None, ldb=None, colsum=None, drop=NO_DROP, occupancy=False):
     """C[M,N] (bf16) or C32[M,N] += (fp32).  A/B are 2-D bf16 tensors in their memory layouts.
     Shapes divisible by 256 go to the 256^2 8-wave kernel, others to the 128^2 kernel."""
     _chk(A, BF16, "A"); _chk(B, BF16, "B")
-    if M % 256 == 0 and N % 256 == 0 and splitk == 1 and lda is None and ldb is None and not FORCE_128:
+    if uses_256(M, N, occupancy) and splitk == 1 and lda is None and ldb is None:
         return gemm_grouped(layout, [make_problem(A, B, M, N, K, C, C32, bias, addend, aux, out2, epi, alpha, colsum, drop)])
     if drop[1]:
         epi |= L.EPI_DROP
