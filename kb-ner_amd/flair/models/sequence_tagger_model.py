@@ -190,13 +190,15 @@ class SequenceTagger(flair.nn.Model):
         self.mask = torch.from_numpy(hb["keep"].astype(np.float32)).to(flair.device)
         return self.engine.forward_loss(db, backward=False)
 
-    def forward_backward(self, data_points, loss_scale=1.0):
-        """forward_loss + backward into the gradient arena (what `loss.backward()` does at finetune_trainer.py:957)"""
+    def forward_backward(self, data_points, loss_scale=1.0, sentence_weights=None):
+        """forward_loss + backward into the gradient arena (what `loss.backward()` does at finetune_trainer.py:957).
+        sentence_weights (optional, one per sentence) replace the 1/B of the batch mean: see ModelFinetuner.train's
+        accumulation-group fusion."""
         self.embeddings.embed(data_points)
         hb, db = self._device_batch(data_points)
         self._last = (hb, db)
         self.mask = torch.from_numpy(hb["keep"].astype(np.float32)).to(flair.device)
-        return self.engine.forward_loss(db, loss_scale=loss_scale, backward=True)
+        return self.engine.forward_loss(db, loss_scale=loss_scale, backward=True, weights=sentence_weights)
 
     def _calculate_loss(self, features, sentences, mask):
         """CRF NLL of given emissions [B,n,T] (mean over sentences); narrows self.mask to the non-S-X tokens like the

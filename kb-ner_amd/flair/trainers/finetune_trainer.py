@@ -63,7 +63,12 @@ class ModelFinetuner:
               use_warmup: bool = False, gradient_accumulation_steps: int = 1, lr_rate: int = 1, sort_data: bool = True,
               fine_tune_mode: bool = False, save_finetuned_embedding: bool = False, one_by_one: bool = False,
               select_model_by_macro: bool = False, max_epochs_without_improvement: int = 100, log_interval: int = None,
-              **kwargs) -> dict:
+              fuse_accumulation: bool = True, **kwargs) -> dict:
+        """fuse_accumulation (not in the reference): the micro-batches of one gradient-accumulation group are encoded as ONE
+        batch whose sentences carry the weights 1/(accumulate * |their micro-batch|) -- the same loss and gradient as
+        `loss / accumulate` summed over the group (finetune_trainer.py:939-957), but the KB-NER YAMLs' `mini_batch_size: 1,
+        gradient_accumulation_steps: 4` then runs 4 sentences per launch instead of 1 (3.6x on one MI355X).  Dropout streams
+        differ (WordDropout positions are shared by the fused batch), nothing else does."""
         from kbner import dp
         from kbner.engine import FusedAdamW
         base_path = Path(base_path)
@@ -130,19 +135,31 @@ class ModelFinetuner:
                 mine = dp.shard_indices(len(loader), dp.rank(), W)
                 losses, seen, micro = [], 0, 0
                 t_ep = t_log = time.time()
+                fuse = bool(fuse_accumulation) and accum > 1
+                group = []
                 for local_no, bi in enumerate(mine):
                     batch = loader[bi]
-                    losses.append(self.model.forward_backward(batch, loss_scale=1.0 / accum))
                     seen += len(batch)
                     micro += 1
-                    store_embeddings(batch, embeddings_storage_mode)
                     last = local_no == len(mine) - 1
+                    if fuse:
+                        group.append(batch)
+                        if micro == accum or last:
+                            sents = [sn for bt in group for sn in bt]
+                            wts = [1.0 / (accum * len(bt)) for bt in group for _ in bt]
+                            fused = self.model.forward_backward(sents, loss_scale=1.0, sentence_weights=wts)
+                            # log the mean of the group's micro-batch losses, once per micro-batch, like the unfused loop
+                            losses += [fused * (float(accum) / len(group))] * len(group)
+                            group = []
+                    else:
+                        losses.append(self.model.forward_backward(batch, loss_scale=1.0 / accum))
+                    store_embeddings(batch, embeddings_storage_mode)
                     if micro == accum or last:
                         scale = dp.all_reduce_sum_(self.model.engine.arena.g)
                         # a short final group keeps the 1/accum scaling, exactly like the reference (:939-946,1007)
                         opt.step(grad_scale=scale)
                         micro = 0
-                    if (local_no + 1) % log_every == 0 and is_main:
+                    if (local_no + 1) % log_every == 0 and is_main and len(losses) >= 1:
                         cur = float(torch.stack(losses[-log_every:]).mean())
                         dt = time.time() - t_log
                         log.info("epoch %d - iter %d/%d - loss %.8f - samples/sec: %.2f (x%d ranks)", epoch + 1, local_no + 1,

@@ -428,10 +428,12 @@ class Tagger:
         em = ops.head_fwd(pooled, self.arena.param("linear.weight"), self.arena.param("linear.bias"))
         return em.view(B, n, self.T), pooled
 
-    def forward_loss(self, batch, loss_scale=1.0, backward=True):
+    def forward_loss(self, batch, loss_scale=1.0, backward=True, weights=None):
         """One micro-batch: encoder -> kept-token gather -> head -> CRF NLL (mean over sentences,
         sequence_tagger_model.py:2499-2506) and, if `backward`, the full backward pass accumulating
-        loss_scale * d loss into arena.g.  Returns the loss as a 0-d device tensor (no host sync)."""
+        loss_scale * d loss into arena.g.  Returns the loss as a 0-d device tensor (no host sync).
+        weights: optional f32[B] per-sentence weights replacing the 1/B of the mean (the trainer uses it to run the
+        micro-batches of one gradient-accumulation group as ONE batch with weights 1/(accumulate * |micro-batch|))."""
         B, S = batch["B"], batch["S"]
         R = batch.get("R", B)  # encoder rows (> B when long sentences were split into sliding windows)
         hidden = self.encoder_forward(batch["ids"], batch["pos_ids"], batch["maskbias"], R, S)
@@ -449,7 +451,12 @@ class Tagger:
         a = self.arena
         trans = a.param("transitions")
         logz, gold, alpha = ops.crf_nll_fwd(em, trans, batch["ctags"], batch["clens"], self.start, self.stop)
-        w = torch.full((B,), 1.0 / B, dtype=F32, device=self.device)
+        if weights is None:
+            w = torch.full((B,), 1.0 / B, dtype=F32, device=self.device)
+        else:
+            w = torch.as_tensor(weights, dtype=F32, device=self.device).contiguous()
+            if w.numel() != B:
+                raise ValueError("weights must hold one value per sentence")
         loss = torch.empty((1,), dtype=F32, device=self.device)
         ops.wdiff_sum(logz, gold, w, loss)
         if backward:

@@ -232,3 +232,33 @@ def test_full_size_step_vs_oracle():
     assert r["grad_min_cos"] > 0.95 and r["grad_worst_rel"] < 0.3, r
     assert r["grad_linear.weight"] < 5e-2 and r["grad_transitions"] < 5e-2, r
     assert r["viterbi_equal"], r
+
+
+def test_accumulation_fusion_is_the_same_gradient(workdir):
+    """ModelFinetuner's fuse_accumulation: the micro-batches of one accumulation group run as one weighted batch == the
+    per-micro-batch `loss / accumulate` backward passes summed (finetune_trainer.py:939-957)."""
+    from flair.config_parser import ConfigParser
+    from flair.custom_data_loader import ColumnDataLoader
+    from flair.utils.from_params import Params
+    torch.manual_seed(3)
+    cp = ConfigParser(Params.from_file(str(workdir / "cfg.yaml")))
+    student = cp.create_student()
+    student.train()
+    student.engine.word_dropout = 0.0                      # the only stochastic site of the tiny config (HF dropout is 0)
+    dl = ColumnDataLoader(list(cp.corpus.train), 1, sentence_level_batch=True)     # the YAMLs' mini_batch_size: 1
+    dl.assign_tags("ner", cp.tag_dictionary)
+    group = [dl[3], dl[11], dl[17], dl[29]]                # different lengths
+    accum = len(group)
+    g = student.engine.arena.g
+    g.zero_()
+    l_un = [float(student.forward_backward(b, loss_scale=1.0 / accum)) for b in group]
+    g_unfused = g.clone()
+    g.zero_()
+    sents = [s for b in group for s in b]
+    l_f = float(student.forward_backward(sents, loss_scale=1.0, sentence_weights=[1.0 / (accum * len(b)) for b in group for _ in b]))
+    torch.cuda.synchronize()
+    assert abs(l_f - sum(l_un) / accum) < 2e-2 * abs(l_f)
+    a, b = g.double(), g_unfused.double()
+    cos = float((a @ b) / (a.norm() * b.norm()))
+    assert cos > 0.995, cos                                # bf16 kernels, different padding: not bit-identical
+    assert abs(float(a.norm() / b.norm()) - 1.0) < 2e-2
