@@ -110,6 +110,7 @@ int kbner_gemm_bf16(int layout, const kbner_bf16* A, int lda, const kbner_bf16* 
 /* Grouped GEMM on the 256x256x64 / 8-wave kernel: up to 16 problems of one layout per launch (the weight-
  * gradient GEMMs of four encoder layers = 768 tiles fill the chip without split-K).  Per problem M,N % 256 == 0, K % 64 == 0. */
 #define KBNER_EPI_RMW32 32 /* C32 += result by non-atomic 16-byte read-modify-write */
+#define KBNER_EPI_STORE32 256 /* C32 = result, fp32 plain stores (must be the only flag): one split-K slab */
 #define KBNER_EPI_COLSUM 64 /* also accumulate the output's column sums (the producing layer's bias gradient) */
 typedef struct kbner_gemm_problem {
   const kbner_bf16* A;
@@ -128,6 +129,11 @@ typedef struct kbner_gemm_problem {
   uint32_t drop_seed, drop_thresh; /* KBNER_EPI_DROP */
 } kbner_gemm_problem;
 int kbner_gemm_bf16_grouped(int layout, int nprob, const kbner_gemm_problem* probs, void* stream);
+/* Split-K for small micro-batches (a few dozen output tiles, long K): the K range is cut into `splits` problems of ONE grouped
+ * launch, each writing an fp32 slab ws[s] (f32[M,N], KBNER_EPI_STORE32); this folds them:
+ * C = bf16(dropout(sum_s ws[s] + bias) + addend).  bias / addend nullable, drop_thresh 0 = no dropout. */
+int kbner_splitk_finish(const float* ws, int splits, const float* bias, const kbner_bf16* addend, int ldadd, kbner_bf16* C, int ldc,
+                        int M, int N, uint32_t drop_seed, uint32_t drop_thresh, void* stream);
 
 /* ---------------- fused self-attention (transformers BertSelfAttention), head_dim 64, S<=512 ---------------- */
 /* drop_*: attention-probability dropout, element (i,j) = (bh*S + query, bh*S + key) with bh = b*A + head */

@@ -18,6 +18,7 @@
 #define EPI_ATOMIC32 16
 #define EPI_RMW32 32  // C32[m,n] += result, non-atomic 16-byte RMW (each output element owned by one lane)
 #define EPI_COLSUM 64  // colsum[n] += sum_m out[m,n] (bias gradient of the producing layer), fp32 atomics, 2 per column per tile
+#define EPI_STORE32 256  // C32[m,n] = result (fp32, plain stores): one split-K slab, summed by kbner_splitk_finish
 #define EPI_DROP 128   // dropout on (acc*alpha + bias) BEFORE the residual add (BertSelfOutput / BertOutput); not with COLSUM
 
 #define G2_MAXP 16
@@ -229,7 +230,7 @@ static __device__ __forceinline__ void epilogue256(const GemmProblem& g, f4v (&a
   // instruction covers 16 rows x 64 B, which the memory pipe retires at ~34 GB/s per CU; re-read as 8 rows x 128 B (8
   // consecutive lanes per cache line) it retires at ~98 GB/s (tools/micro/store_pattern.hip)
   // (specialised forward epilogues only: on the dgrad layout the direct stores measured marginally better in situ)
-  const bool lds_out = EPI_CT >= 0 && !(EPI_CT & (EPI_RMW32 | EPI_ATOMIC32));
+  const bool lds_out = EPI_CT >= 0 && !(EPI_CT & (EPI_RMW32 | EPI_ATOMIC32 | EPI_STORE32));
   const int wr_row = lane & 15;
   unsigned char* scr_w[2] = {scr + wr_row * 128 + (((0 * 4 + gq) ^ (wr_row & 7)) << 4),
                              scr + wr_row * 128 + (((1 * 4 + gq) ^ (wr_row & 7)) << 4)};
@@ -264,6 +265,12 @@ static __device__ __forceinline__ void epilogue256(const GemmProblem& g, f4v (&a
       for (int r = 0; r < 4; ++r) {
         v[r] = acc[mi][2 * q][r] * alpha;
         v[4 + r] = acc[mi][2 * q + 1][r] * alpha;
+      }
+      if (epi & EPI_STORE32) {
+        float4* c = reinterpret_cast<float4*>(g.C32 + (size_t)m * g.ldc32 + n);
+        c[0] = make_float4(v[0], v[1], v[2], v[3]);
+        c[1] = make_float4(v[4], v[5], v[6], v[7]);
+        continue;
       }
       if (epi & EPI_RMW32) {
         float4* c = reinterpret_cast<float4*>(g.C32 + (size_t)m * g.ldc32 + n);
@@ -511,7 +518,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GroupArgs ga) {
   G2_T(2)
   ++tile_no;
   if (!has_next) break;
-  pend = (epi & EPI_ATOMIC32) ? 0 : ((epi & (EPI_GELU | EPI_RMW32)) ? 32 : 16);
+  pend = (epi & EPI_ATOMIC32) ? 0 : ((epi & (EPI_GELU | EPI_RMW32 | EPI_STORE32)) ? 32 : 16);
   id = id_next;
   }  // persistent tile loop
 }
@@ -580,7 +587,7 @@ int kbner_gemm_bf16_grouped(int layout, int nprob, const kbner_gemm_problem* pro
     const kbner_gemm_problem& s = probs[i];
     KBNER_CHECK_ARG(s.M > 0 && s.N > 0 && s.K > 0 && s.M % T2 == 0 && s.N % T2 == 0 && s.K % BK2 == 0);
     KBNER_CHECK_ARG(s.A != nullptr && s.B != nullptr && s.lda % 8 == 0 && s.ldb % 8 == 0);
-    if (s.epi & (EPI_ATOMIC32 | EPI_RMW32)) {
+    if (s.epi & (EPI_ATOMIC32 | EPI_RMW32 | EPI_STORE32)) {
       KBNER_CHECK_ARG(s.C32 != nullptr && s.ldc32 >= s.N && s.ldc32 % 4 == 0);
     } else {
       KBNER_CHECK_ARG(s.C != nullptr && s.ldc >= s.N && s.ldc % 8 == 0);
@@ -589,7 +596,8 @@ int kbner_gemm_bf16_grouped(int layout, int nprob, const kbner_gemm_problem* pro
     if (s.epi & EPI_ADD) KBNER_CHECK_ARG(s.addend != nullptr && s.ldadd % 8 == 0);
     if (s.epi & EPI_DGELU) KBNER_CHECK_ARG(s.aux != nullptr && s.ldaux % 8 == 0);
     if (s.epi & EPI_GELU) KBNER_CHECK_ARG(s.out2 != nullptr && s.ldout2 % 8 == 0);
-    if (s.epi & EPI_COLSUM) KBNER_CHECK_ARG(s.colsum != nullptr && !(s.epi & (EPI_ATOMIC32 | EPI_RMW32)));
+    if (s.epi & EPI_COLSUM) KBNER_CHECK_ARG(s.colsum != nullptr && !(s.epi & (EPI_ATOMIC32 | EPI_RMW32 | EPI_STORE32)));
+    if (s.epi & EPI_STORE32) KBNER_CHECK_ARG(s.epi == EPI_STORE32);
     if (s.epi & EPI_DROP) KBNER_CHECK_ARG(!(s.epi & (EPI_ATOMIC32 | EPI_RMW32 | EPI_COLSUM | EPI_GELU | EPI_DGELU)));
     GemmProblem& d = ga.p[i];
     d.A = s.A; d.B = s.B; d.C = s.C; d.C32 = s.C32; d.bias = s.bias; d.addend = s.addend; d.aux = s.aux; d.out2 = s.out2; d.colsum = s.colsum;

@@ -196,6 +196,7 @@ class _Acts:
         self.dws = z(B, A, S, dt=F32)
         self._z, self._H = z, H
         self.dhm = self.dh1m = None
+        self.splitk_ws = None  # f32 [4, Mp, H] split-K slabs, allocated on first use (small micro-batches only)
 
     def drop_buffers(self):
         """masked copies of dh / dh1 (the dY of the two GEMMs whose outputs were dropped); allocated on first training use"""
@@ -330,6 +331,27 @@ class Tagger:
         self._acts[key] = ac
         return ac
 
+    SPLITK_MAX_TILES = 64  # outputs with at most this many 256x256 tiles split a long K (small micro-batches)
+
+    def _long_k_gemm(self, layout, A, W, Mp, N, K, C, ac, bias=None, addend=None, drop=ops.NO_DROP):
+        """C = bf16(dropout(A.W + bias) + addend) for the three K >= 3H GEMMs of a layer (FFN-down forward, its two dgrad
+        siblings).  With a small micro-batch the [Mp, H] output has a few dozen tiles, each a serial chain of K/64 DMA
+        round trips (86 us at K=4096 whatever Mp): K is then cut over up to 4 workgroups per tile (ops.gemm_splitk)."""
+        tiles = (Mp // 256) * (N // 256) if Mp % 256 == 0 and N % 256 == 0 else 0
+        splits = 0
+        if 0 < tiles <= self.SPLITK_MAX_TILES and not ops.FORCE_128:
+            for sp in (4, 3, 2):
+                if K % (64 * sp) == 0 and K // sp >= 512:
+                    splits = sp
+                    break
+        if splits:
+            if ac.splitk_ws is None:
+                ac.splitk_ws = torch.empty((4, Mp, N), dtype=F32, device=self.device)
+            ops.gemm_splitk(layout, A, W, Mp, N, K, splits, ac.splitk_ws, C, bias=bias, addend=addend, drop=drop)
+        else:
+            epi = (EPI_BIAS if bias is not None else 0) | (EPI_ADD if addend is not None else 0)
+            ops.gemm(layout, A, W, Mp, N, K, C=C, bias=bias, addend=addend, epi=epi, drop=drop, occupancy=True)
+
     # ---------------------------------------------------------------- encoder
     def encoder_forward(self, ids, pos_ids, maskbias, B, S):
         """ids/pos_ids i32[Mp], maskbias f32[B,S] -> last hidden state bf16 [Mp,H] (rows >= B*S are padding)."""
@@ -352,8 +374,8 @@ class Tagger:
             ops.ln_fwd(ac.h1[l], a.param(p + "ln1.g"), a.param(p + "ln1.b"), eps, ac.x1[l], ac.st1[l][0], ac.st1[l][1])
             ops.gemm(GEMM_NT, ac.x1[l], a.bf(p + "ffn1.weight"), Mp, F_, H, C=ac.act[l], out2=ac.dact[l],
                      bias=a.param(p + "ffn1.bias"), epi=EPI_BIAS | EPI_GELU, occupancy=True)
-            ops.gemm(GEMM_NT, ac.act[l], a.bf(p + "ffn2.weight"), Mp, H, F_, C=ac.h2[l], bias=a.param(p + "ffn2.bias"),
-                     addend=ac.x1[l], epi=EPI_BIAS | EPI_ADD, drop=d_f, occupancy=True)
+            self._long_k_gemm(GEMM_NT, ac.act[l], a.bf(p + "ffn2.weight"), Mp, H, F_, ac.h2[l], ac, bias=a.param(p + "ffn2.bias"),
+                              addend=ac.x1[l], drop=d_f)
             ops.ln_fwd(ac.h2[l], a.param(p + "ln2.g"), a.param(p + "ln2.b"), eps, ac.x[l + 1], ac.st2[l][0], ac.st2[l][1])
         self._enc_saved = (ids, pos_ids, maskbias, B, S, d_emb, d_layers)
         return ac.x[L]
@@ -388,7 +410,7 @@ class Tagger:
             # FFN up
             if not fused:
                 ops.colsum(dpre, a.grad(p + "ffn1.bias"))
-            ops.gemm(GEMM_NN, dpre, a.bf(p + "ffn1.weight"), Mp, H, F_, C=ac.dx1, addend=dh, epi=EPI_ADD, occupancy=True)
+            self._long_k_gemm(GEMM_NN, dpre, a.bf(p + "ffn1.weight"), Mp, H, F_, ac.dx1, ac, addend=dh)
             # LN1 backward; fused: d o.bias
             ops.ln_bwd(ac.dx1, ac.h1[l], ac.st1[l][0], ac.st1[l][1], a.param(p + "ln1.g"), dh1, a.grad(p + "ln1.g"),
                        a.grad(p + "ln1.b"), a.grad(p + "o.bias"), dhm=dh1m if d_o[1] else None, drop=d_o)
@@ -398,7 +420,7 @@ class Tagger:
             ops.attn_bwd(ac.qkv[l], ac.ctx[l], ac.dctx, maskbias, ac.lse[l], ac.dws, dqkv, B, S, H, A, drop=d_att,
                          dbias=a.grad(p + "qkv.bias"))
             # QKV projection
-            ops.gemm(GEMM_NN, dqkv, a.bf(p + "qkv.weight"), Mp, H, 3 * H, C=ac.dx, addend=dh1, epi=EPI_ADD, occupancy=True)
+            self._long_k_gemm(GEMM_NN, dqkv, a.bf(p + "qkv.weight"), Mp, H, 3 * H, ac.dx, ac, addend=dh1)
             # weight gradients dW += dY^T X are deferred and launched for WGRAD_GROUP layers at once
             # (no split-K, no atomics; the dY buffers rotate so they stay live until the group is flushed)
             pending += [(dhm, ac.act[l], H, F_, p + "ffn2.weight"), (dpre, ac.x1[l], F_, H, p + "ffn1.weight"),

@@ -188,11 +188,13 @@ def _addr(t):
 
 
 def make_problem(A, B, M, N, K, C=None, C32=None, bias=None, addend=None, aux=None, out2=None, epi=0, alpha=1.0, colsum=None,
-                 drop=NO_DROP):
+                 drop=NO_DROP, a_off=0, b_off=0):
+    """a_off / b_off: element offsets into A / B (a K slice of a split-K problem keeps the parent's leading dimensions)"""
     _chk(A, BF16, "A"); _chk(B, BF16, "B")
     if drop[1]:
         epi |= L.EPI_DROP
-    return L.GemmProblem(_addr(A), _addr(B), _addr(C), _addr(C32), _addr(bias), _addr(addend), _addr(aux), _addr(out2), _addr(colsum),
+    return L.GemmProblem(A.data_ptr() + 2 * a_off, B.data_ptr() + 2 * b_off, _addr(C), _addr(C32), _addr(bias), _addr(addend), _addr(aux),
+                         _addr(out2), _addr(colsum),
                          M, N, K, A.shape[1], B.shape[1], C.shape[1] if C is not None else 0,
                          C32.shape[1] if C32 is not None else 0, addend.shape[1] if addend is not None else 0,
                          aux.shape[1] if aux is not None else 0, out2.shape[1] if out2 is not None else 0, epi, alpha,
@@ -240,6 +242,22 @@ def gemm(layout, A, B, M, N, K, C=None, C32=None, bias=None, addend=None, aux=No
     if hook is not None:
         ev1.record()
         hook.append((ev0, ev1, 2.0 * M * N * K, layout))
+
+
+def gemm_splitk(layout, A, B, M, N, K, splits, ws, C, bias=None, addend=None, drop=NO_DROP):
+    """C = bf16(dropout(A.B + bias) + addend) with K cut into `splits` problems of one grouped launch (fp32 slabs in ws
+    f32[splits, M, N]) + the finish pass.  For NT / NN layouts whose output has too few tiles to fill the chip."""
+    if layout not in (L.GEMM_NT, L.GEMM_NN) or K % (64 * splits) or M % 256 or N % 256:
+        raise L.KbnerError("gemm_splitk: unsupported shape / layout")
+    _chk(ws, F32, "ws")
+    Ks = K // splits
+    probs = []
+    for s in range(splits):
+        b_off = s * Ks if layout == L.GEMM_NT else s * Ks * B.shape[1]   # NT: B[N,K] rows; NN: Bmem[K,N] rows
+        probs.append(make_problem(A, B, M, N, Ks, C32=ws[s], epi=L.EPI_STORE32, a_off=s * Ks, b_off=b_off))
+    gemm_grouped(layout, probs)
+    L.call("kbner_splitk_finish", ptr(ws), splits, ptr(bias), ptr(addend), addend.shape[1] if addend is not None else 0, ptr(C),
+           C.shape[1], M, N, drop[0], drop[1], stream_ptr())
 
 
 # ---------------------------------------------------------------- attention

@@ -105,6 +105,28 @@ def check_gemm(layout, M, N, K, epi=0, splitk=1, seed=0, drop_p=0.0):
     return err
 
 
+def check_gemm_splitk(layout, M, N, K, splits, seed=0, drop_p=0.0):
+    """split-K (fp32 slabs + finish pass) vs fp64: C = dropout(A.B^T + bias) + addend"""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    A = (torch.randn(M, K, generator=g) * 0.5).to(BF16)
+    Bm = (torch.randn(N, K, generator=g) * 0.5).to(BF16)
+    bias = torch.randn(N, generator=g)
+    add = torch.randn(M, N, generator=g).to(BF16)
+    ref = A.double() @ Bm.double().t() + bias.double()[None, :]
+    drop = ops.NO_DROP
+    if drop_p:
+        drop = (777 + seed, ops.drop_thresh(drop_p))
+        ref = ref * ops.dropout_mask(1, M, N, *drop)[0].cpu().double()
+    ref = ref + add.double()
+    Ad = A.to(DEV)
+    Bd = Bm.to(DEV) if layout == GEMM_NT else Bm.t().contiguous().to(DEV)
+    ws = torch.empty(4, M, N, dtype=F32, device=DEV)
+    C = torch.zeros(M, N, dtype=BF16, device=DEV)
+    ops.gemm_splitk(layout, Ad, Bd, M, N, K, splits, ws, C, bias=bias.to(DEV), addend=add.to(DEV), drop=drop)
+    torch.cuda.synchronize()
+    return rel_l2(C.cpu().float(), ref)
+
+
 def check_gemm_grouped(seed=0):
     """four TN (wgrad) problems of different shapes in one grouped launch, RMW32 epilogue."""
     g = torch.Generator(device="cpu").manual_seed(seed)

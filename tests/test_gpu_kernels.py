@@ -279,3 +279,10 @@ def test_optimizer_steps_vs_oracle_trainer(st):
     assert r["loss_decreased"], r
     assert r["delta_cos_min"] > 0.85, r
     assert r["transitions_maxabs"] < 0.25 * r["transitions_moved"], r
+
+
+@pytest.mark.parametrize("layout,M,N,K,splits,drop_p", [(0, 512, 256, 1024, 4, 0.0), (1, 256, 512, 768, 3, 0.0), (0, 256, 256, 256, 2, 0.1),
+                                                         (1, 512, 1024, 4096, 4, 0.0)])
+def test_gemm_splitk(st, layout, M, N, K, splits, drop_p):
+    """small-micro-batch path: K cut into fp32 slabs by one grouped launch (KBNER_EPI_STORE32) + kbner_splitk_finish"""
+    assert st.check_gemm_splitk(layout, M, N, K, splits, drop_p=drop_p) < 6e-3
