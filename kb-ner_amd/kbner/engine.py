@@ -14,6 +14,7 @@ import math
 
 import torch
 
+from . import lib as L_
 from . import ops
 from .lib import EPI_ADD, EPI_ATOMIC32, EPI_BIAS, EPI_COLSUM, EPI_DGELU, EPI_GELU, EPI_RMW32, GEMM_NN, GEMM_NT, GEMM_TN
 
@@ -94,15 +95,23 @@ class Arena:
             n *= s
         return buf[off:off + n].view(shape)
 
+    # views are created once per (buffer, name): the engine asks for ~700 of them per micro-batch
+    def _cached(self, tag, buf, name):
+        cache = self.__dict__.setdefault("_views", {})
+        v = cache.get((tag, name))
+        if v is None:
+            v = cache[(tag, name)] = self._view(buf, name)
+        return v
+
     def param(self, name):
-        return self._view(self.p, name)
+        return self._cached("p", self.p, name)
 
     def grad(self, name):
-        return self._view(self.g, name)
+        return self._cached("g", self.g, name)
 
     def bf(self, name):
         assert self.offsets[name] < self.n_shadow
-        return self._view(self.shadow, name)
+        return self._cached("s", self.shadow, name)
 
     def refresh_shadow(self):
         if self.n_shadow:
@@ -456,6 +465,10 @@ class Tagger:
         loss_scale * d loss into arena.g.  Returns the loss as a 0-d device tensor (no host sync).
         weights: optional f32[B] per-sentence weights replacing the 1/B of the mean (the trainer uses it to run the
         micro-batches of one gradient-accumulation group as ONE batch with weights 1/(accumulate * |micro-batch|))."""
+        with L_.stream_scope():
+            return self._forward_loss(batch, loss_scale, backward, weights)
+
+    def _forward_loss(self, batch, loss_scale, backward, weights):
         B, S = batch["B"], batch["S"]
         R = batch.get("R", B)  # encoder rows (> B when long sentences were split into sliding windows)
         hidden = self.encoder_forward(batch["ids"], batch["pos_ids"], batch["maskbias"], R, S)
