@@ -228,7 +228,10 @@ class Sentence:
         return [lab.value for lab in self.labels]
 
     # -- spans (flair/data.py:455-532)
-    def get_spans(self, tag_type: str, min_score: float = -1) -> List[Span]:
+    def get_spans(self, tag_type: str, min_score: float = -1, skip_class: str = None) -> List[Span]:
+        """skip_class (not in the reference): tokens of that class are treated like "O" -- they break spans exactly as their
+        own single-token spans would, but no Span object is built for them (evaluate() drops every X span of the
+        hundreds of S-X context tokens anyway)."""
         spans: List[Span] = []
         cur: List[Token] = []
         votes: Dict[str, float] = defaultdict(float)
@@ -250,6 +253,8 @@ class Sentence:
                 val = "O-"
             if val[:2] not in _BIOES:
                 val = "S-" + val           # a bare class name counts as a single-token span
+            if skip_class is not None and val[2:] == skip_class and val[:2] == "S-":
+                val = "O-"
             inside = val[:2] != "O-"
             opens = val[:2] in ("B-", "S-")
             if prev[:2] == "S-" and prev[2:] != val[2:] and inside:

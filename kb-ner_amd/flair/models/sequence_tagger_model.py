@@ -260,6 +260,14 @@ class SequenceTagger(flair.nn.Model):
             out.append([Label(p, c) for p, c in zip(path, cf)])
         return out, []
 
+    def _gold_x_token_ids(self, sentence):
+        """1-based token ids whose gold tag is an X tag (from the loader's tag-id row when present)"""
+        row = getattr(sentence, self.tag_type + "_tags", None)
+        if row is not None and self.x_idx is not None:
+            r = np.asarray(row)[:len(sentence)]
+            return set((np.nonzero(r == self.x_idx)[0] + 1).tolist())
+        return {t.idx for t in sentence.tokens if t.get_tag(self.tag_type).value.endswith("-X")}
+
     # ------------------------------------------------------------------ evaluation
     def evaluate(self, data_loader, out_path: Path = None, embeddings_storage_mode: str = "cpu", prediction_mode=False,
                  speed_test=False):
@@ -277,16 +285,20 @@ class SequenceTagger(flair.nn.Model):
             for sentence, sent_tags in zip(batch, tags):
                 for token, tag in zip(sentence.tokens, sent_tags):
                     token.add_tag_label("predicted", tag)
-                    lines.append("{} {} {} {}\n".format(token.text, token.get_tag(self.tag_type).value, tag.value, tag.score))
+                    if out_path is not None:
+                        lines.append("{} {} {} {}\n".format(token.text, token.get_tag(self.tag_type).value, tag.value, tag.score))
                 lines.append("\n")
             for sentence in batch:
-                gold = [(s.tag, str(s)) for s in sentence.get_spans(self.tag_type)]
-                pred = [(s.tag, str(s)) for s in sentence.get_spans("predicted")]
                 if self.remove_x:
-                    x_ids = {t.idx for t in sentence.tokens if t.get_tag(self.tag_type).value.endswith("-X")}
-                    gold = [g for g in gold if g[0] != "X"]
-                    pred = [p for p, sp in zip(pred, sentence.get_spans("predicted"))
-                            if p[0] != "X" and not any(t.idx in x_ids for t in sp.tokens)]
+                    # :2653-2672: gold X spans are dropped, predicted spans are dropped when they are X or touch a gold-X token.
+                    # The context tokens (hundreds of single-token S-X spans per sentence) never become Span objects here.
+                    x_ids = self._gold_x_token_ids(sentence)
+                    gold = [(s.tag, str(s)) for s in sentence.get_spans(self.tag_type, skip_class="X") if s.tag != "X"]
+                    pred = [(s.tag, str(s)) for s in sentence.get_spans("predicted", skip_class="X")
+                            if s.tag != "X" and not any(t.idx in x_ids for t in s.tokens)]
+                else:
+                    gold = [(s.tag, str(s)) for s in sentence.get_spans(self.tag_type)]
+                    pred = [(s.tag, str(s)) for s in sentence.get_spans("predicted")]
                 for tag, span in pred:
                     (metric.add_tp if (tag, span) in gold else metric.add_fp)(tag)
                 for tag, span in gold:

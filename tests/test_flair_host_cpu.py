@@ -259,3 +259,21 @@ def test_context_file_format_writer_validator_and_reader(tmp_path):
     bad.write_text("berlin _ _ B-LOC\n<EOS> B-X B-X B-X\nfoo _ _ O\n\n")
     with pytest.raises(cf.FormatError):
         cf.validate_file(str(bad))
+
+
+def test_get_spans_skip_class_equals_filtering():
+    """evaluate()'s remove_x shortcut: spans extracted with skip_class='X' == all spans with the X ones filtered out, for
+    gold-like rows (S-X context tail) and arbitrary predicted rows"""
+    rng = np.random.default_rng(4)
+    tags = ["O", "B-LOC", "I-LOC", "E-LOC", "S-LOC", "B-PER", "E-PER", "S-PER", "S-X", "I-PER"]
+    for _ in range(200):
+        n = int(rng.integers(1, 14))
+        row = [str(rng.choice(tags)) for _ in range(n)]
+        if rng.random() < 0.7:
+            row += ["S-X"] * int(rng.integers(1, 6))
+        s = Sentence(" ".join("w%d" % i for i in range(len(row))))
+        for tok, t in zip(s, row):
+            tok.add_tag("ner", t)
+        full = [(sp.tag, str(sp)) for sp in s.get_spans("ner") if sp.tag != "X"]
+        fast = [(sp.tag, str(sp)) for sp in s.get_spans("ner", skip_class="X") if sp.tag != "X"]
+        assert full == fast, (row, full, fast)

@@ -80,6 +80,25 @@ def main():
         print("forward_backward: %.1f ms per batch of %d" % (dt / 8 * 1e3, a.batch))
         pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
         return
+    if os.environ.get("KBNER_EVAL"):
+        from flair.custom_data_loader import ColumnDataLoader
+        dl = ColumnDataLoader(list(cc.train), a.batch, sentence_level_batch=True)
+        dl.assign_tags("ner", td)
+        tagger.eval()
+        tagger.evaluate(dl)
+        torch.cuda.synchronize()
+        import cProfile
+        import pstats
+        pr = cProfile.Profile()
+        t0 = time.perf_counter()
+        pr.enable()
+        res, loss = tagger.evaluate(dl)
+        pr.disable()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        print("evaluate: %.1f sentences/s (%d sentences, batch %d)" % (a.sentences / dt, a.sentences, a.batch))
+        pstats.Stats(pr).sort_stats("cumulative").print_stats(22)
+        return
     for epochs in (1, 2):  # epoch 1 warms up (tokenizer cache, buffers); report the second epoch's rate
         t0 = time.perf_counter()
         trainer.train(os.path.join(d, "out%d" % epochs), learning_rate=5e-6, mini_batch_size=a.batch, max_epochs=1, lr_rate=10000,
