@@ -190,13 +190,13 @@ def main():
         # HBM-side bytes per launch of the same kernel family, from the committed rocprofv3 PMC passes of THIS command at its
         # default configuration (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE; tools/pmc_traffic.py); None otherwise
         traffic, traffic_src = None, None
-        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1_f_hbm_traffic.json")
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1_g_hbm_traffic.json")
         if args.model == "large" and B == 128 and S == 512 and os.path.exists(tpath):
             ks = [v for k, v in json.load(open(tpath))["kernels"].items() if "gemm256_kernel" in k]
             n = sum(v["launches"] for v in ks)
             if n:
                 traffic = round(sum(v["launches"] * v["hbm_bytes_per_launch"] for v in ks) / n)
-                traffic_src = "profiles/round1_f_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch)"
+                traffic_src = "profiles/round1_g_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch)"
         roofline = {"bound": "mfma", "kernel": "gemm256_kernel<A_KS,B_KS> (bf16 MFMA 16x16x32, 256x256x64 tiles, all 3 layouts)",
                     "achieved": round(ach, 2), "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
