@@ -24,6 +24,9 @@
 #define AT_D 64
 #define AT_MAXS 512
 #define AT_NW 8  // wavefronts per workgroup (2 per SIMD: one wave's softmax VALU overlaps the other's MFMAs)
+#ifndef AT_NWB
+#define AT_NWB 8  // wavefronts per workgroup of the two backward kernels (-DAT_NWB=16, 4 waves per SIMD at 128 VGPRs, measured no faster)
+#endif
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void glb_cvoid;
@@ -56,10 +59,11 @@ static __device__ __forceinline__ void wait_vm(int n) {
 static __device__ __forceinline__ int kc_swz(int row) { return (row >> 1) & 7; }
 
 // DMA a [S rows][64] bf16 panel (row stride ld elements) into a swizzled LDS image (128-B rows)
+template <int NW = AT_NW>
 static __device__ __forceinline__ void stage_panel(const bf16_t* __restrict__ src, int ld, int S, unsigned char* s, int wid,
                                                    int lane) {
   const int ninstr = S / 8;  // 1 KiB = 8 rows per wave-instruction
-  for (int q = wid; q < ninstr; q += AT_NW) {
+  for (int q = wid; q < ninstr; q += NW) {
     const int row = q * 8 + (lane >> 3);
     const int pos = lane & 7;
     glds16(src + (size_t)row * ld + ((pos ^ kc_swz(row)) << 3), s + q * 1024);
@@ -299,6 +303,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const bf16_t* __restri
 // fused QKV projection (d qkv.bias = column sums of dQ | dK | dV), so no separate pass re-reads the 3H-wide dqkv.
 // acc[db][r] is this lane's running sum for column db*16 + g*4 + r (rows li); reduce over li, over the 8 waves, one atomic
 // per column per workgroup.
+template <int NW>
 static __device__ __forceinline__ void flush_colsum(f4v (&acc)[4], float (*red)[64], float* __restrict__ out, int wid, int lane,
                                                     int tid) {
 #pragma unroll
@@ -316,7 +321,7 @@ static __device__ __forceinline__ void flush_colsum(f4v (&acc)[4], float (*red)[
   if (tid < 64) {
     float t = 0.0f;
 #pragma unroll
-    for (int w = 0; w < AT_NW; ++w) t += red[w][tid];
+    for (int w = 0; w < NW; ++w) t += red[w][tid];
     atomicAdd(out + tid, t);
   }
   __syncthreads();
@@ -330,14 +335,14 @@ static __device__ __forceinline__ void flush_colsum(f4v (&acc)[4], float (*red)[
 // It also produces D[b,h,q] = rowdot(dO, O) (the softmax-backward correction) for its own queries from the dO / O
 // fragments it already needs, and writes it for the dK/dV kernel that runs next: no separate row-dot pass.
 template <bool DROP>
-__global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dctx,
+__global__ __launch_bounds__(AT_NWB * 64) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dctx,
                                                              const bf16_t* __restrict__ ctx,
                                                              const float* __restrict__ maskbias, const float* __restrict__ lse,
                                                              float* __restrict__ Dv, bf16_t* __restrict__ dqkv, int S,
                                                              int H, int A, float scale, int rpw, uint32_t drop_seed,
                                                              uint32_t drop_thresh, float* __restrict__ dbias) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ float red[AT_NW][64];
+  __shared__ float red[AT_NWB][64];
   unsigned char* sK = smem;
   unsigned char* sV = smem + AT_MAXS * 128;
   float* sMask = reinterpret_cast<float*>(smem + 2 * AT_MAXS * 128);
@@ -352,9 +357,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(const bf16_t* __res
   f4v bsum[4];
 #pragma unroll
   for (int db = 0; db < 4; ++db) bsum[db] = (f4v){0.f, 0.f, 0.f, 0.f};
-  stage_panel(base + H, ld, S, sK, wid, lane);
-  stage_panel(base + 2 * H, ld, S, sV, wid, lane);
-  for (int i = tid; i < S; i += 512) {
+  stage_panel<AT_NWB>(base + H, ld, S, sK, wid, lane);
+  stage_panel<AT_NWB>(base + 2 * H, ld, S, sV, wid, lane);
+  for (int i = tid; i < S; i += AT_NWB * 64) {
     sMask[i] = maskbias[(size_t)b * S + i] * 1.4426950408889634f;
     if (DROP) sCk[i] = drop_colkey(drop_seed, bhS + (uint32_t)i);
   }
@@ -367,8 +372,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(const bf16_t* __res
   const bf16_t* dob = dctx + (size_t)b * S * H + h * AT_D;
   const bf16_t* ob = ctx + (size_t)b * S * H + h * AT_D;
 #pragma unroll 1
-  for (int pass = 0; pass < rpw / 128; ++pass) {
-    const int q0 = qt * rpw + wid * (rpw / 8) + pass * 16;
+  for (int pass = 0; pass < rpw / (16 * AT_NWB); ++pass) {
+    const int q0 = qt * rpw + wid * (rpw / AT_NWB) + pass * 16;
     if (q0 >= S) break;
     const bf16x8 qf0 = glb_frag(base, ld, q0, 0, lane);
     const bf16x8 qf1 = glb_frag(base, ld, q0, 1, lane);
@@ -446,20 +451,20 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(const bf16_t* __res
       bsum[db] += dq[db] * scale;
     }
   }
-  if (dbias != nullptr) flush_colsum(bsum, red, dbias + h * AT_D, wid, lane, tid);
+  if (dbias != nullptr) flush_colsum<AT_NWB>(bsum, red, dbias + h * AT_D, wid, lane, tid);
 }
 
 // ------------------------------------------------------------------------------------------
 // backward: dK, dV   (owner = key rows; panels Q, dO)
 // ------------------------------------------------------------------------------------------
 template <bool DROP>
-__global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dctx,
+__global__ __launch_bounds__(AT_NWB * 64) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dctx,
                                                               const float* __restrict__ maskbias, const float* __restrict__ lse,
                                                               const float* __restrict__ Dv, bf16_t* __restrict__ dqkv, int S,
                                                               int H, int A, float scale, int rpw, uint32_t drop_seed,
                                                               uint32_t drop_thresh, float* __restrict__ dbias) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ float red[AT_NW][64];
+  __shared__ float red[AT_NWB][64];
   f4v bsk[4], bsv[4];
 #pragma unroll
   for (int db = 0; db < 4; ++db) bsk[db] = bsv[db] = (f4v){0.f, 0.f, 0.f, 0.f};
@@ -474,12 +479,12 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
   const int ld = 3 * H;
   const bf16_t* base = qkv + (size_t)b * S * ld + h * AT_D;
   const bf16_t* dob = dctx + (size_t)b * S * H + h * AT_D;
-  stage_panel(base, ld, S, sQ, wid, lane);
-  stage_panel(dob, H, S, sO, wid, lane);
+  stage_panel<AT_NWB>(base, ld, S, sQ, wid, lane);
+  stage_panel<AT_NWB>(dob, H, S, sO, wid, lane);
   const size_t sbase = ((size_t)b * A + h) * S;
   const uint32_t bhS = (uint32_t)sbase;
   const float dscale = DROP ? drop_scale(drop_thresh) : 1.0f;
-  for (int i = tid; i < S; i += 512) {
+  for (int i = tid; i < S; i += AT_NWB * 64) {
     sL[i] = lse[sbase + i] * 1.4426950408889634f;  // log2 domain
     sD[i] = -Dv[sbase + i];  // negated: the dP accumulators start at -D (no-dropout variant), dS = P * (dP + (-D)) otherwise
     if (DROP) sRk[i] = drop_rowkey(drop_seed, bhS + (uint32_t)i);
@@ -491,8 +496,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
   const float scale2 = scale * 1.4426950408889634f;
   const PanelBases pQ = panel_bases(sQ, lane), pO = panel_bases(sO, lane);
 #pragma unroll 1
-  for (int pass = 0; pass < rpw / 128; ++pass) {
-    const int k0 = kt * rpw + wid * (rpw / 8) + pass * 16;
+  for (int pass = 0; pass < rpw / (16 * AT_NWB); ++pass) {
+    const int k0 = kt * rpw + wid * (rpw / AT_NWB) + pass * 16;
     if (k0 >= S) break;
     const bf16x8 kf0 = glb_frag(base + H, ld, k0, 0, lane);
     const bf16x8 kf1 = glb_frag(base + H, ld, k0, 1, lane);
@@ -584,8 +589,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
     }
   }
   if (dbias != nullptr) {
-    flush_colsum(bsk, red, dbias + H + h * AT_D, wid, lane, tid);
-    flush_colsum(bsv, red, dbias + 2 * H + h * AT_D, wid, lane, tid);
+    flush_colsum<AT_NWB>(bsk, red, dbias + H + h * AT_D, wid, lane, tid);
+    flush_colsum<AT_NWB>(bsv, red, dbias + 2 * H + h * AT_D, wid, lane, tid);
   }
 }
 
@@ -637,11 +642,12 @@ static int launch_attn_bwd(const bf16_t* qkv, const bf16_t* ctx, const bf16_t* d
     if (r) return r;
     once = true;
   }
-  const int rpw = pick_rpw(B, S, A);
+  int rpw = pick_rpw(B, S, A);
+  if (rpw < 16 * AT_NWB) rpw = 16 * AT_NWB;  // every wave owns at least one 16-row pass
   const dim3 grid((S + rpw - 1) / rpw, A, B);
-  hipLaunchKernelGGL(attn_bwd_dq_kernel<DROP>, grid, dim3(512), AT_LDS_BYTES, s, qkv, dctx, ctx, maskbias, lse, Dws, dqkv, S, H, A,
+  hipLaunchKernelGGL(attn_bwd_dq_kernel<DROP>, grid, dim3(AT_NWB * 64), AT_LDS_BYTES, s, qkv, dctx, ctx, maskbias, lse, Dws, dqkv, S, H, A,
                      0.125f, rpw, seed, thresh, dbias);
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel<DROP>, grid, dim3(512), AT_LDS_BYTES, s, qkv, dctx, maskbias, lse, Dws, dqkv, S, H, A,
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel<DROP>, grid, dim3(AT_NWB * 64), AT_LDS_BYTES, s, qkv, dctx, maskbias, lse, Dws, dqkv, S, H, A,
                      0.125f, rpw, seed, thresh, dbias);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
