@@ -72,13 +72,20 @@ def cpu_baseline(args, cfg_kw, T, tags):
               first_idx=torch.from_numpy(b["first_idx"]), tags=torch.from_numpy(b["tags"].astype(np.int64)),
               lengths=torch.from_numpy(b["lengths"].astype(np.int64)))
     setup = time.time() - t0
-    t1 = time.time()
-    trainer.micro_batch(ob)
+    tw = time.time()
+    trainer.micro_batch(ob)          # untimed warm-up step: first-touch allocation of activations / Adam state, thread-pool start
     trainer.optimizer_step()
-    dt = time.time() - t1
+    warm = time.time() - tw
+    nt = max(1, args.cpu_steps)
+    t1 = time.time()
+    for _ in range(nt):
+        trainer.micro_batch(ob)
+        trainer.optimizer_step()
+    dt = (time.time() - t1) / nt
     return {"value": Bc / dt, "unit": "sentences/sec", "cores": ncores, "kind": "port",
-            "sample": "1 optimizer step of %d synthetic 512-token sentences (fwd+bwd+clip+AdamW, fp32 torch-CPU oracle, "
-                      "%d threads; %.1fs timed, %.1fs setup)" % (Bc, ncores, dt, setup)}
+            "sample": "%d timed optimizer steps (after 1 untimed warm-up) of %d synthetic 512-token sentences each (fwd+bwd+clip+"
+                      "AdamW, fp32 torch-CPU oracle, %d threads; %.1fs per timed step, warm-up step %.1fs, %.1fs setup)"
+                      % (nt, Bc, ncores, dt, warm, setup)}
 
 
 def main():
@@ -91,8 +98,13 @@ def main():
     ap.add_argument("--seq-len", type=int, default=512)
     ap.add_argument("--model", default="large", choices=["large", "base"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sentences", type=int, default=8)
+    ap.add_argument("--cpu-sentences", type=int, default=4)
+    ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--blocking-allreduce", action="store_true", help="N>1: no overlap, everything exchanged after backward (A/B)")
+    ap.add_argument("--compress-embedding-grad", action="store_true",
+                    help="N>1: all-reduce the word-embedding gradient as bf16 when it is not row-sparse (deviation from the fp32 mean)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (small micro-batches, dropout)")
     ap.add_argument("--dropout", type=float, default=0.0,
                     help="train with this dropout probability at the encoder's three HF sites + WordDropout (default 0: "
                          "BASELINE.md's workload is 'dropout off', and so is the cpu_baseline leg)")
@@ -140,12 +152,39 @@ def main():
     opt = engine.FusedAdamW(tg.arena, lr=5e-6, lr_rate=10000.0, t_total=max(total_steps, 100))
     losses = []
 
-    def one_step():
-        for mb in micro:
-            losses.append(tg.forward_loss(mb, loss_scale=1.0 / accum, backward=True))
-        if world > 1:
-            dist.all_reduce(tg.arena.g)  # sum over ranks; AdamW applies 1/world (mean gradient)
-        opt.step(grad_scale=1.0 / world)
+    # data parallel: the gradient exchange of a step overlaps with its backward (kbner.dp.GradReducer): the GEMM-weight
+    # gradients travel as 6 buckets of 4 layers, each all-reduced (RCCL, async) as soon as its grouped weight-gradient launch
+    # is enqueued; only embeddings + vectors + head are exchanged after backward.  --blocking-allreduce restores round 1's
+    # single 2.24 GB all-reduce for A/B.
+    reducer = None
+    if world > 1:
+        from kbner import dp
+        a = tg.arena
+        lo = a.offsets["emb.word"]
+        Vv, Hh = a.shapes["emb.word"]
+        reducer = dp.GradReducer(a.g, emb_range=(lo, lo + Vv * Hh), emb_width=Hh, compress_embedding=args.compress_embedding_grad)
+    touched = None
+    if reducer is not None:
+        import numpy as np
+        touched = np.unique(np.concatenate([m["ids"].cpu().numpy().ravel() for m in micro]))
+    exposed = []
+
+    def one_step(time_exchange=False):
+        if reducer is not None:
+            reducer.begin(touched)
+        for i, mb in enumerate(micro):
+            hook = reducer.bucket_ready if (reducer is not None and i == len(micro) - 1 and not args.blocking_allreduce) else None
+            losses.append(tg.forward_loss(mb, loss_scale=1.0 / accum, backward=True, grad_ready=hook))
+        scale = 1.0
+        if reducer is not None:
+            if time_exchange:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            scale = reducer.finish()   # sum over ranks; AdamW applies 1/world (mean gradient)
+            if time_exchange:
+                e1.record()
+                exposed.append((e0, e1))
+        opt.step(grad_scale=scale)
 
     def fence():
         torch.cuda.synchronize()
@@ -190,13 +229,15 @@ def main():
         # HBM-side bytes per launch of the same kernel family, from the committed rocprofv3 PMC passes of THIS command at its
         # default configuration (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE; tools/pmc_traffic.py); None otherwise
         traffic, traffic_src = None, None
-        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1_g_hbm_traffic.json")
-        if args.model == "large" and B == 128 and S == 512 and os.path.exists(tpath):
+        pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+        cands = sorted(f for f in (os.listdir(pdir) if os.path.isdir(pdir) else []) if f.endswith("_hbm_traffic.json"))
+        tpath = os.path.join(pdir, cands[-1]) if cands else ""
+        if args.model == "large" and B == 128 and S == 512 and tpath:
             ks = [v for k, v in json.load(open(tpath))["kernels"].items() if "gemm256_kernel" in k]
             n = sum(v["launches"] for v in ks)
             if n:
                 traffic = round(sum(v["launches"] * v["hbm_bytes_per_launch"] for v in ks) / n)
-                traffic_src = "profiles/round1_g_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch)"
+                traffic_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch)" % cands[-1]
         roofline = {"bound": "mfma", "kernel": "gemm256_kernel<A_KS,B_KS> (bf16 MFMA 16x16x32, 256x256x64 tiles, all 3 layouts)",
                     "achieved": round(ach, 2), "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
@@ -205,6 +246,53 @@ def main():
                     "by_layout": {("NT_fwd", "NN_dgrad", "TN_wgrad")[k]: {"tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 2),
                                                                               "ms": round(v[1], 3), "launches": v[2]}
                                   for k, v in sorted(by.items())}}
+
+    # data parallel: how long the compute stream waits for / runs the part of the exchange backward could not hide
+    # (HIP events around GradReducer.finish() on one extra step); None at N=1
+    allreduce_ms_exposed, dp_stats = None, None
+    if reducer is not None:
+        one_step(time_exchange=True)
+        torch.cuda.synchronize()
+        allreduce_ms_exposed = round(max(a.elapsed_time(b) for a, b in exposed), 3)
+        dp_stats = dict(reducer.stats)
+
+    # secondary measurements of the SAME step at the other points BASELINE.md / SURVEY.md §8d name: micro-batch {1,4,16,32} x
+    # accumulate 4 (the YAMLs run 1 x 4) and dropout 0.1 at every site -- N=1, default workload only, a few steps each
+    extra = None
+    if world == 1 and not args.no_extras and args.model == "large" and B == 128 and accum == 1 and args.dropout == 0.0:
+        extra = {"micro_batch_x_accumulate": {}, "unit": "sentences/sec"}
+
+        def timed(tgx, optx, mbs, steps, warm=1):
+            def st():
+                for mb in mbs:
+                    tgx.forward_loss(mb, loss_scale=1.0 / len(mbs), backward=True)
+                optx.step()
+            for _ in range(warm):
+                st()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                st()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / steps
+
+        for mbsz in (1, 4, 16, 32):
+            mbs = [kb.to_device(kb.synthetic_batch(mbsz, S, vocab=cfg.vocab_size, T=T, x_idx=x_idx, start=start, stop=stop,
+                                                   seed=kb.SEED + 50 + i), dev) for i in range(4)]
+            sec = timed(tg, opt, mbs, steps=3 if mbsz >= 16 else 6)
+            extra["micro_batch_x_accumulate"]["%dx4" % mbsz] = {"value": round(4 * mbsz / sec, 2), "ms_per_step": round(sec * 1e3, 3)}
+        # the fused form the drop-in trainer uses for the YAMLs' 1 x 4 (one weighted batch of 4: same loss and gradient)
+        mb4 = [kb.to_device(kb.synthetic_batch(4, S, vocab=cfg.vocab_size, T=T, x_idx=x_idx, start=start, stop=stop,
+                                               seed=kb.SEED + 60), dev)]
+        sec = timed(tg, opt, mb4, steps=6)
+        extra["micro_batch_x_accumulate"]["1x4_fused_by_trainer"] = {"value": round(4 / sec, 2), "ms_per_step": round(sec * 1e3, 3)}
+        tg.cfg.hidden_dropout_prob = tg.cfg.attention_probs_dropout_prob = 0.1
+        tg.train(True)
+        tg.word_dropout = 0.1
+        sec = timed(tg, opt, micro, steps=3)
+        tg.train(False)
+        tg.cfg.hidden_dropout_prob = tg.cfg.attention_probs_dropout_prob = 0.0
+        extra["dropout_0.1_all_sites_128x1"] = {"value": round(B / sec, 2), "ms_per_step": round(sec * 1e3, 3)}
 
     if rank == 0:
         fl_sent = 3 * encoder_flops_per_sentence(cfg, S)
@@ -227,6 +315,11 @@ def main():
         }
         if roofline is not None:
             out["roofline"] = roofline
+        out["allreduce_ms_exposed"] = allreduce_ms_exposed
+        if dp_stats is not None:
+            out["dp_exchange"] = dp_stats
+        if extra is not None:
+            out["extra"] = extra
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args, cfg_kw if args.model == "base" else dict(cfg_kw), T, (start, stop, x_idx))

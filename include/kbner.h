@@ -57,6 +57,9 @@ int kbner_crf_posterior(const float* emit, const float* trans, const int* lens, 
 int kbner_gather_rows(const kbner_bf16* src, const int* idx, kbner_bf16* out, int R, int H, void* stream);
 /* fp32 variant for the evaluation path: emissions [B*n,T] -> the rows _obtain_labels decodes (sequence_tagger_model.py:1198-1200) */
 int kbner_gather_rows_f32(const float* src, const int* idx, float* out, int R, int W, void* stream);
+/* fp32 row scatter dst[idx[r],:] = rows[r,:] (unique indices, W % 4 == 0): the data-parallel exchange of the touched
+ * word-embedding gradient rows -- new capability, the reference has no distributed path (finetune_trainer.py:466,699-700) */
+int kbner_scatter_rows_f32(const float* rows, const int* idx, float* dst, int R, int W, void* stream);
 /* its backward (unique indices; caller zero-fills dsrc) */
 int kbner_scatter_rows(const kbner_bf16* dout, const int* idx, kbner_bf16* dsrc, int R, int H, void* stream);
 /* self.linear, sequence_tagger_model.py:1027: out f32[R,T] = x bf16[R,H] . w f32[T,H]^T + bias */
@@ -151,6 +154,7 @@ int kbner_adamw_hf(float* p, float* g, float* m, float* v, kbner_bf16* shadow, s
                    float lr_wd, float b1, float b2, float eps, const float* gnorm_sq, float max_norm, float grad_scale,
                    int zero_grad, void* stream);
 int kbner_f32_to_bf16(const float* x, kbner_bf16* y, size_t n, void* stream);
+int kbner_bf16_to_f32(const kbner_bf16* x, float* y, size_t n, void* stream); /* n % 4 == 0 */
 int kbner_wdiff_sum(const float* a, const float* b, const float* w, int n, float* out, void* stream);
 
 /* ---------------- hardware-semantics probes (debug) ---------------- */

@@ -95,6 +95,20 @@ __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restric
   }
 }
 
+__global__ __launch_bounds__(256) void bf16_to_f32_kernel(const bf16_t* __restrict__ x, float* __restrict__ y, size_t n) {
+  const size_t n4 = n / 4;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const uint2 u = reinterpret_cast<const uint2*>(x)[i];
+    float4 a;
+    a.x = __uint_as_float(u.x << 16);
+    a.y = __uint_as_float(u.x & 0xffff0000u);
+    a.z = __uint_as_float(u.y << 16);
+    a.w = __uint_as_float(u.y & 0xffff0000u);
+    reinterpret_cast<float4*>(y)[i] = a;
+  }
+}
+
 // out[0] = sum_i w[i] * (a[i] - b[i])      (CRF loss: mean over sentences of logZ - gold)
 __global__ __launch_bounds__(64) void wdiff_sum_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                        const float* __restrict__ w, int n, float* __restrict__ out) {
@@ -140,6 +154,15 @@ int kbner_f32_to_bf16(const float* x, bf16_t* y, size_t n, void* stream) {
   size_t blocks = (n / 4 + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, y, n);
+  KBNER_LAUNCH_RET();
+}
+
+int kbner_bf16_to_f32(const bf16_t* x, float* y, size_t n, void* stream) {
+  KBNER_CHECK_ARG(n % 4 == 0);
+  if (n == 0) return 0;
+  size_t blocks = (n / 4 + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(bf16_to_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, y, n);
   KBNER_LAUNCH_RET();
 }
 

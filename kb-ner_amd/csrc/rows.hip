@@ -264,6 +264,26 @@ extern "C" int kbner_gather_rows_f32(const float* src, const int* idx, float* ou
   KBNER_LAUNCH_RET();
 }
 
+// fp32 row scatter (data-parallel exchange of the touched word-embedding gradient rows, kbner/dp.py): dst[idx[r],:] = rows[r,:];
+// indices unique, 16-byte accesses (W % 4 == 0)
+__global__ __launch_bounds__(256) void scatter_rows_f32_kernel(const float4* __restrict__ rows, const int* __restrict__ idx,
+                                                               float4* __restrict__ dst, int R, int W4) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)R * W4) return;
+  const int r = (int)(i / W4), c = (int)(i % W4);
+  const int d = idx[r];
+  if (d >= 0) dst[(size_t)d * W4 + c] = rows[i];
+}
+
+extern "C" int kbner_scatter_rows_f32(const float* rows, const int* idx, float* dst, int R, int W, void* stream) {
+  KBNER_CHECK_ARG(R >= 0 && W > 0 && W % 4 == 0);
+  if (R == 0) return 0;
+  const size_t n = (size_t)R * (W / 4);
+  hipLaunchKernelGGL(scatter_rows_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const float4*>(rows), idx, reinterpret_cast<float4*>(dst), R, W / 4);
+  KBNER_LAUNCH_RET();
+}
+
 // Materialise a dropout site's multiplier (tests / debugging only: the product kernels regenerate it in registers):
 // out[z,i,j] = drop_keep(rowkey(seed, z*M+i), colkey(seed, z*N+j)) ? 1/(1-p) : 0.  Hidden-state sites: Z=1, [M tokens, H];
 // attention-probability sites: Z = B*A heads, M = N = S.

@@ -26,6 +26,12 @@ if not logger.handlers:
     logger.setLevel(logging.INFO)
     logger.propagate = False
 
+# Launched by torchrun (WORLD_SIZE > 1): one process per GPU over RCCL.  The reference's train.py knows nothing about
+# torch.distributed, so the process group is created here, at `import flair`, before any model exists.
+if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    from kbner import dp as _dp
+    _dp.init_from_env()
+
 from . import data  # noqa: E402,F401
 from . import models  # noqa: E402,F401
 from . import trainers  # noqa: E402,F401

@@ -36,10 +36,15 @@ class ConfigParser:
         if td and Path(td).exists():
             self.tag_dictionary = Dictionary.load_from_file(td)
         else:
+            # every rank derives the same dictionary from the same corpus; only rank 0 writes it, atomically (a reader never
+            # sees a half-written pickle)
             self.tag_dictionary = self.corpus.make_tag_dictionary(tag_type=self.target)
-            if td:
+            import os
+            if td and int(os.environ.get("RANK", "0")) == 0:
                 Path(td).parent.mkdir(parents=True, exist_ok=True)
-                self.tag_dictionary.save(td)
+                tmp = "%s.tmp.%d" % (td, os.getpid())
+                self.tag_dictionary.save(tmp)
+                os.replace(tmp, td)
         log.info(self.tag_dictionary.item2idx)
         self.num_corpus = len(self.corpus.targets)
         log.info(self.corpus)

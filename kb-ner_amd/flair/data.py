@@ -78,7 +78,7 @@ class Label:
 
     @score.setter
     def score(self, s):
-        self._score = float(s) if 0.0 <= float(s) <= 1.0 else 1.0
+        self._score = s if 0.0 <= s <= 1.0 else 1.0   # the value is kept as given (an int 1 prints "1", data.py:132-137)
 
     def to_dict(self):
         return {"value": self.value, "confidence": self.score}
@@ -228,10 +228,12 @@ class Sentence:
         return [lab.value for lab in self.labels]
 
     # -- spans (flair/data.py:455-532)
-    def get_spans(self, tag_type: str, min_score: float = -1, skip_class: str = None) -> List[Span]:
-        """skip_class (not in the reference): tokens of that class are treated like "O" -- they break spans exactly as their
-        own single-token spans would, but no Span object is built for them (evaluate() drops every X span of the
-        hundreds of S-X context tokens anyway)."""
+    def get_spans(self, tag_type: str, min_score: float = -1, skip_class: str = None, drop_touching=None) -> List[Span]:
+        """skip_class / drop_touching (not in the reference) are POST-FILTERS applied before a Span object is built, exactly
+        equivalent to filtering the reference's list afterwards: spans whose class is `skip_class` and spans containing a
+        token whose 1-based idx is in `drop_touching` are not returned.  evaluate()'s remove_x rule (sequence_tagger_model.py
+        :2653-2672) drops the hundreds of single-token S-X context spans per sentence anyway; not materialising them is what
+        keeps the host loop fast."""
         spans: List[Span] = []
         cur: List[Token] = []
         votes: Dict[str, float] = defaultdict(float)
@@ -243,7 +245,9 @@ class Sentence:
                 mean = sum(sc) / len(sc)
                 if mean > min_score:
                     best = sorted(votes.items(), key=lambda kv: kv[1], reverse=True)[0][0]
-                    spans.append(Span(cur, tag=best, score=mean))
+                    if not (skip_class is not None and best == skip_class) and \
+                            not (drop_touching and any(t.idx in drop_touching for t in cur)):
+                        spans.append(Span(cur, tag=best, score=mean))
             cur, votes = [], defaultdict(float)
 
         prev = "O"
@@ -253,8 +257,6 @@ class Sentence:
                 val = "O-"
             if val[:2] not in _BIOES:
                 val = "S-" + val           # a bare class name counts as a single-token span
-            if skip_class is not None and val[2:] == skip_class and val[:2] == "S-":
-                val = "O-"
             inside = val[:2] != "O-"
             opens = val[:2] in ("B-", "S-")
             if prev[:2] == "S-" and prev[2:] != val[2:] and inside:
@@ -267,6 +269,18 @@ class Sentence:
             prev = val
         close()
         return spans
+
+    def chunk_sentence(self, start_idx: int, end_idx: int):
+        """keep tokens [start_idx, end_idx) and renumber them (data.py:704-715); used to cut a sentence at its <EOS> token"""
+        kept = []
+        for i in range(start_idx, end_idx):
+            tok = self.tokens[i]
+            kept.append(tok)
+            tok.idx = len(kept)
+        self.tokens = kept
+        self.tokenized = " ".join(t.text for t in self.tokens)
+        if hasattr(self, "_kbner_tok"):
+            del self._kbner_tok
 
     # -- strings
     def to_tokenized_string(self) -> str:

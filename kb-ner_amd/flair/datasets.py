@@ -6,6 +6,8 @@ import re
 from pathlib import Path
 from typing import Dict, List, Union
 
+import torch.utils.data as _torch_data
+
 from .data import Corpus, FlairDataset, Sentence, Token
 
 log = logging.getLogger("flair")
@@ -131,3 +133,22 @@ def _split_tail(ds, frac=0.1):
     k = max(1, round(n * frac)) if n > 1 else 0
     sents = [ds[i] for i in range(n)]
     return _Subset(sents[n - k:]), _Subset(sents[: n - k])
+
+
+class DataLoader(_torch_data.DataLoader):
+    """Sentence-list loader (`from flair.datasets import DataLoader`, train.py:25; reference: flair/datasets.py:4729-4771):
+    batches are plain python lists of Sentence; in-memory datasets are never handed to worker processes."""
+
+    def __init__(self, dataset, batch_size=1, shuffle=False, sampler=None, batch_sampler=None, num_workers=4, drop_last=False,
+                 timeout=0, worker_init_fn=None):
+        inner = dataset
+        while isinstance(inner, (_torch_data.Subset, _torch_data.ConcatDataset)):
+            inner = inner.dataset if isinstance(inner, _torch_data.Subset) else inner.datasets[0]
+        if isinstance(inner, list) or (isinstance(inner, FlairDataset) and inner.is_in_memory()):
+            num_workers = 0
+        if batch_sampler is not None:  # torch forbids batch_size / shuffle / drop_last next to a batch_sampler
+            super().__init__(dataset, batch_sampler=batch_sampler, num_workers=num_workers, collate_fn=list, timeout=timeout,
+                             worker_init_fn=worker_init_fn)
+        else:
+            super().__init__(dataset, batch_size=batch_size, shuffle=shuffle, sampler=sampler, num_workers=num_workers,
+                             collate_fn=list, drop_last=drop_last, timeout=timeout, worker_init_fn=worker_init_fn)

@@ -26,23 +26,46 @@ log = logging.getLogger("flair")
 START_TAG: str = "<START>"
 STOP_TAG: str = "<STOP>"
 
-_UNSUPPORTED_TRUE = ("use_mfvi", "use_rnn", "use_cnn", "distill_crf", "crf_attention", "biaf_attention", "use_language_attention",
-                     "distill_posterior", "posterior_constraint", "enhanced_crf", "use_transition_attention",
-                     "relearn_embeddings", "map_embeddings", "embedding_selector", "use_rl", "multi_view_training")
+# constructor switches of the reference that select code outside the hot path (KD / MFVI / attention variants / ACE controller
+# training): accepted by name, rejected when switched on
+_UNSUPPORTED_TRUE = ("use_mfvi", "use_cnn", "distill_crf", "crf_attention", "biaf_attention", "use_language_attention",
+                     "token_level_attention", "distill_with_gold", "exp_score", "distill_posterior", "distill_prob",
+                     "distill_emission", "distill_exact", "posterior_constraint", "use_language_vector", "enhanced_crf",
+                     "use_language_id", "use_transition_attention", "unlabel_entropy_loss", "relearn_embeddings", "map_embeddings",
+                     "no_encoder", "new_drop", "use_embedding_masks", "use_gumbel", "embedding_attention", "multi_view_training",
+                     "calculate_l2_loss", "l2_loss_only", "train_initial_hidden_state")
 
 
 class SequenceTagger(flair.nn.Model):
     def __init__(self, hidden_size: int, embeddings, tag_dictionary: Dictionary, tag_type: str, use_crf: bool = True,
-                 use_rnn: bool = True, use_cnn: bool = False, rnn_layers: int = 1, dropout: float = 0.0, word_dropout: float = 0.05,
-                 locked_dropout: float = 0.5, sentence_loss: bool = False, remove_x: bool = False, config=None, target_languages: int = 1,
-                 use_decoder_timer: bool = True, testing: bool = False, **kwargs):
+                 use_mfvi: bool = False, use_rnn: bool = True, use_cnn: bool = False, rnn_layers: int = 1, dropout: float = 0.0,
+                 word_dropout: float = 0.05, locked_dropout: float = 0.5, train_initial_hidden_state: bool = False,
+                 pickle_module: str = "pickle", interpolation: float = 0.5, sentence_loss: bool = False, distill_crf: bool = False,
+                 crf_attention: bool = False, biaf_attention: bool = False, use_language_attention: bool = False,
+                 token_level_attention: bool = False, distill_with_gold: bool = False, exp_score: bool = False,
+                 distill_posterior: bool = False, distill_prob: bool = False, distill_emission: bool = False,
+                 distill_exact: bool = False, posterior_constraint: bool = False, predict_posterior: bool = False,
+                 use_language_vector: bool = False, enhanced_crf: bool = False, use_language_id: bool = False,
+                 use_transition_attention: bool = False, teacher_hidden: int = 256, num_teachers: int = 0,
+                 target_languages: int = 1, gold_const: float = 1.0, posterior_interpolation: float = 0.0, config=None,
+                 word_map=None, char_map=None, use_decoder_timer=True, debug=False, unlabel_entropy_loss=False,
+                 entropy_loss_rate=0.001, relearn_embeddings=False, map_embeddings=False, no_encoder=False,
+                 temperature: float = 1, relearn_size=-1, embedding_selector=False, new_drop: bool = False, use_rl: bool = False,
+                 use_embedding_masks: bool = False, use_gumbel: bool = False, embedding_attention: bool = False,
+                 testing: bool = False, remove_x: bool = False, multi_view_training: bool = False,
+                 calculate_l2_loss: bool = False, l2_loss_only: bool = False, **kwargs):
+        """Keywords are the reference's (sequence_tagger_model.py:100-163), spelled out so a misspelt YAML key is reported."""
         super().__init__()
+        if kwargs:
+            log.warning("SequenceTagger: ignoring unknown keyword(s) %s -- check the YAML for a misspelt key", ", ".join(sorted(kwargs)))
+        given = dict(locals())
         for k in _UNSUPPORTED_TRUE:
-            v = {"use_rnn": use_rnn, "use_cnn": use_cnn}.get(k, kwargs.get(k, False))
-            if v:
-                raise NotImplementedError("%s=True is outside the MI355X hot path (XLM-R + linear + CRF, use_rnn: false)" % k)
+            if given.get(k):
+                raise NotImplementedError("%s=True is outside the MI355X hot path (XLM-R [+ frozen stack + BiLSTM] + linear + CRF)" % k)
         if not use_crf:
             raise NotImplementedError("use_crf=False (softmax head) is not on the hot path")
+        if use_rnn:
+            raise NotImplementedError("use_rnn=True: see flair.models.sequence_tagger_model (BiLSTM head, inference only) -- not built yet")
         if dropout or locked_dropout:
             raise NotImplementedError("dropout / locked_dropout > 0 on the tagger head is not implemented (KB-NER YAMLs use 0.0)")
         self.hidden_size = hidden_size
@@ -57,7 +80,9 @@ class SequenceTagger(flair.nn.Model):
         self.remove_x = remove_x
         self.use_word_dropout = word_dropout  # flair.nn.WordDropout on the token features while training (engine.word_dropout)
         self.use_dropout, self.use_locked_dropout = 0.0, 0.0
-        self.predict_posterior = bool(kwargs.get("predict_posterior", False))  # marginal (forward-backward) decoding
+        self.predict_posterior = bool(predict_posterior)  # marginal (forward-backward) decoding
+        self.temperature = temperature
+        self.embedding_selector, self.use_rl = bool(embedding_selector), bool(use_rl)   # set by ReinforcementTrainer (ACE inference)
         self.config = config
         self.target_languages = target_languages
         self.use_decoder_timer = use_decoder_timer
@@ -190,15 +215,22 @@ class SequenceTagger(flair.nn.Model):
         self.mask = torch.from_numpy(hb["keep"].astype(np.float32)).to(flair.device)
         return self.engine.forward_loss(db, backward=False)
 
-    def forward_backward(self, data_points, loss_scale=1.0, sentence_weights=None):
+    def forward_backward(self, data_points, loss_scale=1.0, sentence_weights=None, grad_ready=None):
         """forward_loss + backward into the gradient arena (what `loss.backward()` does at finetune_trainer.py:957).
         sentence_weights (optional, one per sentence) replace the 1/B of the batch mean: see ModelFinetuner.train's
-        accumulation-group fusion."""
+        accumulation-group fusion.  grad_ready(lo, hi): called as soon as arena.g[lo:hi] is final (data-parallel overlap)."""
         self.embeddings.embed(data_points)
         hb, db = self._device_batch(data_points)
         self._last = (hb, db)
         self.mask = torch.from_numpy(hb["keep"].astype(np.float32)).to(flair.device)
-        return self.engine.forward_loss(db, loss_scale=loss_scale, backward=True, weights=sentence_weights)
+        return self.engine.forward_loss(db, loss_scale=loss_scale, backward=True, weights=sentence_weights, grad_ready=grad_ready)
+
+    def touched_word_ids(self, sentences):
+        """the word-embedding rows a list of sentences looks up (host integers): what the data-parallel gradient exchange
+        needs to send only the touched rows of the [V, H] embedding gradient"""
+        ids = self._emb.prepare_batch(sentences)[0]
+        # + the ids the engine pads with (0 inside a row like the reference, the pad id for the rows up to a multiple of 256)
+        return np.union1d(np.asarray(ids).ravel(), np.asarray([0, self.engine.cfg.pad_token_id]))
 
     def _calculate_loss(self, features, sentences, mask):
         """CRF NLL of given emissions [B,n,T] (mean over sentences); narrows self.mask to the non-S-X tokens like the
@@ -254,63 +286,72 @@ class SequenceTagger(flair.nn.Model):
                 kept = np.nonzero(keep[b])[0]
                 before = int(kept[0]) if len(kept) else 0
                 path = [x_item] * before + path
-                cf = [1.0] * before + cf
+                cf = [1] * before + cf          # the reference pads with the INTEGER 1 (:1204-1207): prediction files print "1"
                 after = L - len(path)
-                path, cf = path + [x_item] * after, cf + [1.0] * after
+                path, cf = path + [x_item] * after, cf + [1] * after
             out.append([Label(p, c) for p, c in zip(path, cf)])
         return out, []
 
     def _gold_x_token_ids(self, sentence):
-        """1-based token ids whose gold tag is an X tag (from the loader's tag-id row when present)"""
+        """1-based ids of the tokens whose gold tag is exactly 'S-X' (:2663; from the loader's tag-id row when present)"""
         row = getattr(sentence, self.tag_type + "_tags", None)
-        if row is not None and self.x_idx is not None:
+        sx = self.tag_dictionary.get_idx_for_item("S-X") if "S-X" in self.tag_dictionary.get_items() else None
+        if row is not None and sx is not None:
             r = np.asarray(row)[:len(sentence)]
-            return set((np.nonzero(r == self.x_idx)[0] + 1).tolist())
-        return {t.idx for t in sentence.tokens if t.get_tag(self.tag_type).value.endswith("-X")}
+            return set((np.nonzero(r == sx)[0] + 1).tolist())
+        return {t.idx for t in sentence.tokens if t.get_tag(self.tag_type).value == "S-X"}
 
     # ------------------------------------------------------------------ evaluation
     def evaluate(self, data_loader, out_path: Path = None, embeddings_storage_mode: str = "cpu", prediction_mode=False,
                  speed_test=False):
+        """sequence_tagger_model.py:2593-2729.  Under speed_test only forward + decode run (no loss, so self.mask keeps ALL
+        tokens and Viterbi decodes the context too; no prediction lines, no metric) -- as in the reference."""
         import time
-        eval_loss, batch_no, lines = 0.0, 0, []
+        eval_loss, batch_no = 0.0, 0
         metric = Metric("Evaluation")
+        outfile = open(out_path, "w", encoding="utf-8") if out_path is not None else None
         t0 = time.time()
-        for batch in data_loader:
-            batch_no += 1
-            features = self.forward(batch, prediction_mode=prediction_mode)
-            if not speed_test:
-                loss = self._calculate_loss(features, batch, self.mask)
-                eval_loss += float(loss)
-            tags, _ = self._obtain_labels(features, batch)
-            for sentence, sent_tags in zip(batch, tags):
-                for token, tag in zip(sentence.tokens, sent_tags):
-                    token.add_tag_label("predicted", tag)
-                    if out_path is not None:
-                        lines.append("{} {} {} {}\n".format(token.text, token.get_tag(self.tag_type).value, tag.value, tag.score))
-                lines.append("\n")
-            for sentence in batch:
-                if self.remove_x:
-                    # :2653-2672: gold X spans are dropped, predicted spans are dropped when they are X or touch a gold-X token.
-                    # The context tokens (hundreds of single-token S-X spans per sentence) never become Span objects here.
-                    x_ids = self._gold_x_token_ids(sentence)
-                    gold = [(s.tag, str(s)) for s in sentence.get_spans(self.tag_type, skip_class="X") if s.tag != "X"]
-                    pred = [(s.tag, str(s)) for s in sentence.get_spans("predicted", skip_class="X")
-                            if s.tag != "X" and not any(t.idx in x_ids for t in s.tokens)]
-                else:
-                    gold = [(s.tag, str(s)) for s in sentence.get_spans(self.tag_type)]
-                    pred = [(s.tag, str(s)) for s in sentence.get_spans("predicted")]
-                for tag, span in pred:
-                    (metric.add_tp if (tag, span) in gold else metric.add_fp)(tag)
-                for tag, span in gold:
-                    if (tag, span) not in pred:
-                        metric.add_fn(tag)
-            store_embeddings(batch, embeddings_storage_mode)
+        try:
+            for batch in data_loader:
+                batch_no += 1
+                features = self.forward(batch, prediction_mode=prediction_mode)
+                if not speed_test:
+                    loss = self._calculate_loss(features, batch, self.mask)
+                tags, _ = self._obtain_labels(features, batch)
+                if not speed_test:
+                    eval_loss += float(loss)
+                    for sentence, sent_tags in zip(batch, tags):
+                        for token, tag in zip(sentence.tokens, sent_tags):
+                            token.add_tag_label("predicted", tag)
+                            if outfile is not None:
+                                outfile.write("{} {} {} {}\n".format(token.text, token.get_tag(self.tag_type).value, tag.value,
+                                                                     tag.score))
+                        if outfile is not None:
+                            outfile.write("\n")
+                    for sentence in batch:
+                        if self.remove_x:
+                            # :2653-2672: a predicted span is dropped iff it contains a token whose GOLD tag is exactly 'S-X'
+                            # (predicted X-class spans on other tokens stay and count as false positives); gold spans of class
+                            # X are dropped.  Both filters run inside get_spans so the context tokens never become Spans.
+                            gold = [(s.tag, str(s)) for s in sentence.get_spans(self.tag_type, skip_class="X")]
+                            pred = [(s.tag, str(s)) for s in sentence.get_spans("predicted",
+                                                                               drop_touching=self._gold_x_token_ids(sentence))]
+                        else:
+                            gold = [(s.tag, str(s)) for s in sentence.get_spans(self.tag_type)]
+                            pred = [(s.tag, str(s)) for s in sentence.get_spans("predicted")]
+                        for tag, span in pred:
+                            (metric.add_tp if (tag, span) in gold else metric.add_fp)(tag)
+                        for tag, span in gold:
+                            (metric.add_fn if (tag, span) not in pred else metric.add_tn)(tag)
+                store_embeddings(batch, embeddings_storage_mode)
+        finally:
+            if outfile is not None:
+                outfile.close()
         if speed_test:
-            log.info("decode speed: %.2f sents/sec", getattr(data_loader, "num_examples", 0) / max(1e-9, time.time() - t0))
+            rate = getattr(data_loader, "num_examples", 0) / max(1e-9, time.time() - t0)
+            print(rate)
+            log.info("decode speed: %.2f sents/sec", rate)
         eval_loss /= max(1, batch_no)
-        if out_path is not None:
-            with open(out_path, "w", encoding="utf-8") as f:
-                f.write("".join(lines))
         detailed = ("\nMICRO_AVG: acc {} - f1-score {}\nMACRO_AVG: acc {} - f1-score {}".format(
             metric.micro_avg_accuracy(), metric.micro_avg_f_score(), metric.macro_avg_accuracy(), metric.macro_avg_f_score()))
         for c in metric.get_classes():

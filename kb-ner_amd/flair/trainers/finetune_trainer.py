@@ -25,6 +25,14 @@ from flair.training_utils import add_file_handler, init_output_file, log_line, s
 log = logging.getLogger("flair")
 
 
+def _warn_unknown(where, kwargs):
+    """a misspelt YAML key must not vanish into **kwargs (the reference swallows it silently, finetune_trainer.py:436)"""
+    known_inert = {"compress_embedding_grad"}
+    extra = sorted(k for k in kwargs if k not in known_inert)
+    if extra:
+        log.warning("%s: ignoring unknown keyword(s) %s -- check the YAML for a misspelt key", where, ", ".join(extra))
+
+
 class ModelFinetuner:
     def __init__(self, model: flair.nn.Model, teachers: List[flair.nn.Model], corpus, optimizer=None, professors=None,
                  epoch: int = 0, optimizer_state: dict = None, scheduler_state: dict = None, use_tensorboard: bool = False,
@@ -35,7 +43,10 @@ class ModelFinetuner:
                  sentence_level_pretrained_data: bool = False, assign_doc_for_ext_context: bool = False, **kwargs):
         if distill_mode or ensemble_distill_mode or train_with_professor:
             raise NotImplementedError("knowledge distillation is outside the hot path (all KB-NER configs set distill_mode: false)")
+        _warn_unknown("ModelFinetuner", kwargs)
         self.model = model
+        self.optimizer_state = optimizer_state     # checkpoint resume (finetune_trainer.py:573,690)
+        self.scheduler_state = scheduler_state
         self.corpus = corpus
         self.config = config
         self.teachers = teachers or []
@@ -54,23 +65,55 @@ class ModelFinetuner:
             for part in ("train_list", "dev_list", "test_list"):
                 for s in getattr(corpus, part)[i]:
                     s.lang_id = i
+        if assign_doc_for_ext_context:
+            self.assign_ext_context_doc(self.corpus)   # finetune_trainer.py:373-377
+
+    @classmethod
+    def load_from_checkpoint(cls, checkpoint: dict, corpus, **kwargs):
+        """resume from Model.load_checkpoint()'s dict (reference: ModelTrainer.load_from_checkpoint, trainers/trainer.py:582):
+        the trainer restarts at checkpoint['epoch'] with the saved Adam moments, step count, LR-schedule position and RNG streams"""
+        return cls(checkpoint["model"], None, corpus, epoch=checkpoint["epoch"], optimizer_state=checkpoint["optimizer_state_dict"],
+                   scheduler_state=checkpoint["scheduler_state_dict"], **kwargs)
 
     # ------------------------------------------------------------------ training
     def train(self, base_path: Union[Path, str], learning_rate: float = 5e-5, mini_batch_size: int = 32,
-              eval_mini_batch_size: int = None, max_epochs: int = 100, train_with_dev: bool = False, monitor_train: bool = False,
-              monitor_test: bool = False, embeddings_storage_mode: str = "cpu", checkpoint: bool = False,
-              save_final_model: bool = True, shuffle: bool = True, true_reshuffle: bool = False, warmup_steps: int = 0,
-              use_warmup: bool = False, gradient_accumulation_steps: int = 1, lr_rate: int = 1, sort_data: bool = True,
-              fine_tune_mode: bool = False, save_finetuned_embedding: bool = False, one_by_one: bool = False,
-              select_model_by_macro: bool = False, max_epochs_without_improvement: int = 100, log_interval: int = None,
-              fuse_accumulation: bool = True, **kwargs) -> dict:
-        """fuse_accumulation (not in the reference): the micro-batches of one gradient-accumulation group are encoded as ONE
+              eval_mini_batch_size: int = None, max_epochs: int = 100, anneal_factor: float = 0.5, patience: int = 10,
+              min_learning_rate: float = 5e-9, train_with_dev: bool = False, dataset_level_macro_avg: bool = True,
+              monitor_train: bool = False, monitor_test: bool = False, embeddings_storage_mode: str = "cpu",
+              checkpoint: bool = False, save_final_model: bool = True, anneal_with_restarts: bool = False, shuffle: bool = True,
+              true_reshuffle: bool = False, param_selection_mode: bool = False, num_workers: int = 4, sampler=None,
+              use_amp: bool = False, use_autocast: bool = False, language_attention_warmup_and_fix: bool = False,
+              language_attention_warmup: bool = False, language_attention_entropy: bool = False,
+              train_language_attention_by_dev: bool = False, calc_teachers_target_loss: bool = False,
+              entropy_loss_rate: float = 1, amp_opt_level: str = "O1", professor_interpolation=0.5, best_k=10,
+              max_epochs_without_improvement=100, gold_reward=False, warmup_steps: int = 0, warmup_epochs: int = 1,
+              use_warmup: bool = False, gradient_accumulation_steps: int = 1, lr_rate: int = 1, decay: float = 0.75,
+              decay_steps: int = 5000, use_unlabeled_data: bool = False, sort_data: bool = True, fine_tune_mode: bool = False,
+              debug: bool = False, min_freq: int = -1, min_lemma_freq: int = -1, min_pos_freq: int = -1,
+              unlabeled_data_for_zeroshot: bool = False, rootschedule: bool = False, freezing: bool = False,
+              save_finetuned_embedding: bool = False, multi_view_rate: float = 0.5, one_by_one: bool = False,
+              select_model_by_macro: bool = False, log_interval: int = None, fuse_accumulation: bool = True,
+              overlap_allreduce: bool = True, **kwargs) -> dict:
+        """Keywords are the reference's (finetune_trainer.py:379-437), spelled out so that a misspelt YAML key is reported
+        (`**kwargs` only warns).  Those that select paths outside the hot path raise when switched on; the annealing /
+        plateau-scheduler keywords have no effect on the fine-tune path in the reference either (:672-688 uses the linear
+        schedule whenever fine_tune_mode), so they are accepted and unused.
+
+        fuse_accumulation (not in the reference): the micro-batches of one gradient-accumulation group are encoded as ONE
         batch whose sentences carry the weights 1/(accumulate * |their micro-batch|) -- the same loss and gradient as
         `loss / accumulate` summed over the group (finetune_trainer.py:939-957), but the KB-NER YAMLs' `mini_batch_size: 1,
         gradient_accumulation_steps: 4` then runs 4 sentences per launch instead of 1 (3.6x on one MI355X).  Dropout streams
         differ (WordDropout positions are shared by the fused batch), nothing else does."""
         from kbner import dp
         from kbner.engine import FusedAdamW
+        _warn_unknown("ModelFinetuner.train", kwargs)
+        for flag, on in (("use_amp", use_amp), ("use_autocast", use_autocast), ("rootschedule", rootschedule),
+                         ("freezing", freezing), ("use_unlabeled_data", use_unlabeled_data),
+                         ("unlabeled_data_for_zeroshot", unlabeled_data_for_zeroshot), ("gold_reward", gold_reward),
+                         ("language_attention_warmup", language_attention_warmup or language_attention_warmup_and_fix),
+                         ("sampler", sampler is not None)):
+            if on:
+                raise NotImplementedError("train(%s=...) selects a path outside the XLM-R + CRF fine-tune hot path" % flag)
         base_path = Path(base_path)
         base_path.mkdir(parents=True, exist_ok=True)
         is_main = dp.rank() == 0
@@ -104,14 +147,42 @@ class ModelFinetuner:
 
         steps_epoch = dp.steps_per_epoch(len(loader), accum, W)
         t_total = steps_epoch * max_epochs
-        opt = FusedAdamW(self.model.engine.arena, lr=learning_rate, lr_rate=float(lr_rate), eps=1e-6, weight_decay=0.0,
-                         max_norm=5.0, t_total=t_total, warmup=warmup_steps if use_warmup else 0)
+        # finetune_trainer.py:679-688: `use_warmup` derives the warm-up length from warmup_epochs; otherwise warmup_steps is used as given
+        warmup = steps_epoch * int(warmup_epochs) if use_warmup else int(warmup_steps)
+        arena = self.model.engine.arena
+        # every replica starts from rank 0's parameters: the head / transitions are drawn from each process's own torch seed
+        # (sequence_tagger_model.py:402-410 uses the global RNG), and nothing else would ever make them equal
+        if W > 1:
+            dp.broadcast_params_(arena.p)
+            arena.refresh_shadow()
+        opt = FusedAdamW(arena, lr=learning_rate, lr_rate=float(lr_rate), eps=1e-6, weight_decay=0.0, max_norm=5.0,
+                         t_total=t_total, warmup=warmup)
         self.optimizer = opt
+        rng = random.Random(20220711)  # rank-shared shuffle of the batch order
+        order = list(range(len(loader)))  # batch order as a permutation of the loader's (fixed) batches: checkpointable
+        if self.optimizer_state is not None:   # resume (finetune_trainer.py:573,690): Adam moments, step count, RNG streams
+            opt.load_state_dict(self.optimizer_state)
+            sch = self.scheduler_state or {}
+            if sch.get("t_total") not in (None, t_total):
+                log.warning("resuming with t_total %s (checkpoint was written with %s)", t_total, sch.get("t_total"))
+            if "shuffle_rng" in sch:
+                rng.setstate(sch["shuffle_rng"])
+            if sch.get("order") is not None and len(sch["order"]) == len(order):
+                order = list(sch["order"])
+            if "dropout_rng" in sch:
+                self.model.engine._drop_rng.bit_generator.state = sch["dropout_rng"]
+            self.optimizer_state = self.scheduler_state = None
+        elif self.epoch:
+            log.warning("starting at epoch %d without optimizer state: Adam moments and the LR schedule restart", self.epoch)
+        emb_lo = arena.offsets["emb.word"]
+        V, Hh = arena.shapes["emb.word"]
+        reducer = dp.GradReducer(arena.g, emb_range=(emb_lo, emb_lo + V * Hh), emb_width=Hh,
+                                 compress_embedding=bool(kwargs.get("compress_embedding_grad", False))) if W > 1 else None
         log_line(log)
         log.info('Model: "XLM-R encoder + linear + CRF on kbner HIP engine", tags=%d', len(self.model.tag_dictionary))
         log.info('Parameters: learning_rate "%s", mini_batch_size "%s", accumulate "%s", max_epochs "%s", world_size "%s", '
-                 'global batch "%s", t_total "%s"', learning_rate, mini_batch_size, accum, max_epochs, W,
-                 mini_batch_size * accum * W, t_total)
+                 'global batch "%s", t_total "%s", warmup "%s"', learning_rate, mini_batch_size, accum, max_epochs, W,
+                 mini_batch_size * accum * W, t_total, warmup)
         log.info('Model training base path: "%s"', base_path)
         log_line(log)
         loss_txt = init_output_file(base_path, "loss.tsv") if is_main else None
@@ -120,8 +191,7 @@ class ModelFinetuner:
                 f.write("EPOCH\tTIMESTAMP\tLEARNING_RATE\tTRAIN_LOSS\tDEV_LOSS\tDEV_F1\tDEV_MACRO_F1\n")
 
         dev_score_history, dev_loss_history, train_loss_history = [], [], []
-        best_score, bad_epochs = -1.0, 0
-        rng = random.Random(20220711)  # rank-shared shuffle of the batch order
+        best_score, bad_epochs = 0.0, 0   # finetune_trainer.py: best_score starts at 0 and a TIE with it still saves (:1280-1289)
         log_every = log_interval or max(1, len(loader) // W // 10)
         try:
             for epoch in range(self.epoch, max_epochs):
@@ -129,11 +199,15 @@ class ModelFinetuner:
                     if true_reshuffle:
                         random.seed(20220711 + epoch)
                         loader.true_reshuffle()
+                        order = list(range(len(loader)))
                     else:
-                        rng.shuffle(loader.data)
+                        rng.shuffle(order)
                 self.model.train()
-                mine = dp.shard_indices(len(loader), dp.rank(), W)
-                losses, seen, micro = [], 0, 0
+                mine = [order[i] for i in dp.shard_indices(len(loader), dp.rank(), W)]
+                # the trailing partial accumulation group is averaged over ITS size, not over `accum` (finetune_trainer.py:939-946)
+                n_full = len(mine) // accum * accum
+                rem = len(mine) - n_full
+                losses, scaled, seen, micro = [], [], 0, 0   # scaled: loss / average_factor, what the reference accumulates
                 t_ep = t_log = time.time()
                 fuse = bool(fuse_accumulation) and accum > 1
                 group = []
@@ -142,21 +216,30 @@ class ModelFinetuner:
                     seen += len(batch)
                     micro += 1
                     last = local_no == len(mine) - 1
+                    flush = micro == accum or last
+                    div = accum if local_no < n_full else rem   # this micro-batch's average_factor
+                    if reducer is not None and micro == 1:
+                        # the word ids of the whole accumulation group are known now: agree on the union of touched
+                        # embedding rows on the host while the GPU works (kbner.dp.GradReducer)
+                        grp = [loader[b2] for b2 in mine[local_no:local_no + div]]
+                        reducer.begin(self.model.touched_word_ids([sn for bt in grp for sn in bt]))
+                    hook = reducer.bucket_ready if (reducer is not None and flush and overlap_allreduce) else None
                     if fuse:
                         group.append(batch)
-                        if micro == accum or last:
+                        if flush:
                             sents = [sn for bt in group for sn in bt]
-                            wts = [1.0 / (accum * len(bt)) for bt in group for _ in bt]
-                            fused = self.model.forward_backward(sents, loss_scale=1.0, sentence_weights=wts)
+                            wts = [1.0 / (len(group) * len(bt)) for bt in group for _ in bt]
+                            fused = self.model.forward_backward(sents, loss_scale=1.0, sentence_weights=wts, grad_ready=hook)
                             # log the mean of the group's micro-batch losses, once per micro-batch, like the unfused loop
-                            losses += [fused * (float(accum) / len(group))] * len(group)
+                            losses += [fused] * len(group)
+                            scaled += [fused / div] * len(group)
                             group = []
                     else:
-                        losses.append(self.model.forward_backward(batch, loss_scale=1.0 / accum))
+                        losses.append(self.model.forward_backward(batch, loss_scale=1.0 / div, grad_ready=hook))
+                        scaled.append(losses[-1] / div)
                     store_embeddings(batch, embeddings_storage_mode)
-                    if micro == accum or last:
-                        scale = dp.all_reduce_sum_(self.model.engine.arena.g)
-                        # a short final group keeps the 1/accum scaling, exactly like the reference (:939-946,1007)
+                    if flush:
+                        scale = reducer.finish() if reducer is not None else 1.0
                         opt.step(grad_scale=scale)
                         micro = 0
                     if (local_no + 1) % log_every == 0 and is_main and len(losses) >= 1:
@@ -165,8 +248,10 @@ class ModelFinetuner:
                         log.info("epoch %d - iter %d/%d - loss %.8f - samples/sec: %.2f (x%d ranks)", epoch + 1, local_no + 1,
                                  len(mine), cur, log_every * mini_batch_size / max(dt, 1e-9), W)
                         t_log = time.time()
-                loss_sum = float(torch.stack(losses).sum()) if losses else 0.0
-                tot, cnt = dp.all_reduce_scalars([loss_sum, float(len(losses))])
+                # the reference's epoch loss is the mean of loss / average_factor over the micro-batches (:1003-1004,1070), i.e.
+                # 1/accum of the mean micro-batch loss; kept, so train_loss_history / loss.tsv read the same
+                loss_sum = float(torch.stack(scaled).sum()) if scaled else 0.0
+                tot, cnt = dp.all_reduce_scalars([loss_sum, float(len(scaled))])
                 train_loss = tot / max(cnt, 1.0)
                 train_loss_history.append(train_loss)
                 self.model.trained_epochs = epoch + 1
@@ -182,9 +267,11 @@ class ModelFinetuner:
                         for name, dl in zip(getattr(self.corpus, "targets", ["dev"]), dev_loaders):
                             res, dl_loss = self.model.evaluate(dl, embeddings_storage_mode=embeddings_storage_mode)
                             log.info("%s DEV : loss %.4f - f1 %.4f - macro %.4f", name, dl_loss, res.main_score, res.macro_score)
-                            f1s.append(res.macro_score if select_model_by_macro else res.main_score)
+                            # dataset-level macro average over the dev sets, in PERCENT (:1108-1126)
+                            f1s.append((res.macro_score if select_model_by_macro else res.main_score) * 100)
                             dls.append(dl_loss)
                         score = sum(f1s) / len(f1s)
+                        log.info("Dataset-Level Macro Average: %.2f\tDataset-Level Macro avg loss: %.2f", score, sum(dls) / len(dls))
                         dev_score_history.append(score)
                         dev_loss_history.append(sum(dls) / len(dls))
                     for name, tl in zip(getattr(self.corpus, "targets", ["test"]), test_loaders):
@@ -194,16 +281,24 @@ class ModelFinetuner:
                         f.write("%d\t%s\t%.3e\t%.6f\t%s\t%s\t_\n" % (epoch + 1, time.strftime("%H:%M:%S"), learning_rate * opt.lr_lambda(),
                                                                    train_loss, dev_loss_history[-1] if dev_loss_history else "_",
                                                                    score if score is not None else "_"))
-                    improved = score is not None and score > best_score
-                    if improved:
-                        best_score, bad_epochs = score, 0
-                        self.model.save(base_path / "best-model.pt")
-                        if save_finetuned_embedding:
-                            self.save_finetuned_embedding(base_path)
-                    elif score is not None:
-                        bad_epochs += 1
-                    if checkpoint:
-                        self.model.save_checkpoint(base_path / "checkpoint.pt", {"t": opt.t}, {}, epoch + 1, train_loss)
+                    if score is not None:
+                        if score > best_score:
+                            best_score, bad_epochs = score, 0
+                        else:
+                            bad_epochs += 1
+                        if score == best_score:   # (:1280-1298) also on a tie with the best so far, e.g. 0.0 in the first epochs
+                            log.info("==================Saving the current best model: %s==================", score)
+                            self.model.save(base_path / "best-model.pt")
+                            if save_finetuned_embedding:
+                                self.save_finetuned_embedding(base_path)
+                    if checkpoint and not param_selection_mode:
+                        # finetune_trainer.py:1261-1277: model + optimizer.state_dict() + scheduler.state_dict() + epoch + loss.
+                        # Here: Adam moments + step count, and what the LR schedule / batch order / dropout streams need
+                        self.model.save_checkpoint(base_path / "checkpoint.pt", opt.state_dict(),
+                                                   {"t": opt.t, "t_total": t_total, "warmup": warmup, "shuffle_rng": rng.getstate(),
+                                                    "order": list(order),
+                                                    "dropout_rng": self.model.engine._drop_rng.bit_generator.state},
+                                                   epoch + 1, train_loss)
                 stop = dp.broadcast_object(bad_epochs >= max_epochs_without_improvement if is_main else None)
                 if stop:
                     log.info("no improvement for %d epochs: stopping", bad_epochs)
@@ -265,5 +360,19 @@ class ModelFinetuner:
         return sum(scores) / max(1, len(scores))
 
     def assign_ext_context_doc(self, corpus):
-        """config 5 only (`assign_doc_for_ext_context`); the XLM-R + CRF configs feed the whole 'sentence <EOS> context' sequence"""
-        raise NotImplementedError("assign_doc_for_ext_context is a 'next' row (SURVEY.md §8f-1)")
+        """config 5 (`assign_doc_for_ext_context: true`, distillation_trainer.py:675-686): every sentence keeps an unchunked copy
+        as `sentence.doc_sent` -- what embeddings with `use_internal_doc` encode (embeddings.py:3116-3117) -- and is itself cut
+        at the first `<EOS>` token, so the tagger head (BiLSTM / CRF) only sees the real tokens."""
+        import copy
+        from torch.utils.data.dataset import ConcatDataset
+        for data_lists in (self.corpus.train_list, self.corpus.dev_list, self.corpus.test_list):
+            for data_list in data_lists:
+                for sentence in data_list:
+                    words = [w.text for w in sentence]
+                    sentence.doc_sent = copy.deepcopy(sentence)
+                    if "<EOS>" in words:
+                        sentence.chunk_sentence(0, words.index("<EOS>"))
+                    sentence.doc_pos = 0
+        self.corpus._train = ConcatDataset(list(self.corpus.train_list))
+        self.corpus._dev = ConcatDataset(list(self.corpus.dev_list))
+        self.corpus._test = ConcatDataset(list(self.corpus.test_list))

@@ -89,3 +89,164 @@ def broadcast_object(obj, src=0):
 def barrier():
     if world_size() > 1:
         dist.barrier()
+
+
+class _HipRowOps:
+    """device-side pieces of the exchange, all in libkbner_hip.so (the CPU gloo test injects torch stand-ins instead)"""
+
+    @staticmethod
+    def gather_rows(src2d, idx):
+        from . import ops
+        return ops.gather_rows_f32(src2d, idx)
+
+    @staticmethod
+    def scatter_rows(rows, idx, dst2d):
+        from . import ops
+        ops.scatter_rows_f32(rows, idx, dst2d)
+
+    @staticmethod
+    def to_bf16(x):
+        from . import ops
+        y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+        ops.f32_to_bf16(x, y)
+        return y
+
+    @staticmethod
+    def from_bf16(y, out):
+        from . import ops
+        ops.bf16_to_f32(y, out)
+
+
+class GradReducer:
+    """The gradient exchange of ONE optimizer step, overlapped with backward.
+
+    The gradient arena is laid out so that what backward finishes first is contiguous: the GEMM weights of layers
+    [4g, 4g+4) become final when their grouped weight-gradient launch has been enqueued (engine.encoder_backward), i.e.
+    6 x 201 MB buckets for XLM-R-large that complete one by one while backward still runs ~5/6 .. 0 of its length.
+
+      * `bucket_ready(lo, hi)` -- called by the engine right after it enqueued the kernels that finalise arena.g[lo:hi]:
+        issues `all_reduce(async_op=True)` on that slice.  ProcessGroupNCCL runs the collective on its own stream after an
+        event on the current (compute) stream, so RCCL moves bucket g over xGMI while the GPU computes layers below it.
+      * `finish()` -- after backward: exchanges what is left (embeddings, LayerNorm / bias vectors, head, transitions) and
+        makes the compute stream wait for every outstanding bucket.  The word-embedding gradient ([V=250002, H], 46 % of
+        all bytes) only becomes final at the very end of backward and cannot be hidden, but at most B*S of its rows are
+        non-zero per rank: `begin(touched_ids)` lets the ranks agree on the union of touched rows on the HOST (gloo) before
+        the forward pass, and when that union is below `sparse_threshold` of the vocabulary only those rows travel
+        (gather -> all-reduce [U, H] -> scatter back); otherwise the dense slice is reduced (optionally as bf16:
+        `compress_embedding=True`, a documented deviation from the fp32 mean gradient).
+    The result is the SUM over ranks in arena.g; the 1/W is applied by the AdamW kernel (grad_scale).  With world_size 1
+    everything is a no-op."""
+
+    def __init__(self, arena_g, emb_range=None, emb_width=None, sparse_threshold=0.5, compress_embedding=False, row_ops=None):
+        self.g = arena_g
+        self.emb_range = emb_range          # (lo, hi) element range of emb.word inside the arena, or None
+        self.emb_width = emb_width
+        self.sparse_threshold = sparse_threshold
+        self.compress_embedding = compress_embedding
+        self.ops = row_ops or _HipRowOps
+        self.works, self.covered = [], []
+        self.stats = {"buckets": 0, "bytes_overlapped": 0, "bytes_tail": 0, "emb_rows": None, "emb_mode": None}
+
+    def _cpu_group(self):
+        """host-side group for the touched-row ids (control plane): with the nccl backend a gloo group is created next to it,
+        so the id exchange never synchronises the host with the GPU stream"""
+        if getattr(self, "_cpu_pg", None) is None:
+            self._cpu_pg = dist.new_group(backend="gloo") if dist.get_backend() != "gloo" else dist.group.WORLD
+        return self._cpu_pg
+
+    def begin(self, touched_ids=None):
+        """start of an optimizer step.  touched_ids: the word ids (host integers, any shape) this rank will look up in the
+        step's micro-batches -- known before the forward pass, so the union over ranks is agreed on the host while the GPU
+        works, and only its rows of the word-embedding gradient travel in finish()."""
+        self.works, self.covered = [], []
+        self.stats = {"buckets": 0, "bytes_overlapped": 0, "bytes_tail": 0, "emb_rows": None, "emb_mode": None}
+        self._union = None
+        if world_size() == 1 or self.emb_range is None or touched_ids is None or self.sparse_threshold <= 0:
+            return
+        import numpy as np
+        V = (self.emb_range[1] - self.emb_range[0]) // self.emb_width
+        mine = np.unique(np.asarray(touched_ids, dtype=np.int64).ravel())
+        pg = self._cpu_group()
+        cnt = torch.tensor([mine.size], dtype=torch.int64)
+        cnts = [torch.zeros(1, dtype=torch.int64) for _ in range(world_size())]
+        dist.all_gather(cnts, cnt, group=pg)
+        cap = max(int(c) for c in cnts)
+        if cap >= self.sparse_threshold * V:   # one rank alone already touches too much: dense exchange
+            return
+        pad = torch.full((cap,), -1, dtype=torch.int64)
+        pad[:mine.size] = torch.from_numpy(mine)
+        allp = [torch.empty_like(pad) for _ in range(world_size())]
+        dist.all_gather(allp, pad, group=pg)
+        union = np.unique(np.concatenate([t.numpy() for t in allp]))
+        union = union[union >= 0]
+        if union.size < self.sparse_threshold * V:
+            self._union = torch.from_numpy(union.astype(np.int32)).to(self.g.device, non_blocking=True)
+
+    def bucket_ready(self, lo, hi):
+        if world_size() == 1 or hi <= lo:
+            return
+        self.works.append(dist.all_reduce(self.g[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+        self.covered.append((lo, hi))
+        self.stats["buckets"] += 1
+        self.stats["bytes_overlapped"] += 4 * (hi - lo)
+
+    def _complement(self, skip):
+        """ranges of [0, n) neither reduced by a bucket nor listed in `skip`"""
+        done = sorted(self.covered + list(skip))
+        out, cur = [], 0
+        for lo, hi in done:
+            if lo > cur:
+                out.append((cur, lo))
+            cur = max(cur, hi)
+        if cur < self.g.numel():
+            out.append((cur, self.g.numel()))
+        return out
+
+    def _exchange_embedding(self):
+        lo, hi = self.emb_range
+        H = self.emb_width
+        V = (hi - lo) // H
+        g2 = self.g[lo:lo + V * H].view(V, H)
+        if self._union is not None:
+            mode = "sparse"
+            idx = self._union
+            rows = self.ops.gather_rows(g2, idx)
+            dist.all_reduce(rows, op=dist.ReduceOp.SUM)
+            self.ops.scatter_rows(rows, idx, g2)
+            self.stats["emb_rows"] = int(idx.numel())
+            self.stats["bytes_tail"] += 4 * H * int(idx.numel())
+        elif self.compress_embedding:
+            mode = "dense_bf16"
+            half = self.ops.to_bf16(self.g[lo:hi])
+            dist.all_reduce(half, op=dist.ReduceOp.SUM)
+            self.ops.from_bf16(half, self.g[lo:hi])
+            self.stats["bytes_tail"] += 2 * (hi - lo)
+        else:
+            mode = "dense"
+            dist.all_reduce(self.g[lo:hi], op=dist.ReduceOp.SUM)
+            self.stats["bytes_tail"] += 4 * (hi - lo)
+        self.stats["emb_mode"] = mode
+
+    def finish(self):
+        """after the step's last backward: -> the 1/W factor AdamW must apply"""
+        w = world_size()
+        if w == 1:
+            return 1.0
+        skip = []
+        if self.emb_range is not None:
+            self._exchange_embedding()
+            skip.append(tuple(self.emb_range))
+        for lo, hi in self._complement(skip):
+            dist.all_reduce(self.g[lo:hi], op=dist.ReduceOp.SUM)
+            self.stats["bytes_tail"] += 4 * (hi - lo)
+        for wk in self.works:
+            wk.wait()   # nccl: the compute stream waits on the collective's event (no host block); gloo: host wait
+        self.works = []
+        return 1.0 / w
+
+
+def broadcast_params_(flat, src=0):
+    """make every replica start from rank `src`'s parameters (the tagger head / transitions are drawn from each process's
+    own torch seed otherwise -- ADVICE r1, high)"""
+    if world_size() > 1:
+        dist.broadcast(flat, src=src)

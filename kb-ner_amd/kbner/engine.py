@@ -389,8 +389,11 @@ class Tagger:
         self._enc_saved = (ids, pos_ids, maskbias, B, S, d_emb, d_layers)
         return ac.x[L]
 
-    def encoder_backward(self, dx_top):
-        """dx_top bf16 [Mp,H] = d loss / d last hidden state; accumulates into arena.g."""
+    def encoder_backward(self, dx_top, grad_ready=None):
+        """dx_top bf16 [Mp,H] = d loss / d last hidden state; accumulates into arena.g.
+        grad_ready(lo, hi): called right after the launches that finalise arena.g[lo:hi] were enqueued -- the GEMM-weight
+        gradients of a whole WGRAD_GROUP of layers (contiguous in the arena) -- so a data-parallel trainer can start that
+        bucket's all-reduce while backward continues below (kbner.dp.GradReducer)."""
         cfg, a = self.cfg, self.arena
         H, F_, A, L = cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads, cfg.num_hidden_layers
         ids, pos_ids, maskbias, B, S, d_emb, d_layers = self._enc_saved
@@ -437,6 +440,11 @@ class Tagger:
             if l % WGRAD_GROUP == 0:
                 self._wgrads(pending, Mp)
                 pending = []
+                if grad_ready is not None:
+                    hi_l = min(l + WGRAD_GROUP, L)
+                    lo_off = a.offsets["l%d.qkv.weight" % l]
+                    hi_off = a.offsets["l%d.qkv.weight" % hi_l] if hi_l < L else a.offsets["emb.word"]
+                    grad_ready(lo_off, hi_off)
             dx = ac.dx
         ops.embed_ln_bwd(dx, ac.h0, ac.emb_mean, ac.emb_rstd, a.param("emb.ln.g"), ids, pos_ids, a.grad("emb.ln.g"),
                          a.grad("emb.ln.b"), a.grad("emb.word"), a.grad("emb.pos"), a.grad("emb.type")[0], drop=d_emb)
@@ -459,16 +467,16 @@ class Tagger:
         em = ops.head_fwd(pooled, self.arena.param("linear.weight"), self.arena.param("linear.bias"))
         return em.view(B, n, self.T), pooled
 
-    def forward_loss(self, batch, loss_scale=1.0, backward=True, weights=None):
+    def forward_loss(self, batch, loss_scale=1.0, backward=True, weights=None, grad_ready=None):
         """One micro-batch: encoder -> kept-token gather -> head -> CRF NLL (mean over sentences,
         sequence_tagger_model.py:2499-2506) and, if `backward`, the full backward pass accumulating
         loss_scale * d loss into arena.g.  Returns the loss as a 0-d device tensor (no host sync).
         weights: optional f32[B] per-sentence weights replacing the 1/B of the mean (the trainer uses it to run the
         micro-batches of one gradient-accumulation group as ONE batch with weights 1/(accumulate * |micro-batch|))."""
         with L_.stream_scope():
-            return self._forward_loss(batch, loss_scale, backward, weights)
+            return self._forward_loss(batch, loss_scale, backward, weights, grad_ready)
 
-    def _forward_loss(self, batch, loss_scale, backward, weights):
+    def _forward_loss(self, batch, loss_scale, backward, weights, grad_ready=None):
         B, S = batch["B"], batch["S"]
         R = batch.get("R", B)  # encoder rows (> B when long sentences were split into sliding windows)
         hidden = self.encoder_forward(batch["ids"], batch["pos_ids"], batch["maskbias"], R, S)
@@ -503,7 +511,7 @@ class Tagger:
             ac = self.acts(R, S)
             ac.dx.zero_()
             ops.scatter_rows(dpooled, crow_idx, ac.dx)
-            self.encoder_backward(ac.dx)
+            self.encoder_backward(ac.dx, grad_ready)
         return loss[0]
 
     def forward_features(self, batch):
@@ -533,6 +541,21 @@ class FusedAdamW:
         self.ws = torch.zeros(L.load().kbner_sqnorm_ws_floats(), dtype=F32, device=arena.device)
         self.norm_sq = torch.zeros(1, dtype=F32, device=arena.device)
         self.split = arena.offsets["transitions"]
+
+    def state_dict(self):
+        """what a resume needs (the reference stores optimizer.state_dict(), finetune_trainer.py:1261-1277): the step count and
+        the two Adam moment arenas (host copies; 2 x 2.24 GB for XLM-R-large, like the reference's exp_avg / exp_avg_sq)"""
+        a = self.arena
+        return {"t": self.t, "n": a.n, "m": a.m.detach().cpu(), "v": a.v.detach().cpu()}
+
+    def load_state_dict(self, sd):
+        a = self.arena
+        if int(sd["n"]) != a.n:
+            raise ValueError("optimizer state holds %d elements, the arena %d" % (int(sd["n"]), a.n))
+        a.ensure_state()
+        a.m.copy_(sd["m"].to(a.device))
+        a.v.copy_(sd["v"].to(a.device))
+        self.t = int(sd["t"])
 
     def lr_lambda(self):
         if self.t_total is None:

@@ -25,6 +25,7 @@ SIGNATURES = {
     "kbner_gather_rows": (c_int, [P, P, P, c_int, c_int, P]),
     "kbner_gather_rows_f32": (c_int, [P, P, P, c_int, c_int, P]),
     "kbner_scatter_rows": (c_int, [P, P, P, c_int, c_int, P]),
+    "kbner_scatter_rows_f32": (c_int, [P, P, P, c_int, c_int, P]),
     "kbner_head_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
     "kbner_head_bwd_dx": (c_int, [P, P, P, c_int, c_int, c_int, P]),
     "kbner_head_bwd_dw": (c_int, [P, P, P, P, c_int, c_int, c_int, P]),
@@ -46,6 +47,7 @@ SIGNATURES = {
     "kbner_adamw_hf": (c_int, [P, P, P, P, P, c_size_t, c_size_t, c_float, c_float, c_float, c_float, c_float, P, c_float,
                                c_float, c_int, P]),
     "kbner_f32_to_bf16": (c_int, [P, P, c_size_t, P]),
+    "kbner_bf16_to_f32": (c_int, [P, P, c_size_t, P]),
     "kbner_wdiff_sum": (c_int, [P, P, P, c_int, P, P]),
     "kbner_probe_tr": (c_int, [P, P, P]),
     "kbner_probe_mfma": (c_int, [P, P, P, P]),

@@ -100,6 +100,12 @@ def gather_rows_f32(src, idx):
     return out
 
 
+def scatter_rows_f32(rows, idx, dst):
+    """dst f32[V, W][idx[r], :] = rows f32[R, W][r, :] (unique indices; idx < 0 skipped)"""
+    _chk(rows, F32, "rows"); _chk(idx, I32, "idx"); _chk(dst, F32, "dst")
+    L.call("kbner_scatter_rows_f32", ptr(rows), ptr(idx), ptr(dst), idx.numel(), rows.shape[-1], stream_ptr())
+
+
 def scatter_rows(dout, idx, dsrc):
     _chk(dout, BF16, "dout"); _chk(idx, I32, "idx"); _chk(dsrc, BF16, "dsrc")
     L.call("kbner_scatter_rows", ptr(dout), ptr(idx), ptr(dsrc), idx.numel(), dout.shape[-1], stream_ptr())
@@ -284,6 +290,10 @@ def adamw(p, g, m, v, shadow, n_shadow, step_size, lr_wd, b1, b2, eps, gnorm_sq,
 
 def f32_to_bf16(x, y):
     L.call("kbner_f32_to_bf16", ptr(x), ptr(y), x.numel(), stream_ptr())
+
+
+def bf16_to_f32(x, y):
+    L.call("kbner_bf16_to_f32", ptr(x), ptr(y), x.numel(), stream_ptr())
 
 
 def wdiff_sum(a, b, w, out):

@@ -122,6 +122,74 @@ class HFAdamW:
         return _Impl(params, lr, betas, eps, weight_decay, correct_bias)
 
 
+class TokenizerAdapter:
+    """transformers-3.0.0 tokenizer surface the reference uses (flair/embeddings.py:3001-3004,3143-3163,3173,3200-3227) over
+    a transformers-5.x fast tokenizer, which has neither `_eos_token` nor `encode_plus(ids, ...)` (without
+    them the reference silently takes the `else` branch at :3228-3230 and feeds ids WITHOUT <s> </s> while still using
+    begin_offset=1).  encode_plus restates the 3.0.0 semantics for a list of ids: `<s> ids[:max_length-2] </s>`; with
+    return_overflowing_tokens the overflow is the tail that did not fit, preceded by `stride` ids of overlap."""
+
+    def __init__(self, tok):
+        self.__dict__["_tok"] = tok
+        for a in ("eos", "sep", "bos", "cls", "pad", "unk"):
+            self.__dict__["_%s_token" % a] = getattr(tok, a + "_token", None)
+
+    def __getattr__(self, name):
+        return getattr(self.__dict__["_tok"], name)
+
+    def __len__(self):
+        return len(self._tok)
+
+    def tokenize(self, text, **kw):
+        return self._tok.tokenize(text, **kw)
+
+    def convert_tokens_to_ids(self, toks):
+        return self._tok.convert_tokens_to_ids(toks)
+
+    def encode_plus(self, ids, max_length=None, stride=0, return_overflowing_tokens=False, truncation=True, **kw):
+        ids = list(ids)
+        bos, eos = self._tok.bos_token_id, self._tok.eos_token_id
+        if bos is None:
+            bos = self._tok.cls_token_id
+        if eos is None:
+            eos = self._tok.sep_token_id
+        out = {}
+        room = len(ids) if max_length is None else max_length - 2
+        if truncation and len(ids) > room:
+            # truncation=True selects 'longest_first', whose 3.0.0 loop removes ONE id at a time from the end: the first
+            # removal records the last stride+1 ids, every later one appends the id it removes -- so the overflow is the
+            # window's tail followed by the earlier ids in REVERSE order (a defect of that release, fixed later; restated from
+            # the published 3.0.0 algorithm, which cannot be installed here).  The build's product path implements the intended
+            # semantics (next window restarts `stride` ids before the cut); KB-NER data never exceeds one window in training
+            # (kb/context_process.py:974), so goldens captured through this adapter never reach this branch.
+            overflow = []
+            for _ in range(len(ids) - room):
+                w = min(len(ids), stride + 1) if not overflow else 1
+                overflow.extend(ids[-w:])
+                ids = ids[:-1]
+            if return_overflowing_tokens:
+                out["overflowing_tokens"] = overflow
+        out["input_ids"] = [bos] + ids + [eos]
+        return out
+
+    def save_pretrained(self, path, **kw):
+        return self._tok.save_pretrained(path, **kw)
+
+
+def wrap_auto_tokenizer():
+    """AutoTokenizer.from_pretrained (flair/embeddings.py:2951) returns the adapter"""
+    import transformers
+    if getattr(transformers.AutoTokenizer, "_kbner_wrapped", False):
+        return
+    orig = transformers.AutoTokenizer.from_pretrained
+
+    def from_pretrained(*a, **k):
+        return TokenizerAdapter(orig(*a, **k))
+
+    transformers.AutoTokenizer.from_pretrained = staticmethod(from_pretrained)
+    transformers.AutoTokenizer._kbner_wrapped = True
+
+
 _installed = False
 
 

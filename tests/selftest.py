@@ -1,18 +1,19 @@
-"""GPU self-checks of the HIP path against the oracle (oracle/ is imported HERE only as the checker:
-this module is used by tests/, __graft_entry__.smoke() and tools/gpu_diag.py -- never by the product path)."""
+"""TEST INFRASTRUCTURE: GPU self-checks of the HIP path against the oracle (oracle/ is imported HERE as the checker; this
+module is used by tests/, __graft_entry__.smoke() and tools/gpu_diag.py -- it is not part of the kb-ner_amd product package)."""
 import os
 import sys
 
 import numpy as np
 import torch
 
-from . import batch as kb
-from . import engine, ops
-from .lib import EPI_ADD, EPI_ATOMIC32, EPI_BIAS, EPI_DGELU, EPI_GELU, EPI_RMW32, GEMM_NN, GEMM_NT, GEMM_TN
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for _p in (ROOT, os.path.join(ROOT, "kb-ner_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-if ROOT not in sys.path:
-    sys.path.insert(0, ROOT)
+from kbner import batch as kb  # noqa: E402
+from kbner import engine, ops  # noqa: E402
+from kbner.lib import EPI_ADD, EPI_ATOMIC32, EPI_BIAS, EPI_DGELU, EPI_GELU, EPI_RMW32, GEMM_NN, GEMM_NT, GEMM_TN  # noqa: E402
 
 BF16, F32, I32 = torch.bfloat16, torch.float32, torch.int32
 DEV = "cuda"
@@ -32,7 +33,7 @@ def cosine(a, b):
 
 # ------------------------------------------------------------------ probes
 def probe_tr():
-    from . import lib as L
+    from kbner import lib as L
     inp = torch.arange(2048, dtype=torch.int16, device=DEV)
     out = torch.zeros(256, dtype=torch.int16, device=DEV)
     L.call("kbner_probe_tr", L.ptr(inp), L.ptr(out), L.stream_ptr())
@@ -47,7 +48,7 @@ def probe_tr():
 
 
 def probe_mfma():
-    from . import lib as L
+    from kbner import lib as L
     g = torch.Generator(device="cpu").manual_seed(3)
     a = torch.randn(16, 32, generator=g).to(BF16)
     b = torch.randn(16, 32, generator=g).to(BF16)
@@ -554,7 +555,7 @@ def check_adamw(n=4096 + 64, seed=0):
     md = torch.zeros(n, dtype=F32, device=DEV)
     vd = torch.zeros(n, dtype=F32, device=DEV)
     sh = torch.zeros(n, dtype=BF16, device=DEV)
-    from . import lib as L
+    from kbner import lib as L
     ws = torch.zeros(L.load().kbner_sqnorm_ws_floats(), dtype=F32, device=DEV)
     nsq = torch.zeros(1, dtype=F32, device=DEV)
     worst = 0.0
@@ -580,9 +581,9 @@ def check_adamw(n=4096 + 64, seed=0):
 def smoke():
     r = check_step()
     print("smoke:", r)
-    assert r["loss_rel"] < 3e-2, r
-    assert r["grad_min_cos"] > 0.98, r
+    assert r["loss_rel"] < 7e-4, r          # 3x the round-1 driver observation (2.3e-4)
+    assert r["grad_min_cos"] > 0.9998, r    # observed 0.99993
     assert r["viterbi_equal"], r
     t = check_train_steps(steps=2)
     print("smoke train steps:", {k: v for k, v in t.items() if not k.startswith("dcos_")})
-    assert t["loss_rel_max"] < 5e-2 and t["norm_rel_max"] < 1e-1, t
+    assert t["loss_rel_max"] < 1.5e-3 and t["norm_rel_max"] < 5.1e-4, t   # observed 4.7e-4 / 1.7e-4

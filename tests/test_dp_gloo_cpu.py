@@ -80,8 +80,43 @@ def _worker(rank, world, port, out):
                  dp.steps_per_epoch(10, 4), dp.broadcast_object({"stop": False})))
     else:
         dp.broadcast_object(None)
-    dp.barrier()
+    # 4. overlapped exchange protocol (kbner.dp.GradReducer): async buckets + host-agreed union of touched embedding rows
+    #    == one dense all-reduce of the whole arena, for a sparse step, a dense step and the bf16-compressed variant
     import torch.distributed as dist
+
+    class _TorchRows:   # CPU stand-ins for the HIP row kernels (gather / scatter / bf16 pack) -- test only
+        gather_rows = staticmethod(lambda src, idx: src.index_select(0, idx.long()))
+        scatter_rows = staticmethod(lambda rows, idx, dst: dst.index_copy_(0, idx.long(), rows))
+        to_bf16 = staticmethod(lambda x: x.to(torch.bfloat16))
+        from_bf16 = staticmethod(lambda y, out: out.copy_(y.float()))
+
+    V, H, n = 64, 16, 5000
+    lo = 2000
+    checks = []
+    for case, n_touch, compress in (("sparse", 5, False), ("dense", 60, False), ("dense_bf16", 60, True)):
+        gen = torch.Generator().manual_seed(100 + rank)
+        g = torch.randn(n, generator=gen)
+        touched = torch.randperm(V, generator=gen)[:n_touch]
+        emb = torch.zeros(V, H)
+        emb[touched] = torch.randn(n_touch, H, generator=gen)
+        g[lo:lo + V * H] = emb.flatten()
+        want = g.clone()
+        dist.all_reduce(want)
+        red = dp.GradReducer(g, emb_range=(lo, lo + V * H), emb_width=H, compress_embedding=compress, row_ops=_TorchRows)
+        red.begin(touched.numpy())
+        red.bucket_ready(1000, 2000)     # the order backward finishes them: top layers first
+        red.bucket_ready(0, 1000)
+        scale = red.finish()
+        tol = 2e-2 if compress else 1e-6
+        checks.append((case, red.stats["emb_mode"], float((g - want).abs().max()) <= tol * float(want.abs().max()), scale,
+                       red.stats["buckets"], red.stats["bytes_overlapped"]))
+    # 5. replicas start identical: broadcast of the parameter arena from rank 0
+    p = torch.full((100,), float(rank + 7))
+    dp.broadcast_params_(p)
+    same = bool(torch.all(p == 7.0))
+    if rank == 0:
+        out.put(("reducer", checks, same))
+    dp.barrier()
     dist.destroy_process_group()
 
 
@@ -93,9 +128,16 @@ def test_dp_two_ranks_gloo():
     for p in procs:
         p.start()
     res = out.get(timeout=240)
+    res2 = out.get(timeout=240)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
+    tag, checks, same = res2
+    assert tag == "reducer" and same
+    modes = {c[0]: c[1] for c in checks}
+    assert modes == {"sparse": "sparse", "dense": "dense", "dense_bf16": "dense_bf16"}, modes
+    for case, mode, ok, scale, nb, nbytes in checks:
+        assert ok and scale == 0.5 and nb == 2 and nbytes == 8000, (case, mode, ok, scale, nb, nbytes)
     err, gmax, loss_dp, loss_full, steps, obj = res
     assert err <= 2e-5 * max(gmax, 1.0), res          # same gradient up to fp32 summation order
     assert abs(loss_dp - loss_full) <= 1e-5 * abs(loss_full)

@@ -14,24 +14,7 @@ pytestmark = pytest.mark.gpu
 def workdir(tmp_path_factory):
     import tiny_assets
     d = tmp_path_factory.mktemp("e2e")
-    tiny_assets.build_model_dir(str(d / "xlmr-tiny"))
-    tiny_assets.write_conll_corpus(str(d / "data"), n_train=32, n_dev=8, n_test=8)
-    cfg = {
-        "ModelFinetuner": {"distill_mode": False, "sentence_level_batch": True},
-        "embeddings": {"TransformerWordEmbeddings-0": {"fine_tune": True, "layers": "-1", "model": str(d / "xlmr-tiny"),
-                                                        "pooling_operation": "first"}},
-        "model": {"FastSequenceTagger": {"crf_attention": False, "dropout": 0.0, "hidden_size": 256, "locked_dropout": 0.0,
-                                         "remove_x": True, "sentence_loss": True, "use_cnn": False, "use_crf": True,
-                                         "use_rnn": False, "word_dropout": 0.1}},
-        "model_name": "tiny_run", "target_dir": str(d / "out"), "targets": "ner", "trainer": "ModelFinetuner",
-        "ner": {"Corpus": "ColumnCorpus-TINY", "tag_dictionary": str(d / "tags.pkl"),
-                "ColumnCorpus-TINY": {"column_format": {0: "text", 1: "pos", 2: "upos", 3: "ner"}, "comment_symbol": "# id",
-                                      "data_folder": str(d / "data"), "tag_to_bioes": "ner"}},
-        "train": {"embeddings_storage_mode": "none", "fine_tune_mode": True, "gradient_accumulation_steps": 2,
-                  "learning_rate": 2.0e-3, "lr_rate": 50, "max_epochs": 6, "mini_batch_size": 4, "monitor_test": False,
-                  "save_finetuned_embedding": True, "select_model_by_macro": True, "train_with_dev": False,
-                  "true_reshuffle": False, "use_warmup": False},
-    }
+    cfg = tiny_assets.e2e_config(str(d), word_dropout=0.1, max_epochs=6, n_train=32, n_dev=8, n_test=8)
     with open(d / "cfg.yaml", "w") as f:
         yaml.safe_dump(cfg, f)
     return d
@@ -55,6 +38,7 @@ def test_yaml_to_trained_model(workdir):
     hist = out["train_loss_history"]
     assert len(hist) == 6 and hist[-1] < 0.8 * hist[0], hist                 # it learns
     assert len(out["dev_score_history"]) == 6
+    assert all(0.0 <= x <= 100.0 for x in out["dev_score_history"])      # dataset-level macro average, in percent
     base = cp.get_target_path
     for f in ("training.log", "loss.tsv", "final-model.pt", "best-model.pt"):
         assert (base / f).exists(), f
@@ -225,11 +209,11 @@ def test_bench_two_ranks_one_gpu_functional():
 def test_full_size_step_vs_oracle():
     """BASELINE size for real: XLM-R-large dimensions (L24/H1024/A16/F4096, V=250002), two ragged 512-token sentences, one
     forward + backward on the HIP path vs the oracle's fp32 autograd on the host CPU (~1 min)."""
-    from kbner import selftest as st
+    import selftest as st
     r = st.check_step(H=1024, A=16, F_=4096, L=24, S=512, V=250002, std=0.02)
     assert r["loss_rel"] < 3e-2, r
     assert r["emissions_rel"] < 5e-2, r
-    assert r["grad_min_cos"] > 0.95 and r["grad_worst_rel"] < 0.3, r
+    assert r["grad_min_cos"] > 0.98 and r["grad_worst_rel"] < 0.2, r    # observed 0.991 / 0.13 (DESIGN.md §4)
     assert r["grad_linear.weight"] < 5e-2 and r["grad_transitions"] < 5e-2, r
     assert r["viterbi_equal"], r
 
@@ -262,3 +246,243 @@ def test_accumulation_fusion_is_the_same_gradient(workdir):
     cos = float((a @ b) / (a.norm() * b.norm()))
     assert cos > 0.995, cos                                # bf16 kernels, different padding: not bit-identical
     assert abs(float(a.norm() / b.norm()) - 1.0) < 2e-2
+
+
+
+# ------------------------------------------------------------------ the reference's own entry-script surface, on live objects
+def test_train_surface_live(workdir):
+    """tests/golden/train_surface.json (ast of the reference's train.py): every attribute it READS on the student / trainer /
+    corpus / config-parser / embedding objects exists on the live mirror objects, and the calls it makes are accepted"""
+    import json
+    import flair
+    from flair.config_parser import ConfigParser
+    from flair.custom_data_loader import ColumnDataLoader
+    from flair.utils.from_params import Params
+    surface = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "train_surface.json")))
+    cp = ConfigParser(Params.from_file(str(workdir / "cfg.yaml")), all=False, zero_shot=False, other_shot=False, predict=False,
+                      save_embedding=False)
+    student = cp.create_student(nocrf=False)
+    trainer = getattr(flair.trainers, cp.config["trainer"])(student, None, cp.corpus, config=cp.config,
+                                                             **cp.config["ModelFinetuner"], is_test=True)
+    live = {"tagger": student, "trainer": trainer, "corpus": cp.corpus, "config_parser": cp,
+            "embedding": student.embeddings.embeddings[0], "stacked_embeddings": student.embeddings,
+            "dictionary": student.tag_dictionary, "flair_module": flair}
+    skip = {("embedding", "ee"), ("embedding", "is_hit_elmo"), ("tagger", "is_mst")}
+    missing = []
+    for role, obj in live.items():
+        for name, uses in surface["attributes"].get(role, {}).items():
+            if uses["load"] and not name.startswith("__") and (role, name) not in skip and not hasattr(obj, name):
+                missing.append("%s.%s" % (role, name))
+    assert not missing, missing
+    # the loader / evaluate calls of train.py:153-155 (speed test) and :398-400 (parse)
+    test_loader = ColumnDataLoader(list(trainer.corpus.test), 32, use_bert=trainer.use_bert, tokenizer=trainer.bert_tokenizer,
+                                   sort_data=False, model=student, sentence_level_batch=True)
+    test_loader.assign_tags(student.tag_type, student.tag_dictionary)
+    student.eval()
+    res, loss = student.evaluate(test_loader, embeddings_storage_mode="none", speed_test=True)
+    res, loss = student.evaluate(test_loader, out_path=workdir / "parse.conllu", embeddings_storage_mode="none", prediction_mode=True)
+    assert res.detailed_results and isinstance(res.main_score, float)
+    assert sum(1 for _ in student.named_parameters()) > 3 and hasattr(student, "named_modules")
+
+
+# ------------------------------------------------------------------ G5 on the PRODUCT path
+def test_obtain_labels_product_path_vs_reference_golden(workdir, golden_dir):
+    """FastSequenceTagger._obtain_labels (HIP Viterbi + host re-padding) against the reference-captured obtain_labels.npz in
+    BOTH orders: (a) evaluate order -- _calculate_loss ran first and narrowed self.mask to the non-S-X tokens, context is
+    re-padded with S-X / 1; (b) speed_test order -- self.mask is the plain length mask, the context is decoded too
+    (sequence_tagger_model.py:1193-1210, 2618-2622)"""
+    from flair.data import Dictionary, Sentence
+    from flair.embeddings import StackedEmbeddings, TransformerWordEmbeddings
+    from flair.models import FastSequenceTagger
+    g = np.load(os.path.join(golden_dir, "obtain_labels.npz"))
+    items = [str(x) for x in g["items"]]
+    td = Dictionary(add_unk=False)
+    for it in items:
+        td.add_item(it)
+    emb = TransformerWordEmbeddings(model=str(workdir / "xlmr-tiny"), layers="-1", pooling_operation="first", fine_tune=True)
+    tagger = FastSequenceTagger(hidden_size=256, embeddings=StackedEmbeddings([emb]), tag_dictionary=td, tag_type="ner",
+                                use_crf=True, use_rnn=False, remove_x=True, dropout=0.0, locked_dropout=0.0, word_dropout=0.0)
+    assert (tagger.start_idx, tagger.stop_idx) == (int(g["start"]), int(g["stop"])) and tagger.x_idx == int(g["x_idx"])
+    tagger.engine.set_param("transitions", torch.from_numpy(g["trans"]))
+    feats, lengths, tags = g["feats"], g["lengths"], g["tags"]
+    B, n, T = feats.shape
+
+    class _S:   # what _obtain_labels reads: len(sentence) and the loader's tag-id row
+        def __init__(self, k, row):
+            self.tokens, self.ner_tags = [None] * k, row
+
+        def __len__(self):
+            return len(self.tokens)
+
+    sents = [_S(int(lengths[b]), tags[b]) for b in range(B)]
+    ft = torch.from_numpy(feats).cuda()
+    length_mask = (torch.arange(n)[None, :] < torch.from_numpy(lengths)[:, None]).float().cuda()
+    keep = length_mask.bool().cpu().numpy() & (tags != int(g["x_idx"]))
+    for order, mask in (("a", torch.from_numpy(keep.astype(np.float32)).cuda()), ("b", length_mask)):
+        tagger.mask = mask
+        labels, _ = tagger._obtain_labels(ft, sents)
+        for b in range(B):
+            got_t = np.asarray([td.get_idx_for_item(l.value) for l in labels[b]], np.int32)
+            got_c = np.asarray([l.score for l in labels[b]], np.float32)
+            np.testing.assert_array_equal(got_t, g["%s%d_tags" % (order, b)], err_msg="%s %d" % (order, b))
+            np.testing.assert_allclose(got_c, g["%s%d_conf" % (order, b)], rtol=2e-6, err_msg="%s %d" % (order, b))
+
+
+# ------------------------------------------------------------------ G12: the whole drop-in path vs the reference's own run
+@pytest.fixture(scope="module")
+def g12(tmp_path_factory):
+    import json
+    import tiny_assets
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    e2e = json.load(open(os.path.join(gold, "e2e_train.json"), encoding="utf-8"))
+    arrs = np.load(os.path.join(gold, "e2e_train.npz"))
+    d = tmp_path_factory.mktemp("g12")
+    cfg = tiny_assets.e2e_config(str(d), **e2e["config_kwargs"])
+    with open(d / "cfg.yaml", "w") as f:
+        yaml.safe_dump(cfg, f)
+    return d, e2e, arrs
+
+
+def _student_from(d, arrs, prefix):
+    from flair.config_parser import ConfigParser
+    from flair.utils.from_params import Params
+    cp = ConfigParser(Params.from_file(str(d / "cfg.yaml")))
+    student = cp.create_student()
+    for k in ("linear.weight", "linear.bias", "transitions"):
+        student.engine.set_param(k, torch.from_numpy(arrs[prefix + "/" + k]))
+    return cp, student
+
+
+def test_training_trajectory_vs_reference_run(g12):
+    """ModelFinetuner.train on the HIP engine from the reference run's initial head / transitions, same YAML, no dropout, no
+    shuffling: per-micro-batch losses, epoch losses (the reference's loss/accum convention), dev scores (percent) and the final
+    transitions against what the reference's own ModelFinetuner.train produced (tests/golden/e2e_train.*).
+    Tolerances: bf16 GEMMs/attention vs the reference's fp32 -- first-epoch step losses 2 %, epoch losses 10 % (Adam at
+    lr*lr_rate = 0.1 on the transitions amplifies rounding over 80 steps), transition movement cosine > 0.9."""
+    from flair.trainers import ModelFinetuner
+    d, e2e, arrs = g12
+    cp, student = _student_from(d, arrs, "init")
+    steps = []
+    fb = student.forward_backward
+
+    def spy(*a, **k):
+        out = fb(*a, **k)
+        steps.append(out)
+        return out
+
+    student.forward_backward = spy
+    trainer = ModelFinetuner(student, None, cp.corpus, config=cp.config, **cp.config["ModelFinetuner"])
+    out = trainer.train(cp.get_target_path, fuse_accumulation=False, **cp.config["train"])
+    mine = [float(x) for x in steps]
+    ref = e2e["step_losses"]
+    assert len(mine) == len(ref)
+    n_ep = len(ref) // len(e2e["train_loss_history"])
+    first = max(abs(a - b) / abs(b) for a, b in zip(mine[:n_ep], ref[:n_ep]))
+    hist = max(abs(a - b) / abs(b) for a, b in zip(out["train_loss_history"], e2e["train_loss_history"]))
+    print("G12 first-epoch step loss rel", first, "epoch loss rel", hist, "dev", out["dev_score_history"], e2e["dev_score_history"])
+    assert first < 2e-2, (mine[:n_ep], ref[:n_ep])
+    assert hist < 1e-1, (out["train_loss_history"], e2e["train_loss_history"])
+    assert len(out["dev_score_history"]) == len(e2e["dev_score_history"])
+    t0, t1 = arrs["init/transitions"], arrs["final/transitions"]
+    live = t0 > -1e11
+    mv_ref = (t1 - t0)[live]
+    mv = (student.transitions.detach().cpu().numpy() - t0)[live]
+    cos = float((mv @ mv_ref) / (np.linalg.norm(mv) * np.linalg.norm(mv_ref)))
+    print("G12 transition movement cosine", cos)
+    assert cos > 0.9, cos
+
+
+@pytest.mark.parametrize("part", ["dev", "test"])
+def test_evaluate_with_reference_weights_vs_reference_lines(g12, part):
+    """the reference run's TRAINED weights loaded into the HIP engine, then FastSequenceTagger.evaluate on the same loader: the
+    prediction file (token, gold, predicted tag) and the Result against the reference's own evaluate output.  bf16 emissions can
+    flip a near-tie, so up to 2 % of the real-token tags may differ; when none does, the Result must be identical."""
+    from flair.custom_data_loader import ColumnDataLoader
+    d, e2e, arrs = g12
+    cp, student = _student_from(d, arrs, "final")
+    student.engine.load_hf_state_dict({k[len("final_enc/"):]: torch.from_numpy(arrs[k]) for k in arrs.files if k.startswith("final_enc/")})
+    student.eval()
+    lst = cp.corpus.dev_list if part == "dev" else cp.corpus.test_list
+    dl = ColumnDataLoader(list(lst[0]), 4, False, use_bert=False, sort_data=True, sentence_level_batch=True, model=student)
+    dl.assign_tags("ner", cp.tag_dictionary)
+    res, loss = student.evaluate(dl, out_path=d / (part + ".tsv"), embeddings_storage_mode="none")
+    g = e2e["evaluate"][part]
+    mine = open(d / (part + ".tsv"), encoding="utf-8").read().split("\n")
+    assert len(mine) == len(g["lines"])
+    real = diff = 0
+    for a, b in zip(mine, g["lines"]):
+        if not b:
+            assert a == b
+            continue
+        fa, fb_ = a.split(" "), b.split(" ")
+        assert fa[:2] == fb_[:2], (a, b)                 # token text, gold tag
+        if fb_[1] == "S-X":
+            assert fa[2:] == fb_[2:], (a, b)             # context: S-X 1 (integer, as the reference prints it)
+        else:
+            real += 1
+            diff += fa[2] != fb_[2]
+            if fa[2] == fb_[2]:
+                assert abs(float(fa[3]) - float(fb_[3])) < 5e-2, (a, b)
+    print("G12 evaluate", part, "real tokens", real, "tag flips", diff, "loss", loss, g["eval_loss"])
+    assert diff <= max(1, real // 50), (diff, real)
+    assert abs(loss - g["eval_loss"]) < 3e-2 * abs(g["eval_loss"]), (loss, g["eval_loss"])
+    if diff == 0:
+        assert res.log_line == g["log_line"] and res.detailed_results == g["detailed_results"]
+        assert res.main_score == g["main_score"] and res.macro_score == g["macro_score"]
+
+
+# ------------------------------------------------------------------ checkpoint / resume (SURVEY.md §5)
+def test_checkpoint_resume_equals_uninterrupted(g12, tmp_path):
+    """4 epochs straight == 2 epochs + checkpoint.pt + a NEW process-like restart from Model.load_checkpoint for 2 more
+    (nn.py:69-139, finetune_trainer.py:1261-1277, trainer.py:582): Adam moments, step count (LR decay position), batch order and
+    dropout streams all continue.  Atomics in the embedding backward make runs differ by rounding only."""
+    import copy
+    from flair.models import FastSequenceTagger
+    from flair.trainers import ModelFinetuner
+    d, e2e, arrs = g12
+
+    def run(epochs_then=None):
+        cp, student = _student_from(d, arrs, "init")
+        cfg = copy.deepcopy(cp.config["train"])
+        cfg.update(max_epochs=4, checkpoint=True, shuffle=True)
+        student.use_word_dropout = student.engine.word_dropout = 0.1     # dropout streams are part of what must continue
+        student.engine.seed_dropout(123)
+        base = tmp_path / ("straight" if epochs_then is None else "resumed")
+        tr = ModelFinetuner(student, None, cp.corpus, config=cp.config, **cp.config["ModelFinetuner"])
+        if epochs_then is None:
+            out = tr.train(base, **cfg)
+            return out["train_loss_history"], torch.load(base / "final-model.pt", weights_only=False)
+        # interrupted after `epochs_then` epochs: the loop is stopped by max_epochs_without_improvement-free means -- a hook
+        cfg1 = dict(cfg)
+        hist = []
+        orig_save = student.save_checkpoint
+
+        class _Stop(Exception):
+            pass
+
+        def save_and_stop(path, *a, **k):
+            orig_save(path, *a, **k)
+            if a[2] == epochs_then:
+                raise KeyboardInterrupt      # the trainer's own early-exit path (finetune_trainer.py:1314-1324)
+
+        student.save_checkpoint = save_and_stop
+        out1 = tr.train(base, **cfg1)
+        hist += out1["train_loss_history"]
+        ck = FastSequenceTagger.load_checkpoint(base / "checkpoint.pt")
+        assert ck["epoch"] == epochs_then and ck["optimizer_state_dict"]["t"] > 0
+        tr2 = ModelFinetuner.load_from_checkpoint(ck, cp.corpus, config=cp.config, **cp.config["ModelFinetuner"])
+        out2 = tr2.train(base, **cfg)
+        hist += out2["train_loss_history"]
+        return hist, torch.load(base / "final-model.pt", weights_only=False)
+
+    h_a, p_a = run(None)
+    h_b, p_b = run(2)
+    print("resume: losses", h_a, h_b)
+    assert len(h_a) == len(h_b) == 4
+    assert max(abs(a - b) / abs(a) for a, b in zip(h_a, h_b)) < 2e-3, (h_a, h_b)
+    for k in ("transitions", "linear.weight"):
+        m = p_a[k] > -1e11
+        assert float((p_a[k][m] - p_b[k][m]).abs().max()) < 2e-3 * float(p_a[k][m].abs().max()), k
+    for k, v in p_a["encoder_state_dict"].items():
+        rel = float((v - p_b["encoder_state_dict"][k]).norm() / (v.norm() + 1e-12))
+        assert rel < 1e-3, (k, rel)

@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module")
 def st():
-    from kbner import selftest
+    import selftest
     return selftest
 
 
@@ -88,7 +88,7 @@ def test_layernorm(st, M, H):
     assert r["dgamma"] < 2e-3 and r["dbeta"] < 2e-3 and r["dbias"] < 2e-2, r
 
 
-@pytest.mark.parametrize("B,n", [(3, 7), (32, 64), (256, 32), (32, 16), (8, 512), (1, 1)])
+@pytest.mark.parametrize("B,n", [(3, 7), (32, 64), (256, 32), (32, 16), (8, 512), (32, 512), (1, 1)])   # incl. the four (B, n) points of BASELINE cfg 5
 def test_crf_vs_oracle(st, B, n):
     r = st.check_crf(B, n)
     assert r["tags_equal"] and r["popped_ok"], r       # Viterbi: bit-exact tag indices
@@ -185,12 +185,60 @@ def test_encoder_vs_hf_golden(golden_dir):
     assert err < 2e-2, err
 
 
+def test_encoder_d64_three_layers_vs_hf_golden(golden_dir):
+    """3-layer, head_dim-64 encoder (the only head size the HIP attention kernels implement) vs transformers XLMRobertaModel
+    fp32 (tests/golden/encoder_d64.npz, ragged batch, ids/mask padded with 0 like the reference): EVERY layer's output.
+    Stated tolerance: bf16 activations/weights => relative L2 <= 2e-2 on unmasked positions at every layer."""
+    from kbner import batch as kb
+    from kbner import engine
+    g = np.load(os.path.join(golden_dir, "encoder_d64.npz"))
+    V, H, L, A, F_, P = (int(x) for x in g["cfg"])
+    cfg = engine.EncoderConfig(vocab_size=V, hidden_size=H, num_hidden_layers=L, num_attention_heads=A, intermediate_size=F_,
+                               max_position_embeddings=max(P, 66))
+    tg = engine.Tagger(cfg, 29, 27, 28)
+    sd = {k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w/")}
+    pe = torch.zeros(cfg.max_position_embeddings, H)
+    pe[:P] = sd["embeddings.position_embeddings.weight"]
+    sd["embeddings.position_embeddings.weight"] = pe
+    tg.load_hf_state_dict(sd)
+    ids, am = g["ids"], g["mask"]
+    B, S0 = ids.shape
+    fi = np.tile(np.arange(S0)[None], (B, 1))
+    b = kb.assemble(ids, am, fi, np.zeros((B, S0), np.int64), np.full(B, S0), None)
+    bd = kb.to_device(b)
+    tg.encoder_forward(bd["ids"], bd["pos_ids"], bd["maskbias"], b["B"], b["S"])
+    torch.cuda.synchronize()
+    ac = tg.acts(b["B"], b["S"])
+    valid = am.astype(bool)
+    errs = []
+    for l in range(L + 1):
+        out = ac.x[l][:B * b["S"]].view(B, b["S"], H)[:, :S0].float().cpu().numpy()
+        ref = g["hs%d" % l]
+        errs.append(float(np.linalg.norm(out[valid] - ref[valid]) / np.linalg.norm(ref[valid])))
+    print("encoder_d64 per-layer rel L2:", errs)
+    assert max(errs) < 2e-2, errs
+
+
 def test_full_step_vs_oracle(st):
+    """thresholds = 3x what the round-1 driver run observed (GPUTEST_r01.json smoke: loss 2.3e-4, emissions 5.6e-3, worst
+    gradient 0.0121 / cosine 0.99993, head 4.5e-3, transitions 5.1e-4)"""
     r = st.check_step()
-    assert r["loss_rel"] < 3e-2, r
-    assert r["emissions_rel"] < 3e-2, r
-    assert r["grad_min_cos"] > 0.98 and r["grad_worst_rel"] < 0.15, r
-    assert r["grad_linear.weight"] < 5e-2 and r["grad_transitions"] < 5e-2, r
+    print("check_step:", {k: v for k, v in r.items() if k != "grad_table_top"})
+    assert r["loss_rel"] < 7e-4, r
+    assert r["emissions_rel"] < 1.7e-2, r
+    assert r["grad_min_cos"] > 0.9998 and r["grad_worst_rel"] < 0.037, r
+    assert r["grad_linear.weight"] < 1.4e-2 and r["grad_transitions"] < 1.6e-3, r
+    assert r["viterbi_equal"], r
+
+
+def test_base_config_step_vs_oracle(st):
+    """BASELINE configs[0] shape: xlm-roberta-base dims (L12 / H768 / A12 / F3072) at S = 512, one micro-batch of 2 sentences,
+    fwd + bwd against the oracle's fp32 autograd (small vocabulary: the embedding table is not what this pins)"""
+    r = st.check_step(H=768, A=12, F_=3072, L=12, S=512, V=2048, std=0.02)
+    print("base-config check_step:", {k: v for k, v in r.items() if k != "grad_table_top"}, r["grad_table_top"][:3])
+    assert r["loss_rel"] < 2e-3, r
+    assert r["emissions_rel"] < 2e-2, r
+    assert r["grad_min_cos"] > 0.99 and r["grad_worst_rel"] < 0.15, r
     assert r["viterbi_equal"], r
 
 
@@ -274,11 +322,13 @@ def test_optimizer_steps_vs_oracle_trainer(st):
     """three whole optimiser steps (2 accumulated micro-batches, clip 5.0, HF AdamW with the transitions group at lr*lr_rate,
     linear decay) on the HIP engine vs the oracle trainer: loss trajectory, clip norms, direction of every parameter update"""
     r = st.check_train_steps(steps=3, accum=2)
-    assert r["loss_rel_max"] < 5e-2, r
-    assert r["norm_rel_max"] < 1e-1, r
+    print("check_train_steps:", {k: v for k, v in r.items() if not k.startswith("dcos_")})
+    # 3x the round-1 driver observation (GPUTEST_r01.json: loss 4.7e-4, clip norm 1.7e-4, update cosine 0.9995, transitions 7e-4 of the move)
+    assert r["loss_rel_max"] < 1.5e-3, r
+    assert r["norm_rel_max"] < 5.1e-4, r
     assert r["loss_decreased"], r
-    assert r["delta_cos_min"] > 0.85, r
-    assert r["transitions_maxabs"] < 0.25 * r["transitions_moved"], r
+    assert r["delta_cos_min"] > 0.9985, r
+    assert r["transitions_maxabs"] < 2.1e-3 * r["transitions_moved"], r
 
 
 @pytest.mark.parametrize("layout,M,N,K,splits,drop_p", [(0, 512, 256, 1024, 4, 0.0), (1, 256, 512, 768, 3, 0.0), (0, 256, 256, 256, 2, 0.1),

@@ -1,0 +1,175 @@
+"""CPU: the mirror satisfies the API surface the reference's entry script exercises (north_star: "train.py drops in unchanged").
+
+tests/golden/train_surface.json is produced by oracle/gen_train_surface.py from the `ast` of /root/reference/train.py and the
+keyword sets of /root/reference/config/*.yaml: every `from flair... import`, every attribute train.py touches on the student /
+trainer / corpus / config objects, every keyword it passes.  This test walks that fixture against kb-ner_amd/flair statically
+(signatures + class sources; constructing a tagger needs the GPU -- tests/test_gpu_flair_e2e.py::test_train_surface_live does
+the same walk on live objects)."""
+import ast
+import importlib
+import inspect
+import json
+import os
+import textwrap
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SURFACE = json.load(open(os.path.join(HERE, "golden", "train_surface.json")))
+
+# Names train.py mentions that belong to paths SURVEY.md §8 marks out of scope; each with the reason.  Anything NOT listed here
+# must exist.
+OUT_OF_SCOPE = {
+    ("datasets_module", "UniversalDependenciesCorpus"): "dependency parsing branch (student.tag_type == 'dependency'), SURVEY §2.1",
+    ("embedding", "ee"): "ELMo needs external weight files (SURVEY §8f-1: 'can stay stubbed'); guarded by `'elmo' in embedding.name`",
+    ("embedding", "is_hit_elmo"): "same ELMo-only branch (train.py:228)",
+}
+
+
+def _class_attrs(cls):
+    """names assigned as `self.x = ...` anywhere in the class hierarchy + class attributes / methods / properties"""
+    names = set()
+    for c in cls.__mro__:
+        if c is object:
+            continue
+        names.update(vars(c).keys())
+        try:
+            tree = ast.parse(textwrap.dedent(inspect.getsource(c)))
+        except (OSError, TypeError):
+            continue
+        for node in ast.walk(tree):
+            if isinstance(node, ast.Attribute) and isinstance(node.ctx, ast.Store) and isinstance(node.value, ast.Name) \
+                    and node.value.id == "self":
+                names.add(node.attr)
+    return names
+
+
+def _explicit_params(fn):
+    sig = inspect.signature(fn)
+    return {n for n, p in sig.parameters.items() if p.kind in (p.POSITIONAL_OR_KEYWORD, p.KEYWORD_ONLY)}
+
+
+def _roles():
+    import flair
+    import flair.datasets
+    import flair.embeddings
+    from flair.config_parser import ConfigParser
+    from flair.custom_data_loader import ColumnDataLoader
+    from flair.data import Dictionary
+    from flair.embeddings import StackedEmbeddings, TransformerWordEmbeddings
+    from flair.list_data import ListCorpus
+    from flair.models import FastSequenceTagger
+    from flair.trainers import ModelFinetuner
+    from flair.training_utils import Result
+    return {"tagger": FastSequenceTagger, "trainer": ModelFinetuner, "corpus": ListCorpus, "config_parser": ConfigParser,
+            "embedding": TransformerWordEmbeddings, "stacked_embeddings": StackedEmbeddings, "loader": ColumnDataLoader,
+            "dictionary": Dictionary, "result": Result, "flair_module": flair, "datasets_module": flair.datasets,
+            "embeddings_module": flair.embeddings}
+
+
+def test_every_flair_import_of_train_py_resolves():
+    for imp in SURFACE["imports"]:
+        mod = importlib.import_module(imp["module"])
+        if imp["name"] is not None:
+            assert hasattr(mod, imp["name"]), "train.py:%d  from %s import %s" % (imp["line"], imp["module"], imp["name"])
+
+
+def test_every_attribute_train_py_reads_exists():
+    roles = _roles()
+    missing = []
+    for role, attrs in SURFACE["attributes"].items():
+        if role == "params":
+            from flair.utils.from_params import Params
+            assert hasattr(Params, "__getitem__") and hasattr(Params, "from_file")
+            continue
+        target = roles[role]
+        have = set(dir(target)) if inspect.ismodule(target) else _class_attrs(target)
+        for name, uses in attrs.items():
+            if not uses["load"]:
+                continue  # train.py only assigns it (student.is_mst = True, embedding.v2_doc = True ...)
+            if name.startswith("__"):
+                assert hasattr(target, name), (role, name)
+                continue
+            if name not in have and (role, name) not in OUT_OF_SCOPE:
+                missing.append("%s.%s (train.py:%s)" % (role, name, uses["load"][:3]))
+    assert not missing, missing
+
+
+def _callee(call, roles):
+    owner, func = call["owner"], call["func"]
+    if owner is None:
+        from flair.trainers import ModelFinetuner, ReinforcementTrainer
+        return {"ColumnDataLoader": [roles["loader"].__init__], "ConfigParser": [roles["config_parser"].__init__],
+                "trainer_func": [ModelFinetuner.__init__, ReinforcementTrainer.__init__], "ListCorpus": [roles["corpus"].__init__]
+                }.get(func)
+    target = roles.get(owner)
+    if target is None or (owner, func) in OUT_OF_SCOPE:
+        return None
+    fn = getattr(target, func, None)
+    assert fn is not None, "train.py:%d calls %s.%s" % (call["line"], owner, func)
+    if inspect.isclass(fn):
+        fn = fn.__init__
+    return [fn]
+
+
+def test_every_keyword_train_py_passes_is_an_explicit_parameter():
+    """**kwargs catch-alls do not count: a keyword only satisfies the surface if the callee names it"""
+    roles = _roles()
+    bad = []
+    for call in SURFACE["calls"]:
+        fns = _callee(call, roles)
+        if not fns:
+            continue
+        for fn in fns:
+            if fn in (torch_module_eval(), ):
+                continue
+            try:
+                params = _explicit_params(fn)
+            except (TypeError, ValueError):
+                continue
+            for kw in call["keywords"]:
+                if kw == "professors" and fn.__qualname__.startswith("ReinforcementTrainer"):
+                    continue   # train.py:127 is the distill_mode branch; the reference's ReinforcementTrainer has no such parameter either
+                if kw not in params:
+                    bad.append("train.py:%d %s(%s=...) not a parameter of %s" % (call["line"], call["func"], kw, fn.__qualname__))
+    assert not bad, bad
+
+
+def torch_module_eval():
+    import torch
+    return torch.nn.Module.eval
+
+
+def test_corpus_list_keys_and_train_config_base_path():
+    roles = _roles()
+    p = _explicit_params(roles["corpus"].__init__)
+    assert {"train", "dev", "test"} <= p           # ListCorpus(**{'train':[],'dev':[],'test':[]}), train.py:366-370
+    assert "base_path" in _explicit_params(roles["trainer"].train)   # train_config['base_path'] = ..., train.py:135,412
+
+
+@pytest.mark.parametrize("section", sorted(SURFACE["yaml_keywords"]))
+def test_yaml_keyword_sets_are_explicit_parameters(section):
+    """every key the shipped config/*.yaml files put in train: / <Trainer>: / model: / embeddings: is a named parameter"""
+    import flair.embeddings as E
+    from flair.models import FastSequenceTagger
+    from flair.trainers import ModelFinetuner, ReinforcementTrainer
+    keys = set(SURFACE["yaml_keywords"][section])
+    kind, _, name = section.partition(":")
+    if kind == "train":
+        params = _explicit_params(ModelFinetuner.train) | _explicit_params(ReinforcementTrainer.train)
+    elif kind == "trainer":
+        params = _explicit_params({"ModelFinetuner": ModelFinetuner, "ReinforcementTrainer": ReinforcementTrainer}[name].__init__)
+    elif kind == "model":
+        assert name == "FastSequenceTagger"
+        params = _explicit_params(FastSequenceTagger.__init__)
+    else:
+        cls = getattr(E, name, None)
+        if name in ("ELMoEmbeddings", "FastWordEmbeddings"):
+            # need external weight files that do not exist offline; the classes exist and say so when constructed
+            assert cls is not None
+            return
+        if cls is None and name == "FlairEmbeddings":
+            pytest.xfail("FlairEmbeddings (config 5 char-LM stack, SURVEY §8f-1) is being built this round")
+        assert cls is not None, name
+        params = _explicit_params(cls.__init__)
+    assert keys <= params, sorted(keys - params)

@@ -14,11 +14,14 @@ WORDS = ("the quick brown fox jumps over lazy dog berlin paris london zalando re
 def build_tokenizer_dir(path, vocab_size=300, seed=0):
     """Unigram + Metaspace fast tokenizer with <s>=0 <pad>=1 </s>=2 <unk>=3 (XLM-R's special-token ids), saved so that
     AutoTokenizer.from_pretrained(path) loads it."""
-    from tokenizers import Tokenizer, models, pre_tokenizers, trainers, decoders
+    from tokenizers import Tokenizer, models, normalizers, pre_tokenizers, trainers, decoders
     from transformers import PreTrainedTokenizerFast
     rng = np.random.default_rng(seed)
     corpus = [" ".join(rng.choice(WORDS, size=12)) for _ in range(400)]
     tok = Tokenizer(models.Unigram())
+    # like XLM-R's sentencepiece normaliser (nmt_nfkc), which deletes soft hyphens / zero-width characters: a word token made
+    # only of such characters receives NO sub-token (the 0-length case of flair/embeddings.py:3306-3308)
+    tok.normalizer = normalizers.Replace("\u00ad", "")
     tok.pre_tokenizer = pre_tokenizers.Metaspace()
     tok.decoder = decoders.Metaspace()
     tr = trainers.UnigramTrainer(vocab_size=vocab_size, special_tokens=["<s>", "<pad>", "</s>", "<unk>"], unk_token="<unk>")
@@ -30,11 +33,11 @@ def build_tokenizer_dir(path, vocab_size=300, seed=0):
     return fast
 
 
-def build_model_dir(path, hidden=128, layers=2, heads=2, inter=256, seed=0):
+def build_model_dir(path, hidden=128, layers=2, heads=2, inter=256, seed=0, tokenizer="unigram"):
     """tokenizer + config.json + model.safetensors (random init, HF names) for a tiny XLM-R-shaped encoder (head_dim 64)"""
     import torch
     from safetensors.torch import save_file
-    tok = build_tokenizer_dir(path, seed=seed)
+    tok = build_tokenizer_dir(path, seed=seed) if tokenizer == "unigram" else build_wordpiece_tokenizer_dir(path, seed=seed)
     V = len(tok)
     cfg = dict(model_type="xlm-roberta", architectures=["XLMRobertaModel"], vocab_size=V, hidden_size=hidden,
                num_hidden_layers=layers, num_attention_heads=heads, intermediate_size=inter, max_position_embeddings=514,
@@ -102,3 +105,52 @@ def write_conll_corpus(folder, n_train=24, n_dev=8, n_test=8, seed=0):
                 f.write("# id %s-%d\tdomain=en\n" % (name, i))
                 f.write("\n".join(sentence()) + "\n\n")
     return folder
+
+
+def e2e_config(d, word_dropout=0.1, max_epochs=6, shuffle=None, n_train=32, n_dev=8, n_test=8, accum=2, mini_batch_size=4,
+               save_finetuned_embedding=True):
+    """The KB-NER-shaped YAML (as a dict) of the tiny end-to-end run under directory `d`: builds the model dir + corpus files
+    and returns the config.  Shared by tests/test_gpu_flair_e2e.py and oracle/gen_golden_e2e.py (G12), so the reference and the
+    mirror are configured by the same keys."""
+    d = str(d)
+    build_model_dir(os.path.join(d, "xlmr-tiny"))
+    write_conll_corpus(os.path.join(d, "data"), n_train=n_train, n_dev=n_dev, n_test=n_test)
+    cfg = {
+        "ModelFinetuner": {"distill_mode": False, "sentence_level_batch": True},
+        "embeddings": {"TransformerWordEmbeddings-0": {"fine_tune": True, "layers": "-1", "model": os.path.join(d, "xlmr-tiny"),
+                                                        "pooling_operation": "first"}},
+        "model": {"FastSequenceTagger": {"crf_attention": False, "dropout": 0.0, "hidden_size": 256, "locked_dropout": 0.0,
+                                         "remove_x": True, "sentence_loss": True, "use_cnn": False, "use_crf": True,
+                                         "use_rnn": False, "word_dropout": word_dropout}},
+        "model_name": "tiny_run", "target_dir": os.path.join(d, "out"), "targets": "ner", "trainer": "ModelFinetuner",
+        "ner": {"Corpus": "ColumnCorpus-TINY", "tag_dictionary": os.path.join(d, "tags.pkl"),
+                "ColumnCorpus-TINY": {"column_format": {0: "text", 1: "pos", 2: "upos", 3: "ner"}, "comment_symbol": "# id",
+                                      "data_folder": os.path.join(d, "data"), "tag_to_bioes": "ner"}},
+        "train": {"embeddings_storage_mode": "none", "fine_tune_mode": True, "gradient_accumulation_steps": accum,
+                  "learning_rate": 2.0e-3, "lr_rate": 50, "max_epochs": max_epochs, "mini_batch_size": mini_batch_size,
+                  "monitor_test": False, "save_finetuned_embedding": save_finetuned_embedding, "select_model_by_macro": True,
+                  "train_with_dev": False, "true_reshuffle": False, "use_warmup": False},
+    }
+    if shuffle is not None:
+        cfg["train"]["shuffle"] = bool(shuffle)
+    return cfg
+
+
+def build_wordpiece_tokenizer_dir(path, seed=0):
+    """BERT-style tokenizer ([CLS]=0 [PAD]=1 [SEP]=2 [UNK]=3, BertNormalizer with clean_text: control characters are
+    DELETED, so a word token made only of them receives no sub-token at all -- flair/embeddings.py:3306-3308's case)"""
+    from tokenizers import Tokenizer, models, normalizers, pre_tokenizers, decoders
+    from transformers import PreTrainedTokenizerFast
+    # hand-built vocabulary (WordPieceTrainer's piece order is not reproducible run to run): specials, characters, their
+    # continuation forms, then the corpus words
+    chars = "abcdefghijklmnopqrstuvwxyz0123456789.,!()-"
+    vocab = ["[CLS]", "[PAD]", "[SEP]", "[UNK]"] + list(chars) + ["##" + c for c in chars] + sorted(set(w.lower() for w in WORDS))
+    tok = Tokenizer(models.WordPiece(vocab={w: i for i, w in enumerate(vocab)}, unk_token="[UNK]"))
+    tok.normalizer = normalizers.BertNormalizer(clean_text=True, handle_chinese_chars=False, strip_accents=False, lowercase=True)
+    tok.pre_tokenizer = pre_tokenizers.BertPreTokenizer()
+    tok.decoder = decoders.WordPiece()
+    os.makedirs(path, exist_ok=True)
+    fast = PreTrainedTokenizerFast(tokenizer_object=tok, cls_token="[CLS]", sep_token="[SEP]", pad_token="[PAD]", unk_token="[UNK]",
+                                   model_max_length=512)
+    fast.save_pretrained(path)
+    return fast

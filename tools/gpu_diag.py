@@ -24,7 +24,8 @@ def run(name, fn):
 
 
 def main():
-    from kbner import selftest as st
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
+    import selftest as st
     from kbner.lib import EPI_ADD, EPI_ATOMIC32, EPI_BIAS, EPI_DGELU, EPI_GELU, GEMM_NN, GEMM_NT, GEMM_TN
     print(torch.cuda.get_device_name(0), flush=True)
 
