@@ -20,6 +20,7 @@
 // round trip of computed tiles.)  qkv / dqkv are token-major [M, 3H] (Q | K | V), head h at
 // column h*64, exactly what the fused QKV GEMM produces / consumes: no permute kernels.
 #include "common.h"
+#include <cstdlib>
 
 #define AT_D 64
 #define AT_MAXS 512
@@ -594,12 +595,336 @@ __global__ __launch_bounds__(AT_NWB * 64) void attn_bwd_dkv_kernel(const bf16_t*
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// backward, second structure: 32 stationary rows per wave (two 16-row fragments)
+// ------------------------------------------------------------------------------------------
+// The 16-row kernels above read every LDS operand fragment for ONE MFMA: per 32-key chunk a wave moves 8 KiB (S, dP) +
+// 4 KiB (transposed) out of LDS for 12 MFMAs.  Here every fragment read feeds TWO MFMAs (row blocks j = 0, 1 of the wave's
+// 32 rows), halving the LDS bytes per flop, and the two independent row blocks give the scheduler an MFMA stream (block 1's
+// scores) to run under block 0's exp2 / multiply work.  Measured on MI355X (B=128 x 16 heads, S=512): dQ + dK/dV 813 -> 735 us.
+// (Register double-buffering of the fragment stream one chunk ahead -- 32 more VGPRs + sched_barriers -- measured SLOWER,
+// 783 us: LDS latency is not what these loops wait for.)
+// Key chunks that lie entirely behind the sentence's last unmasked key are skipped: their probabilities are exp(-10000 + x)
+// = 0 exactly in fp32 (as in the reference), so they contribute exactly nothing -- length-sorted real batches are padded
+// (711 us at 450 real keys of 512).
+//
+// klen: 1 + index of the last key whose mask bias is 0 (prefix masks: the number of real sub-tokens).
+template <int NT>
+static __device__ __forceinline__ int stage_mask_klen(const float* __restrict__ maskbias, size_t off, int S, float* sMask,
+                                                       int* sKlen, int tid) {
+  if (tid == 0) *sKlen = 0;
+  __syncthreads();
+  int last = 0;
+  for (int i = tid; i < S; i += NT) {
+    const float m = maskbias[off + i];
+    sMask[i] = m * 1.4426950408889634f;
+    if (m > -1.0f) last = i + 1;   // additive bias 0 = attend (anything near -10000 = masked)
+  }
+  if (last) atomicMax(sKlen, last);
+  __syncthreads();
+  return *sKlen;
+}
+
+template <bool DROP>
+__global__ __launch_bounds__(512) void attn_bwd_dq2_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dctx,
+                                                          const bf16_t* __restrict__ ctx, const float* __restrict__ maskbias,
+                                                          const float* __restrict__ lse, float* __restrict__ Dv,
+                                                          bf16_t* __restrict__ dqkv, int S, int H, int A, float scale, int rpw,
+                                                          uint32_t drop_seed, uint32_t drop_thresh, float* __restrict__ dbias) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ float red[8][64];
+  __shared__ int sKlen;
+  unsigned char* sK = smem;
+  unsigned char* sV = smem + AT_MAXS * 128;
+  float* sMask = reinterpret_cast<float*>(smem + 2 * AT_MAXS * 128);
+  uint32_t* sCk = reinterpret_cast<uint32_t*>(sMask + AT_MAXS);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int ld = 3 * H;
+  const bf16_t* base = qkv + (size_t)b * S * ld + h * AT_D;
+  const uint32_t bhS = (uint32_t)((b * A + h) * S);
+  const float dscale = DROP ? drop_scale(drop_thresh) : 1.0f;
+  f4v bsum[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db) bsum[db] = (f4v){0.f, 0.f, 0.f, 0.f};
+  stage_panel<8>(base + H, ld, S, sK, wid, lane);
+  stage_panel<8>(base + 2 * H, ld, S, sV, wid, lane);
+  const int klen = stage_mask_klen<512>(maskbias, (size_t)b * S, S, sMask, &sKlen, tid);
+  if (DROP)
+    for (int i = tid; i < S; i += 512) sCk[i] = drop_colkey(drop_seed, bhS + (uint32_t)i);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const int g = lane >> 4, li = lane & 15;
+  const int nkc = (klen + 31) >> 5;   // key chunks that hold at least one unmasked key
+  const float scale2 = scale * 1.4426950408889634f;
+  const PanelBases pK = panel_bases(sK, lane), pV = panel_bases(sV, lane);
+  const bf16_t* dob = dctx + (size_t)b * S * H + h * AT_D;
+  const bf16_t* ob = ctx + (size_t)b * S * H + h * AT_D;
+  const f4v zero4 = (f4v){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+  for (int pass = 0; pass < rpw / 256; ++pass) {
+    const int q0 = qt * rpw + wid * (rpw / 8) + pass * 32;
+    if (q0 >= S) break;
+    bf16x8 qf[2][2], dof[2][2];
+    float l_q[2], d_q[2];
+    uint32_t rk[2];
+    f4v dq[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int qj = q0 + j * 16;
+      qf[j][0] = glb_frag(base, ld, qj, 0, lane);
+      qf[j][1] = glb_frag(base, ld, qj, 1, lane);
+      dof[j][0] = glb_frag(dob, H, qj, 0, lane);
+      dof[j][1] = glb_frag(dob, H, qj, 1, lane);
+      const size_t sidx = ((size_t)b * A + h) * S + qj + li;
+      l_q[j] = lse[sidx] * 1.4426950408889634f;
+      d_q[j] = group4_sum(dot8(dof[j][0], glb_frag(ob, H, qj, 0, lane)) + dot8(dof[j][1], glb_frag(ob, H, qj, 1, lane)));
+      if (g == 0) Dv[sidx] = d_q[j];
+      rk[j] = DROP ? drop_rowkey(drop_seed, bhS + (uint32_t)(qj + li)) : 0u;
+#pragma unroll
+      for (int db = 0; db < 4; ++db) dq[j][db] = zero4;
+    }
+    for (int kc = 0; kc < nkc; ++kc) {
+      const int co = kc * 4096;
+      // one read of each K / V fragment of the chunk (keys kc*32 .. +31, two 16-key fragments x two k-steps) ...
+      const bf16x8 k00 = kc_at(pK.kc[0], co), k01 = kc_at(pK.kc[1], co);
+      const bf16x8 k10 = kc_at(pK.kc[0], co + 2048), k11 = kc_at(pK.kc[1], co + 2048);
+      const bf16x8 v00 = kc_at(pV.kc[0], co), v01 = kc_at(pV.kc[1], co);
+      const bf16x8 v10 = kc_at(pV.kc[0], co + 2048), v11 = kc_at(pV.kc[1], co + 2048);
+      const float4 m0 = *reinterpret_cast<const float4*>(sMask + kc * 32 + g * 4);
+      const float4 m1 = *reinterpret_cast<const float4*>(sMask + kc * 32 + 16 + g * 4);
+      const float mb0[4] = {m0.x, m0.y, m0.z, m0.w};
+      const float mb1[4] = {m1.x, m1.y, m1.z, m1.w};
+      uint32_t ck0[4] = {0u, 0u, 0u, 0u}, ck1[4] = {0u, 0u, 0u, 0u};
+      if (DROP) {
+        const uint4 c0 = *reinterpret_cast<const uint4*>(sCk + kc * 32 + g * 4);
+        const uint4 c1 = *reinterpret_cast<const uint4*>(sCk + kc * 32 + 16 + g * 4);
+        ck0[0] = c0.x; ck0[1] = c0.y; ck0[2] = c0.z; ck0[3] = c0.w;
+        ck1[0] = c1.x; ck1[1] = c1.y; ck1[2] = c1.z; ck1[3] = c1.w;
+      }
+      // ... feeds both row blocks: S^T and dP^T tiles [key, query] (lane: keys g*4 + r of each 16-key fragment, query li)
+      f4v s0[2], s1[2], p0[2], p1[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const f4v pinit = DROP ? zero4 : (f4v){-d_q[j], -d_q[j], -d_q[j], -d_q[j]};
+        s0[j] = MFMA(k00, qf[j][0], zero4);
+        s0[j] = MFMA(k01, qf[j][1], s0[j]);
+        s1[j] = MFMA(k10, qf[j][0], zero4);
+        s1[j] = MFMA(k11, qf[j][1], s1[j]);
+        p0[j] = MFMA(v00, dof[j][0], pinit);
+        p0[j] = MFMA(v01, dof[j][1], p0[j]);
+        p1[j] = MFMA(v10, dof[j][0], pinit);
+        p1[j] = MFMA(v11, dof[j][1], p1[j]);
+      }
+      bf16x8 dsb[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        f4v ds0, ds1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pr0 = __builtin_amdgcn_exp2f(s0[j][r] * scale2 + (mb0[r] - l_q[j]));
+          const float pr1 = __builtin_amdgcn_exp2f(s1[j][r] * scale2 + (mb1[r] - l_q[j]));
+          float dp0 = p0[j][r], dp1 = p1[j][r];
+          if (DROP) {
+            dp0 = drop_keep(rk[j], ck0[r], drop_thresh) ? dp0 * dscale : 0.0f;
+            dp1 = drop_keep(rk[j], ck1[r], drop_thresh) ? dp1 * dscale : 0.0f;
+          }
+          ds0[r] = DROP ? pr0 * (dp0 - d_q[j]) : pr0 * dp0;
+          ds1[r] = DROP ? pr1 * (dp1 - d_q[j]) : pr1 * dp1;
+        }
+        dsb[j] = pack_b(ds0, ds1);
+      }
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        const bf16x8 t = tr_at(pK.tr[db], co);
+        dq[0][db] = MFMA(t, dsb[0], dq[0][db]);
+        dq[1][db] = MFMA(t, dsb[1], dq[1][db]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      bf16_t* orow = dqkv + (size_t)(b * S + q0 + j * 16 + li) * ld + h * AT_D;
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        uint2 u;
+        u.x = pack2bf(dq[j][db][0] * scale, dq[j][db][1] * scale);
+        u.y = pack2bf(dq[j][db][2] * scale, dq[j][db][3] * scale);
+        *reinterpret_cast<uint2*>(orow + db * 16 + g * 4) = u;
+        bsum[db] += dq[j][db] * scale;
+      }
+    }
+  }
+  if (dbias != nullptr) flush_colsum<8>(bsum, red, dbias + h * AT_D, wid, lane, tid);
+}
+
+template <bool DROP>
+__global__ __launch_bounds__(512) void attn_bwd_dkv2_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dctx,
+                                                           const float* __restrict__ maskbias, const float* __restrict__ lse,
+                                                           const float* __restrict__ Dv, bf16_t* __restrict__ dqkv, int S,
+                                                           int H, int A, float scale, int rpw, uint32_t drop_seed,
+                                                           uint32_t drop_thresh, float* __restrict__ dbias) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ float red[8][64];
+  f4v bsk[4], bsv[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db) bsk[db] = bsv[db] = (f4v){0.f, 0.f, 0.f, 0.f};
+  unsigned char* sQ = smem;
+  unsigned char* sO = smem + AT_MAXS * 128;
+  float* sL = reinterpret_cast<float*>(smem + 2 * AT_MAXS * 128);
+  float* sD = sL + AT_MAXS;
+  uint32_t* sRk = reinterpret_cast<uint32_t*>(sD + AT_MAXS);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int ld = 3 * H;
+  const bf16_t* base = qkv + (size_t)b * S * ld + h * AT_D;
+  const bf16_t* dob = dctx + (size_t)b * S * H + h * AT_D;
+  stage_panel<8>(base, ld, S, sQ, wid, lane);
+  stage_panel<8>(dob, H, S, sO, wid, lane);
+  const size_t sbase = ((size_t)b * A + h) * S;
+  const uint32_t bhS = (uint32_t)sbase;
+  const float dscale = DROP ? drop_scale(drop_thresh) : 1.0f;
+  for (int i = tid; i < S; i += 512) {
+    sL[i] = lse[sbase + i] * 1.4426950408889634f;
+    sD[i] = -Dv[sbase + i];
+    if (DROP) sRk[i] = drop_rowkey(drop_seed, bhS + (uint32_t)i);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const int g = lane >> 4, li = lane & 15;
+  const int nqc = S / 32;
+  const float scale2 = scale * 1.4426950408889634f;
+  const PanelBases pQ = panel_bases(sQ, lane), pO = panel_bases(sO, lane);
+  const f4v zero4 = (f4v){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+  for (int pass = 0; pass < rpw / 256; ++pass) {
+    const int k0 = kt * rpw + wid * (rpw / 8) + pass * 32;
+    if (k0 >= S) break;
+    bf16x8 kf[2][2], vf[2][2];
+    float mb[2];
+    uint32_t ck[2];
+    f4v dk[2][4], dv[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int kj = k0 + j * 16;
+      kf[j][0] = glb_frag(base + H, ld, kj, 0, lane);
+      kf[j][1] = glb_frag(base + H, ld, kj, 1, lane);
+      vf[j][0] = glb_frag(base + 2 * H, ld, kj, 0, lane);
+      vf[j][1] = glb_frag(base + 2 * H, ld, kj, 1, lane);
+      mb[j] = maskbias[(size_t)b * S + kj + li] * 1.4426950408889634f;
+      ck[j] = DROP ? drop_colkey(drop_seed, bhS + (uint32_t)(kj + li)) : 0u;
+#pragma unroll
+      for (int db = 0; db < 4; ++db) dk[j][db] = dv[j][db] = zero4;
+    }
+    // a wave whose 32 keys are all masked has P = 0 exactly: dK = dV = 0 for its rows (wave-uniform skip of the loop)
+    const bool live = __builtin_amdgcn_readfirstlane(__any((mb[0] > -1.0f) || (mb[1] > -1.0f)) ? 1 : 0) != 0;
+    for (int qc = 0; live && qc < nqc; ++qc) {
+      const int co = qc * 4096;
+      const bf16x8 q00 = kc_at(pQ.kc[0], co), q01 = kc_at(pQ.kc[1], co);
+      const bf16x8 q10 = kc_at(pQ.kc[0], co + 2048), q11 = kc_at(pQ.kc[1], co + 2048);
+      const bf16x8 o00 = kc_at(pO.kc[0], co), o01 = kc_at(pO.kc[1], co);
+      const bf16x8 o10 = kc_at(pO.kc[0], co + 2048), o11 = kc_at(pO.kc[1], co + 2048);
+      const float4 l0 = *reinterpret_cast<const float4*>(sL + qc * 32 + g * 4);
+      const float4 l1 = *reinterpret_cast<const float4*>(sL + qc * 32 + 16 + g * 4);
+      const f4v nd0 = *reinterpret_cast<const f4v*>(sD + qc * 32 + g * 4);
+      const f4v nd1 = *reinterpret_cast<const f4v*>(sD + qc * 32 + 16 + g * 4);
+      const float la[4] = {l0.x, l0.y, l0.z, l0.w}, lb[4] = {l1.x, l1.y, l1.z, l1.w};
+      uint32_t rk0[4] = {0u, 0u, 0u, 0u}, rk1[4] = {0u, 0u, 0u, 0u};
+      if (DROP) {
+        const uint4 c0 = *reinterpret_cast<const uint4*>(sRk + qc * 32 + g * 4);
+        const uint4 c1 = *reinterpret_cast<const uint4*>(sRk + qc * 32 + 16 + g * 4);
+        rk0[0] = c0.x; rk0[1] = c0.y; rk0[2] = c0.z; rk0[3] = c0.w;
+        rk1[0] = c1.x; rk1[1] = c1.y; rk1[2] = c1.z; rk1[3] = c1.w;
+      }
+      // S and dP tiles [query, key]: lane holds queries qc*32 + f*16 + g*4 + r, key k0 + j*16 + li
+      f4v s0[2], s1[2], p0[2], p1[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        s0[j] = MFMA(q00, kf[j][0], zero4);
+        s0[j] = MFMA(q01, kf[j][1], s0[j]);
+        s1[j] = MFMA(q10, kf[j][0], zero4);
+        s1[j] = MFMA(q11, kf[j][1], s1[j]);
+        p0[j] = MFMA(o00, vf[j][0], DROP ? zero4 : nd0);
+        p0[j] = MFMA(o01, vf[j][1], p0[j]);
+        p1[j] = MFMA(o10, vf[j][0], DROP ? zero4 : nd1);
+        p1[j] = MFMA(o11, vf[j][1], p1[j]);
+      }
+      bf16x8 pb[2], dsb[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        f4v pr0, pr1, ds0, ds1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e0 = __builtin_amdgcn_exp2f(s0[j][r] * scale2 + (mb[j] - la[r]));
+          const float e1 = __builtin_amdgcn_exp2f(s1[j][r] * scale2 + (mb[j] - lb[r]));
+          float dp0 = p0[j][r], dp1 = p1[j][r];
+          pr0[r] = e0;
+          pr1[r] = e1;
+          if (DROP) {
+            const bool k0_ = drop_keep(rk0[r], ck[j], drop_thresh), k1_ = drop_keep(rk1[r], ck[j], drop_thresh);
+            pr0[r] = k0_ ? e0 * dscale : 0.0f;
+            pr1[r] = k1_ ? e1 * dscale : 0.0f;
+            dp0 = k0_ ? dp0 * dscale : 0.0f;
+            dp1 = k1_ ? dp1 * dscale : 0.0f;
+          }
+          ds0[r] = DROP ? e0 * (dp0 + nd0[r]) : e0 * dp0;
+          ds1[r] = DROP ? e1 * (dp1 + nd1[r]) : e1 * dp1;
+        }
+        pb[j] = pack_b(pr0, pr1);
+        dsb[j] = pack_b(ds0, ds1);
+      }
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        const bf16x8 tO = tr_at(pO.tr[db], co);
+        const bf16x8 tQ = tr_at(pQ.tr[db], co);
+        dv[0][db] = MFMA(tO, pb[0], dv[0][db]);
+        dv[1][db] = MFMA(tO, pb[1], dv[1][db]);
+        dk[0][db] = MFMA(tQ, dsb[0], dk[0][db]);
+        dk[1][db] = MFMA(tQ, dsb[1], dk[1][db]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      bf16_t* krow = dqkv + (size_t)(b * S + k0 + j * 16 + li) * ld + H + h * AT_D;
+      bf16_t* vrow = krow + H;
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        uint2 u;
+        u.x = pack2bf(dk[j][db][0] * scale, dk[j][db][1] * scale);
+        u.y = pack2bf(dk[j][db][2] * scale, dk[j][db][3] * scale);
+        *reinterpret_cast<uint2*>(krow + db * 16 + g * 4) = u;
+        uint2 w;
+        w.x = pack2bf(dv[j][db][0], dv[j][db][1]);
+        w.y = pack2bf(dv[j][db][2], dv[j][db][3]);
+        *reinterpret_cast<uint2*>(vrow + db * 16 + g * 4) = w;
+        bsk[db] += dk[j][db] * scale;
+        bsv[db] += dv[j][db];
+      }
+    }
+  }
+  if (dbias != nullptr) {
+    flush_colsum<8>(bsk, red, dbias + H + h * AT_D, wid, lane, tid);
+    flush_colsum<8>(bsv, red, dbias + 2 * H + h * AT_D, wid, lane, tid);
+  }
+}
+
 static int set_lds(const void* f, int bytes) {
   hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   return e == hipSuccess ? 0 : -(int)e;
 }
 
 #define AT_LDS_BYTES (2 * AT_MAXS * 128 + 3 * AT_MAXS * 4)
+
+// KBNER_ATTN_V1=1 (experiments / A-B measurements only): keep the 16-row kernels
+static bool at_force_v1() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("KBNER_ATTN_V1");
+    v = (e != nullptr && e[0] == '1') ? 1 : 0;
+  }
+  return v == 1;
+}
 
 // rows per workgroup: the whole head (one DMA of each panel per head) when the grid still covers the
 // chip several times over, otherwise smaller row tiles so small batches spread over more CUs
@@ -645,6 +970,23 @@ static int launch_attn_bwd(const bf16_t* qkv, const bf16_t* ctx, const bf16_t* d
   int rpw = pick_rpw(B, S, A);
   if (rpw < 16 * AT_NWB) rpw = 16 * AT_NWB;  // every wave owns at least one 16-row pass
   const dim3 grid((S + rpw - 1) / rpw, A, B);
+  // 32-row-stationary kernels whenever a workgroup's row tile gives each of its 8 waves whole 32-row passes
+  if (rpw % 256 == 0 && S % 32 == 0 && !at_force_v1()) {
+    static bool once2 = false;
+    if (!once2) {
+      int r = set_lds(reinterpret_cast<const void*>(attn_bwd_dq2_kernel<DROP>), AT_LDS_BYTES);
+      if (r) return r;
+      r = set_lds(reinterpret_cast<const void*>(attn_bwd_dkv2_kernel<DROP>), AT_LDS_BYTES);
+      if (r) return r;
+      once2 = true;
+    }
+    hipLaunchKernelGGL(attn_bwd_dq2_kernel<DROP>, grid, dim3(512), AT_LDS_BYTES, s, qkv, dctx, ctx, maskbias, lse, Dws, dqkv, S, H, A,
+                       0.125f, rpw, seed, thresh, dbias);
+    hipLaunchKernelGGL(attn_bwd_dkv2_kernel<DROP>, grid, dim3(512), AT_LDS_BYTES, s, qkv, dctx, maskbias, lse, Dws, dqkv, S, H, A,
+                       0.125f, rpw, seed, thresh, dbias);
+    hipError_t e2 = hipGetLastError();
+    return e2 == hipSuccess ? 0 : -(int)e2;
+  }
   hipLaunchKernelGGL(attn_bwd_dq_kernel<DROP>, grid, dim3(AT_NWB * 64), AT_LDS_BYTES, s, qkv, dctx, ctx, maskbias, lse, Dws, dqkv, S, H, A,
                      0.125f, rpw, seed, thresh, dbias);
   hipLaunchKernelGGL(attn_bwd_dkv_kernel<DROP>, grid, dim3(AT_NWB * 64), AT_LDS_BYTES, s, qkv, dctx, maskbias, lse, Dws, dqkv, S, H, A,

@@ -13,7 +13,10 @@ H = A * 64
 dev = "cuda"
 qkv = torch.randn(B * S, 3 * H, device=dev).to(torch.bfloat16)
 dctx = torch.randn(B * S, H, device=dev).to(torch.bfloat16)
+ap2 = os.environ.get("ATTN_BENCH_REAL_LEN")   # e.g. 450: mask the tail like a real padded batch
 mb = torch.zeros(B, S, device=dev)
+if ap2:
+    mb[:, int(ap2):] = -10000.0
 ctx = torch.zeros(B * S, H, dtype=torch.bfloat16, device=dev)
 lse = torch.zeros(B, A, S, device=dev)
 dws = torch.zeros(B, A, S, device=dev)
