@@ -601,28 +601,43 @@ __global__ __launch_bounds__(AT_NWB * 64) void attn_bwd_dkv_kernel(const bf16_t*
 // The 16-row kernels above read every LDS operand fragment for ONE MFMA: per 32-key chunk a wave moves 8 KiB (S, dP) +
 // 4 KiB (transposed) out of LDS for 12 MFMAs.  Here every fragment read feeds TWO MFMAs (row blocks j = 0, 1 of the wave's
 // 32 rows), halving the LDS bytes per flop, and the two independent row blocks give the scheduler an MFMA stream (block 1's
-// scores) to run under block 0's exp2 / multiply work.  Measured on MI355X (B=128 x 16 heads, S=512): dQ + dK/dV 813 -> 735 us.
+// scores) to run under block 0's exp2 / multiply work.  Measured on MI355X (B=128 x 16 heads, S=512): dQ + dK/dV 813 -> 735 us;
+// with the score accumulators started at -lse/scale (P = exp2(scale2 * acc): no subtract / fma per score), the mask add only in
+// chunks that hold a masked key and two chunks per loop trip (LDS address adds 30 -> 10 per chunk) 717 us -- a third fewer VALU
+// instructions bought 2.5 %: rocprofv3 --pmc (profiles/round2_attn_pmc.txt) shows neither pipe saturated (MFMA busy 33 %, VALU
+// issue 26 % per wave, LDS 22 %, 36-42 % of the wave cycles parked in s_waitcnt): at two waves per SIMD the loop is bound by
+// its own dependency chain (LDS read -> MFMA pair -> exp2 -> cvt -> MFMA), not by a throughput limit.
 // (Register double-buffering of the fragment stream one chunk ahead -- 32 more VGPRs + sched_barriers -- measured SLOWER,
-// 783 us: LDS latency is not what these loops wait for.)
+// 783 us.)
 // Key chunks that lie entirely behind the sentence's last unmasked key are skipped: their probabilities are exp(-10000 + x)
 // = 0 exactly in fp32 (as in the reference), so they contribute exactly nothing -- length-sorted real batches are padded
 // (711 us at 450 real keys of 512).
 //
 // klen: 1 + index of the last key whose mask bias is 0 (prefix masks: the number of real sub-tokens).
 template <int NT>
-static __device__ __forceinline__ int stage_mask_klen(const float* __restrict__ maskbias, size_t off, int S, float* sMask,
-                                                       int* sKlen, int tid) {
-  if (tid == 0) *sKlen = 0;
+static __device__ __forceinline__ int stage_mask_klen(const float* __restrict__ maskbias, size_t off, int S, float inv_scale,
+                                                       float* sMask, int* sKlen, int tid, int& nfree) {
+  // sMask[i] = maskbias[i] / scale: added to the RAW score sums (see the accumulator-init note in the kernels).
+  // klen = 1 + last unmasked key; nfree = leading 32-key chunks that hold no masked key at all (prefix masks: klen / 32)
+  if (tid < 2) sKlen[tid] = 0;
   __syncthreads();
-  int last = 0;
+  int last = 0, cnt = 0;
   for (int i = tid; i < S; i += NT) {
     const float m = maskbias[off + i];
-    sMask[i] = m * 1.4426950408889634f;
-    if (m > -1.0f) last = i + 1;   // additive bias 0 = attend (anything near -10000 = masked)
+    sMask[i] = m * inv_scale;
+    if (m > -1.0f) {   // additive bias 0 = attend (anything near -10000 = masked)
+      last = i + 1;
+      cnt += 1;
+    }
   }
-  if (last) atomicMax(sKlen, last);
+  if (last) {
+    atomicMax(sKlen, last);
+    atomicAdd(sKlen + 1, cnt);
+  }
   __syncthreads();
-  return *sKlen;
+  const int klen = sKlen[0];
+  nfree = (sKlen[1] == klen) ? (klen >> 5) : 0;
+  return klen;
 }
 
 template <bool DROP>
@@ -633,7 +648,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq2_kernel(const bf16_t* __restr
                                                           uint32_t drop_seed, uint32_t drop_thresh, float* __restrict__ dbias) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ float red[8][64];
-  __shared__ int sKlen;
+  __shared__ int sKlen[2];
   unsigned char* sK = smem;
   unsigned char* sV = smem + AT_MAXS * 128;
   float* sMask = reinterpret_cast<float*>(smem + 2 * AT_MAXS * 128);
@@ -650,13 +665,15 @@ __global__ __launch_bounds__(512) void attn_bwd_dq2_kernel(const bf16_t* __restr
   for (int db = 0; db < 4; ++db) bsum[db] = (f4v){0.f, 0.f, 0.f, 0.f};
   stage_panel<8>(base + H, ld, S, sK, wid, lane);
   stage_panel<8>(base + 2 * H, ld, S, sV, wid, lane);
-  const int klen = stage_mask_klen<512>(maskbias, (size_t)b * S, S, sMask, &sKlen, tid);
+  int nfree;
+  const int klen = stage_mask_klen<512>(maskbias, (size_t)b * S, S, 1.0f / scale, sMask, sKlen, tid, nfree);
   if (DROP)
     for (int i = tid; i < S; i += 512) sCk[i] = drop_colkey(drop_seed, bhS + (uint32_t)i);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   const int g = lane >> 4, li = lane & 15;
-  const int nkc = (klen + 31) >> 5;   // key chunks that hold at least one unmasked key
+  const int nkc = ((klen + 63) >> 6) << 1;   // key chunks holding an unmasked key, rounded up to the loop's unroll of 2
+                                             // (a fully masked extra chunk has P = 0: it adds exactly nothing)
   const float scale2 = scale * 1.4426950408889634f;
   const PanelBases pK = panel_bases(sK, lane), pV = panel_bases(sV, lane);
   const bf16_t* dob = dctx + (size_t)b * S * H + h * AT_D;
@@ -678,68 +695,89 @@ __global__ __launch_bounds__(512) void attn_bwd_dq2_kernel(const bf16_t* __restr
       dof[j][0] = glb_frag(dob, H, qj, 0, lane);
       dof[j][1] = glb_frag(dob, H, qj, 1, lane);
       const size_t sidx = ((size_t)b * A + h) * S + qj + li;
-      l_q[j] = lse[sidx] * 1.4426950408889634f;
+      l_q[j] = -lse[sidx] / scale;   // accumulator init of the score MFMAs: exp2(scale2 * (q.k + mask/scale - lse/scale))
       d_q[j] = group4_sum(dot8(dof[j][0], glb_frag(ob, H, qj, 0, lane)) + dot8(dof[j][1], glb_frag(ob, H, qj, 1, lane)));
       if (g == 0) Dv[sidx] = d_q[j];
       rk[j] = DROP ? drop_rowkey(drop_seed, bhS + (uint32_t)(qj + li)) : 0u;
 #pragma unroll
       for (int db = 0; db < 4; ++db) dq[j][db] = zero4;
     }
-    for (int kc = 0; kc < nkc; ++kc) {
-      const int co = kc * 4096;
-      // one read of each K / V fragment of the chunk (keys kc*32 .. +31, two 16-key fragments x two k-steps) ...
-      const bf16x8 k00 = kc_at(pK.kc[0], co), k01 = kc_at(pK.kc[1], co);
-      const bf16x8 k10 = kc_at(pK.kc[0], co + 2048), k11 = kc_at(pK.kc[1], co + 2048);
-      const bf16x8 v00 = kc_at(pV.kc[0], co), v01 = kc_at(pV.kc[1], co);
-      const bf16x8 v10 = kc_at(pV.kc[0], co + 2048), v11 = kc_at(pV.kc[1], co + 2048);
-      const float4 m0 = *reinterpret_cast<const float4*>(sMask + kc * 32 + g * 4);
-      const float4 m1 = *reinterpret_cast<const float4*>(sMask + kc * 32 + 16 + g * 4);
-      const float mb0[4] = {m0.x, m0.y, m0.z, m0.w};
-      const float mb1[4] = {m1.x, m1.y, m1.z, m1.w};
-      uint32_t ck0[4] = {0u, 0u, 0u, 0u}, ck1[4] = {0u, 0u, 0u, 0u};
-      if (DROP) {
-        const uint4 c0 = *reinterpret_cast<const uint4*>(sCk + kc * 32 + g * 4);
-        const uint4 c1 = *reinterpret_cast<const uint4*>(sCk + kc * 32 + 16 + g * 4);
-        ck0[0] = c0.x; ck0[1] = c0.y; ck0[2] = c0.z; ck0[3] = c0.w;
-        ck1[0] = c1.x; ck1[1] = c1.y; ck1[2] = c1.z; ck1[3] = c1.w;
-      }
-      // ... feeds both row blocks: S^T and dP^T tiles [key, query] (lane: keys g*4 + r of each 16-key fragment, query li)
-      f4v s0[2], s1[2], p0[2], p1[2];
+    // Two chunks per trip with compile-time offsets inside the pair: the 12 per-lane LDS addresses are advanced once per
+    // pair instead of one v_add per fragment read (30 of the ~110 VALU instructions of a chunk were address adds).
+    // Softmax backward arithmetic per score: the score accumulators START at -lse/scale (per query, one value per lane) so
+    //   P = exp2(scale2 * acc)                       -- one multiply + one exp, no subtract, no fma
+    // and only chunks that hold a masked key (at most the last one for prefix masks) add mask/scale first.
+    for (int kc = 0; kc < nkc; kc += 2) {
+      const unsigned char* bk0 = pK.kc[0] + kc * 4096;
+      const unsigned char* bk1 = pK.kc[1] + kc * 4096;
+      const unsigned char* bv0 = pV.kc[0] + kc * 4096;
+      const unsigned char* bv1 = pV.kc[1] + kc * 4096;
+      const unsigned char* bt[4] = {pK.tr[0] + kc * 4096, pK.tr[1] + kc * 4096, pK.tr[2] + kc * 4096, pK.tr[3] + kc * 4096};
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const f4v pinit = DROP ? zero4 : (f4v){-d_q[j], -d_q[j], -d_q[j], -d_q[j]};
-        s0[j] = MFMA(k00, qf[j][0], zero4);
-        s0[j] = MFMA(k01, qf[j][1], s0[j]);
-        s1[j] = MFMA(k10, qf[j][0], zero4);
-        s1[j] = MFMA(k11, qf[j][1], s1[j]);
-        p0[j] = MFMA(v00, dof[j][0], pinit);
-        p0[j] = MFMA(v01, dof[j][1], p0[j]);
-        p1[j] = MFMA(v10, dof[j][0], pinit);
-        p1[j] = MFMA(v11, dof[j][1], p1[j]);
-      }
-      bf16x8 dsb[2];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        f4v ds0, ds1;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float pr0 = __builtin_amdgcn_exp2f(s0[j][r] * scale2 + (mb0[r] - l_q[j]));
-          const float pr1 = __builtin_amdgcn_exp2f(s1[j][r] * scale2 + (mb1[r] - l_q[j]));
-          float dp0 = p0[j][r], dp1 = p1[j][r];
-          if (DROP) {
-            dp0 = drop_keep(rk[j], ck0[r], drop_thresh) ? dp0 * dscale : 0.0f;
-            dp1 = drop_keep(rk[j], ck1[r], drop_thresh) ? dp1 * dscale : 0.0f;
-          }
-          ds0[r] = DROP ? pr0 * (dp0 - d_q[j]) : pr0 * dp0;
-          ds1[r] = DROP ? pr1 * (dp1 - d_q[j]) : pr1 * dp1;
+      for (int u = 0; u < 2; ++u) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int co = u * 4096;
+        const bool masked = (kc + u) >= nfree;   // wave-uniform
+        const bf16x8 k00 = kc_at(bk0, co), k01 = kc_at(bk1, co);
+        const bf16x8 k10 = kc_at(bk0, co + 2048), k11 = kc_at(bk1, co + 2048);
+        const bf16x8 v00 = kc_at(bv0, co), v01 = kc_at(bv1, co);
+        const bf16x8 v10 = kc_at(bv0, co + 2048), v11 = kc_at(bv1, co + 2048);
+        uint32_t ck0[4] = {0u, 0u, 0u, 0u}, ck1[4] = {0u, 0u, 0u, 0u};
+        if (DROP) {
+          const uint4 c0 = *reinterpret_cast<const uint4*>(sCk + (kc + u) * 32 + g * 4);
+          const uint4 c1 = *reinterpret_cast<const uint4*>(sCk + (kc + u) * 32 + 16 + g * 4);
+          ck0[0] = c0.x; ck0[1] = c0.y; ck0[2] = c0.z; ck0[3] = c0.w;
+          ck1[0] = c1.x; ck1[1] = c1.y; ck1[2] = c1.z; ck1[3] = c1.w;
         }
-        dsb[j] = pack_b(ds0, ds1);
-      }
+        // S^T and dP^T tiles [key, query] (lane: keys g*4 + r of each 16-key fragment, query li) for both row blocks
+        f4v s0[2], s1[2], p0[2], p1[2];
 #pragma unroll
-      for (int db = 0; db < 4; ++db) {
-        const bf16x8 t = tr_at(pK.tr[db], co);
-        dq[0][db] = MFMA(t, dsb[0], dq[0][db]);
-        dq[1][db] = MFMA(t, dsb[1], dq[1][db]);
+        for (int j = 0; j < 2; ++j) {
+          const f4v sinit = (f4v){l_q[j], l_q[j], l_q[j], l_q[j]};
+          const f4v pinit = DROP ? zero4 : (f4v){-d_q[j], -d_q[j], -d_q[j], -d_q[j]};
+          s0[j] = MFMA(k00, qf[j][0], sinit);
+          s0[j] = MFMA(k01, qf[j][1], s0[j]);
+          s1[j] = MFMA(k10, qf[j][0], sinit);
+          s1[j] = MFMA(k11, qf[j][1], s1[j]);
+          p0[j] = MFMA(v00, dof[j][0], pinit);
+          p0[j] = MFMA(v01, dof[j][1], p0[j]);
+          p1[j] = MFMA(v10, dof[j][0], pinit);
+          p1[j] = MFMA(v11, dof[j][1], p1[j]);
+        }
+        if (masked) {
+          const f4v m0 = *reinterpret_cast<const f4v*>(sMask + (kc + u) * 32 + g * 4);
+          const f4v m1 = *reinterpret_cast<const f4v*>(sMask + (kc + u) * 32 + 16 + g * 4);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            s0[j] += m0;
+            s1[j] += m1;
+          }
+        }
+        bf16x8 dsb[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          f4v ds0, ds1;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float pr0 = __builtin_amdgcn_exp2f(s0[j][r] * scale2);
+            const float pr1 = __builtin_amdgcn_exp2f(s1[j][r] * scale2);
+            float dp0 = p0[j][r], dp1 = p1[j][r];
+            if (DROP) {
+              dp0 = drop_keep(rk[j], ck0[r], drop_thresh) ? dp0 * dscale : 0.0f;
+              dp1 = drop_keep(rk[j], ck1[r], drop_thresh) ? dp1 * dscale : 0.0f;
+            }
+            ds0[r] = DROP ? pr0 * (dp0 - d_q[j]) : pr0 * dp0;
+            ds1[r] = DROP ? pr1 * (dp1 - d_q[j]) : pr1 * dp1;
+          }
+          dsb[j] = pack_b(ds0, ds1);
+        }
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          const bf16x8 t = tr_at(bt[db], co);
+          dq[0][db] = MFMA(t, dsb[0], dq[0][db]);
+          dq[1][db] = MFMA(t, dsb[1], dq[1][db]);
+        }
       }
     }
 #pragma unroll
@@ -786,7 +824,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv2_kernel(const bf16_t* __rest
   const uint32_t bhS = (uint32_t)sbase;
   const float dscale = DROP ? drop_scale(drop_thresh) : 1.0f;
   for (int i = tid; i < S; i += 512) {
-    sL[i] = lse[sbase + i] * 1.4426950408889634f;
+    sL[i] = -lse[sbase + i] / scale;   // accumulator init of the score MFMAs (see attn_bwd_dq2_kernel)
     sD[i] = -Dv[sbase + i];
     if (DROP) sRk[i] = drop_rowkey(drop_seed, bhS + (uint32_t)i);
   }
@@ -812,76 +850,97 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv2_kernel(const bf16_t* __rest
       kf[j][1] = glb_frag(base + H, ld, kj, 1, lane);
       vf[j][0] = glb_frag(base + 2 * H, ld, kj, 0, lane);
       vf[j][1] = glb_frag(base + 2 * H, ld, kj, 1, lane);
-      mb[j] = maskbias[(size_t)b * S + kj + li] * 1.4426950408889634f;
+      mb[j] = maskbias[(size_t)b * S + kj + li] / scale;
       ck[j] = DROP ? drop_colkey(drop_seed, bhS + (uint32_t)(kj + li)) : 0u;
 #pragma unroll
       for (int db = 0; db < 4; ++db) dk[j][db] = dv[j][db] = zero4;
     }
     // a wave whose 32 keys are all masked has P = 0 exactly: dK = dV = 0 for its rows (wave-uniform skip of the loop)
-    const bool live = __builtin_amdgcn_readfirstlane(__any((mb[0] > -1.0f) || (mb[1] > -1.0f)) ? 1 : 0) != 0;
-    for (int qc = 0; live && qc < nqc; ++qc) {
-      const int co = qc * 4096;
-      const bf16x8 q00 = kc_at(pQ.kc[0], co), q01 = kc_at(pQ.kc[1], co);
-      const bf16x8 q10 = kc_at(pQ.kc[0], co + 2048), q11 = kc_at(pQ.kc[1], co + 2048);
-      const bf16x8 o00 = kc_at(pO.kc[0], co), o01 = kc_at(pO.kc[1], co);
-      const bf16x8 o10 = kc_at(pO.kc[0], co + 2048), o11 = kc_at(pO.kc[1], co + 2048);
-      const float4 l0 = *reinterpret_cast<const float4*>(sL + qc * 32 + g * 4);
-      const float4 l1 = *reinterpret_cast<const float4*>(sL + qc * 32 + 16 + g * 4);
-      const f4v nd0 = *reinterpret_cast<const f4v*>(sD + qc * 32 + g * 4);
-      const f4v nd1 = *reinterpret_cast<const f4v*>(sD + qc * 32 + 16 + g * 4);
-      const float la[4] = {l0.x, l0.y, l0.z, l0.w}, lb[4] = {l1.x, l1.y, l1.z, l1.w};
-      uint32_t rk0[4] = {0u, 0u, 0u, 0u}, rk1[4] = {0u, 0u, 0u, 0u};
-      if (DROP) {
-        const uint4 c0 = *reinterpret_cast<const uint4*>(sRk + qc * 32 + g * 4);
-        const uint4 c1 = *reinterpret_cast<const uint4*>(sRk + qc * 32 + 16 + g * 4);
-        rk0[0] = c0.x; rk0[1] = c0.y; rk0[2] = c0.z; rk0[3] = c0.w;
-        rk1[0] = c1.x; rk1[1] = c1.y; rk1[2] = c1.z; rk1[3] = c1.w;
-      }
-      // S and dP tiles [query, key]: lane holds queries qc*32 + f*16 + g*4 + r, key k0 + j*16 + li
-      f4v s0[2], s1[2], p0[2], p1[2];
+    const bool live = __builtin_amdgcn_readfirstlane(__any((mb[0] > -8.0f) || (mb[1] > -8.0f)) ? 1 : 0) != 0;
+    // none of the wave's 32 keys masked (every full-length sentence): the mask add disappears
+    const bool masked = __builtin_amdgcn_readfirstlane(__any((mb[0] != 0.0f) || (mb[1] != 0.0f)) ? 1 : 0) != 0;
+    // two query chunks per trip, compile-time offsets inside the pair (S % 64 == 0, so nqc is even)
+    for (int qc = 0; live && qc < nqc; qc += 2) {
+      const unsigned char* bq0 = pQ.kc[0] + qc * 4096;
+      const unsigned char* bq1 = pQ.kc[1] + qc * 4096;
+      const unsigned char* bo0 = pO.kc[0] + qc * 4096;
+      const unsigned char* bo1 = pO.kc[1] + qc * 4096;
+      const unsigned char* btq[4] = {pQ.tr[0] + qc * 4096, pQ.tr[1] + qc * 4096, pQ.tr[2] + qc * 4096, pQ.tr[3] + qc * 4096};
+      const unsigned char* bto[4] = {pO.tr[0] + qc * 4096, pO.tr[1] + qc * 4096, pO.tr[2] + qc * 4096, pO.tr[3] + qc * 4096};
+      const float* pl = sL + qc * 32 + g * 4;
+      const float* pd = sD + qc * 32 + g * 4;
+      const uint32_t* prk = sRk + qc * 32 + g * 4;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        s0[j] = MFMA(q00, kf[j][0], zero4);
-        s0[j] = MFMA(q01, kf[j][1], s0[j]);
-        s1[j] = MFMA(q10, kf[j][0], zero4);
-        s1[j] = MFMA(q11, kf[j][1], s1[j]);
-        p0[j] = MFMA(o00, vf[j][0], DROP ? zero4 : nd0);
-        p0[j] = MFMA(o01, vf[j][1], p0[j]);
-        p1[j] = MFMA(o10, vf[j][0], DROP ? zero4 : nd1);
-        p1[j] = MFMA(o11, vf[j][1], p1[j]);
-      }
-      bf16x8 pb[2], dsb[2];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        f4v pr0, pr1, ds0, ds1;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float e0 = __builtin_amdgcn_exp2f(s0[j][r] * scale2 + (mb[j] - la[r]));
-          const float e1 = __builtin_amdgcn_exp2f(s1[j][r] * scale2 + (mb[j] - lb[r]));
-          float dp0 = p0[j][r], dp1 = p1[j][r];
-          pr0[r] = e0;
-          pr1[r] = e1;
-          if (DROP) {
-            const bool k0_ = drop_keep(rk0[r], ck[j], drop_thresh), k1_ = drop_keep(rk1[r], ck[j], drop_thresh);
-            pr0[r] = k0_ ? e0 * dscale : 0.0f;
-            pr1[r] = k1_ ? e1 * dscale : 0.0f;
-            dp0 = k0_ ? dp0 * dscale : 0.0f;
-            dp1 = k1_ ? dp1 * dscale : 0.0f;
-          }
-          ds0[r] = DROP ? e0 * (dp0 + nd0[r]) : e0 * dp0;
-          ds1[r] = DROP ? e1 * (dp1 + nd1[r]) : e1 * dp1;
+      for (int u = 0; u < 2; ++u) {
+        const int co = u * 4096;
+        const bf16x8 q00 = kc_at(bq0, co), q01 = kc_at(bq1, co);
+        const bf16x8 q10 = kc_at(bq0, co + 2048), q11 = kc_at(bq1, co + 2048);
+        const bf16x8 o00 = kc_at(bo0, co), o01 = kc_at(bo1, co);
+        const bf16x8 o10 = kc_at(bo0, co + 2048), o11 = kc_at(bo1, co + 2048);
+        const f4v sl0 = *reinterpret_cast<const f4v*>(pl + u * 32);         // -lse/scale of queries qc*32 + g*4 + r
+        const f4v sl1 = *reinterpret_cast<const f4v*>(pl + u * 32 + 16);
+        const f4v nd0 = *reinterpret_cast<const f4v*>(pd + u * 32);
+        const f4v nd1 = *reinterpret_cast<const f4v*>(pd + u * 32 + 16);
+        uint32_t rk0[4] = {0u, 0u, 0u, 0u}, rk1[4] = {0u, 0u, 0u, 0u};
+        if (DROP) {
+          const uint4 c0 = *reinterpret_cast<const uint4*>(prk + u * 32);
+          const uint4 c1 = *reinterpret_cast<const uint4*>(prk + u * 32 + 16);
+          rk0[0] = c0.x; rk0[1] = c0.y; rk0[2] = c0.z; rk0[3] = c0.w;
+          rk1[0] = c1.x; rk1[1] = c1.y; rk1[2] = c1.z; rk1[3] = c1.w;
         }
-        pb[j] = pack_b(pr0, pr1);
-        dsb[j] = pack_b(ds0, ds1);
-      }
+        // S and dP tiles [query, key]: lane holds queries (qc+u)*32 + f*16 + g*4 + r, key k0 + j*16 + li
+        f4v s0[2], s1[2], p0[2], p1[2];
 #pragma unroll
-      for (int db = 0; db < 4; ++db) {
-        const bf16x8 tO = tr_at(pO.tr[db], co);
-        const bf16x8 tQ = tr_at(pQ.tr[db], co);
-        dv[0][db] = MFMA(tO, pb[0], dv[0][db]);
-        dv[1][db] = MFMA(tO, pb[1], dv[1][db]);
-        dk[0][db] = MFMA(tQ, dsb[0], dk[0][db]);
-        dk[1][db] = MFMA(tQ, dsb[1], dk[1][db]);
+        for (int j = 0; j < 2; ++j) {
+          s0[j] = MFMA(q00, kf[j][0], sl0);
+          s0[j] = MFMA(q01, kf[j][1], s0[j]);
+          s1[j] = MFMA(q10, kf[j][0], sl1);
+          s1[j] = MFMA(q11, kf[j][1], s1[j]);
+          p0[j] = MFMA(o00, vf[j][0], DROP ? zero4 : nd0);
+          p0[j] = MFMA(o01, vf[j][1], p0[j]);
+          p1[j] = MFMA(o10, vf[j][0], DROP ? zero4 : nd1);
+          p1[j] = MFMA(o11, vf[j][1], p1[j]);
+        }
+        if (masked) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            s0[j] += mb[j];
+            s1[j] += mb[j];
+          }
+        }
+        bf16x8 pb[2], dsb[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          f4v pr0, pr1, ds0, ds1;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float e0 = __builtin_amdgcn_exp2f(s0[j][r] * scale2);
+            const float e1 = __builtin_amdgcn_exp2f(s1[j][r] * scale2);
+            float dp0 = p0[j][r], dp1 = p1[j][r];
+            pr0[r] = e0;
+            pr1[r] = e1;
+            if (DROP) {
+              const bool k0_ = drop_keep(rk0[r], ck[j], drop_thresh), k1_ = drop_keep(rk1[r], ck[j], drop_thresh);
+              pr0[r] = k0_ ? e0 * dscale : 0.0f;
+              pr1[r] = k1_ ? e1 * dscale : 0.0f;
+              dp0 = k0_ ? dp0 * dscale : 0.0f;
+              dp1 = k1_ ? dp1 * dscale : 0.0f;
+            }
+            ds0[r] = DROP ? e0 * (dp0 + nd0[r]) : e0 * dp0;
+            ds1[r] = DROP ? e1 * (dp1 + nd1[r]) : e1 * dp1;
+          }
+          pb[j] = pack_b(pr0, pr1);
+          dsb[j] = pack_b(ds0, ds1);
+        }
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          const bf16x8 tO = tr_at(bto[db], co);
+          const bf16x8 tQ = tr_at(btq[db], co);
+          dv[0][db] = MFMA(tO, pb[0], dv[0][db]);
+          dv[1][db] = MFMA(tO, pb[1], dv[1][db]);
+          dk[0][db] = MFMA(tQ, dsb[0], dk[0][db]);
+          dk[1][db] = MFMA(tQ, dsb[1], dk[1][db]);
+        }
       }
     }
 #pragma unroll

@@ -51,6 +51,7 @@ def main():
     from flair.data import Dictionary, Sentence
     from flair.embeddings import StackedEmbeddings, TransformerWordEmbeddings
     from flair.models import FastSequenceTagger
+    from flair.training_utils import store_embeddings
 
     work = tempfile.mkdtemp(prefix="refcpu_")
     mdir = os.path.join(work, "xlmr")
@@ -107,6 +108,7 @@ def main():
         for batch in loader:
             loss = tagger.forward_loss(batch)
             (loss / accum).backward()
+            store_embeddings(batch, "none")     # finetune_trainer.py:1046,1059-1061
             batch.features = {}
         torch.nn.utils.clip_grad_norm_(tagger.parameters(), 5.0)
         opt.step()

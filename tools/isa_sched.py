@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Compact view of a kernel's instruction schedule: M=mfma r=ds_read G=global_load_lds B=barrier w[..]=waitcnt .=other
+"""Compact view of a kernel's instruction schedule: M=mfma v=VALU e=transcendental r=ds_read G=global_load_lds B=barrier n=s_nop w[..]=waitcnt .=other
 Usage: python tools/isa_sched.py file.hip mangled_substring [first_line last_line]"""
 import re, subprocess, sys, os
 src, key = sys.argv[1], sys.argv[2]
@@ -32,6 +32,9 @@ for l in body:
     elif op.startswith(("global_store", "buffer_store")): comp.append("S")
     elif op.startswith("s_waitcnt"): comp.append("w[" + t.split(None, 1)[1].replace(" ", "") + "]")
     elif op.startswith("s_barrier"): comp.append("B")
+    elif op.startswith(("v_exp", "v_log", "v_rcp", "v_rsq", "v_sqrt", "v_sin", "v_cos")): comp.append("e")
+    elif op.startswith("v_"): comp.append("v")
+    elif op.startswith("s_nop"): comp.append("n")
     elif op.startswith(("s_cbranch", "s_branch")): comp.append("<" + t.split()[1] + ">")
     else: comp.append(".")
 txt = "".join(comp)
