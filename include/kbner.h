@@ -55,6 +55,9 @@ int kbner_crf_posterior(const float* emit, const float* trans, const int* lens, 
 /* first-subtoken pooling + assign_batch_features (flair/embeddings.py:3288-3345,108-124) and the remove_x
  * compaction loop (sequence_tagger_model.py:2474-2488) as ONE gather: out[r] = idx[r] >= 0 ? src[idx[r]] : 0 */
 int kbner_gather_rows(const kbner_bf16* src, const int* idx, kbner_bf16* out, int R, int H, void* stream);
+/* strided variant: out[r, 0:H] (row stride ld_out) = idx[r] >= 0 ? src[idx[r], 0:H] (row stride ld_src) : 0.  One embedding's
+ * pooled features written into its column block of the stacked-embedding matrix (torch.cat at sequence_tagger_model.py:879-891) */
+int kbner_gather_rows_ld(const kbner_bf16* src, int ld_src, const int* idx, kbner_bf16* out, int ld_out, int R, int H, void* stream);
 /* fp32 variant for the evaluation path: emissions [B*n,T] -> the rows _obtain_labels decodes (sequence_tagger_model.py:1198-1200) */
 int kbner_gather_rows_f32(const float* src, const int* idx, float* out, int R, int W, void* stream);
 /* fp32 row scatter dst[idx[r],:] = rows[r,:] (unique indices, W % 4 == 0): the data-parallel exchange of the touched
@@ -146,6 +149,17 @@ int kbner_attn_fwd(const kbner_bf16* qkv, const float* maskbias, kbner_bf16* ctx
 int kbner_attn_bwd(const kbner_bf16* qkv, const kbner_bf16* ctx, const kbner_bf16* dctx, const float* maskbias,
                    const float* lse, float* Dws, kbner_bf16* dqkv, int B, int S, int H, int A, uint32_t drop_seed,
                    uint32_t drop_thresh, float* dbias_qkv, void* stream);
+
+/* ---------------- LSTM recurrence (inference): BiLSTM tagger head + FlairEmbeddings character LMs ---------------- */
+/* One time step of torch.nn.LSTM's recurrent half for a whole batch and `ndir` directions / models
+ * (flair/models/sequence_tagger_model.py:324-357,969-994 `self.rnn`; flair/models/language_model.py:41-44,71-95):
+ *   gates = gx[gxi[d][b]] (= Wih x_t + bih + bhh, bf16, gate order i|f|g|o, direction d at column d*4*Hp) + h_in Whh^T
+ *   c = sigmoid(f) c + sigmoid(i) tanh(g) ; h_out = sigmoid(o) tanh(c) ; out[outi[d][b], d*out_dir_stride + :] = h_out
+ * gxi < 0: the sequence is finished (pack_padded_sequence semantics): state carried unchanged.  outi < 0: h not stored.
+ * whh bf16 [ndir, 4Hp, Hp]; h_in / h_out bf16 [ndir, B, Hp]; c f32 [ndir, B, Hp].  Hp % 32 == 0 (zero-pad hidden 1000 -> 1024). */
+int kbner_lstm_step(const kbner_bf16* gx, int ld_gx, const int* gxi, const kbner_bf16* whh, const kbner_bf16* h_in,
+                    kbner_bf16* h_out, float* c, kbner_bf16* out, int ldo, int out_dir_stride, const int* outi, int B, int Hp,
+                    int ndir, void* stream);
 
 /* ---------------- optimiser (transformers==3.0.0 AdamW + clip_grad_norm_, finetune_trainer.py:1010,1018) ------------- */
 int kbner_sqnorm_ws_floats(void);

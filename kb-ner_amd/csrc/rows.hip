@@ -264,6 +264,31 @@ extern "C" int kbner_gather_rows_f32(const float* src, const int* idx, float* ou
   KBNER_LAUNCH_RET();
 }
 
+// Strided variant of gather_rows for the stacked-embedding concat of BASELINE config 5 (sequence_tagger_model.py:879-891:
+// torch.cat of every embedding's [B, n, D_i] features): embedding i's pooled rows are written straight into its column block
+// of the concatenated [rows, ld_out] matrix -- out[r, 0:H] = idx[r] >= 0 ? src[idx[r], 0:H] * mul : 0 -- so the concatenation
+// never exists as a separate copy.  16-byte accesses (H % 8 == 0, ld_out % 8 == 0, out 16-byte aligned).
+__global__ __launch_bounds__(256) void gather_rows_ld_kernel(const bf16_t* __restrict__ src, int ld_src, const int* __restrict__ idx,
+                                                             bf16_t* __restrict__ out, int ld_out, int R, int H8) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)R * H8) return;
+  const int r = (int)(i / H8), c = (int)(i % H8);
+  const int s = idx[r];
+  uint4 v = make_uint4(0u, 0u, 0u, 0u);
+  if (s >= 0) v = *reinterpret_cast<const uint4*>(src + (size_t)s * ld_src + c * 8);
+  *reinterpret_cast<uint4*>(out + (size_t)r * ld_out + c * 8) = v;
+}
+
+extern "C" int kbner_gather_rows_ld(const bf16_t* src, int ld_src, const int* idx, bf16_t* out, int ld_out, int R, int H,
+                                    void* stream) {
+  KBNER_CHECK_ARG(R >= 0 && H > 0 && H % 8 == 0 && ld_src % 8 == 0 && ld_out % 8 == 0);
+  if (R == 0) return 0;
+  const size_t n = (size_t)R * (H / 8);
+  hipLaunchKernelGGL(gather_rows_ld_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, ld_src, idx,
+                     out, ld_out, R, H / 8);
+  KBNER_LAUNCH_RET();
+}
+
 // fp32 row scatter (data-parallel exchange of the touched word-embedding gradient rows, kbner/dp.py): dst[idx[r],:] = rows[r,:];
 // indices unique, 16-byte accesses (W % 4 == 0)
 __global__ __launch_bounds__(256) void scatter_rows_f32_kernel(const float4* __restrict__ rows, const int* __restrict__ idx,

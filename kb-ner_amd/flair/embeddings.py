@@ -336,6 +336,22 @@ class TransformerWordEmbeddings(TokenEmbeddings):
             r0 += len(rows)
         return ids, am, first, lengths, first_row
 
+    def prepare_stack_batch(self, sentences):
+        """integer batch for the frozen-stack path (BASELINE config 5).  With `use_internal_doc` the encoder reads each
+        sentence's UNCHUNKED copy `sentence.doc_sent` (the sentence plus its retrieved context, embeddings.py:3116-3117) while
+        only the tokens of the chunked sentence are pooled (:3283-3284: zip over the input sentence truncates)."""
+        src = [getattr(s, "doc_sent", s) for s in sentences] if self.use_internal_doc else list(sentences)
+        ids, am, first, lengths, first_row = self.prepare_batch(src)
+        n = max(len(s) for s in sentences)
+        B = len(sentences)
+        f2 = np.full((B, n), -1, np.int64)
+        r2 = np.zeros((B, n), np.int64)
+        for b, s in enumerate(sentences):
+            k = min(len(s), first.shape[1])
+            f2[b, :k] = first[b, :k]
+            r2[b, :k] = first_row[b, :k]
+        return ids, am, f2, np.asarray([len(s) for s in sentences], np.int64), r2
+
     def _add_embeddings_internal(self, sentences):
         """stores the integer batch on the BatchedData (or returns it); the tagger's engine turns it into features"""
         batch = self.prepare_batch(sentences)
@@ -349,6 +365,79 @@ class TransformerWordEmbeddings(TokenEmbeddings):
 
     def extra_repr(self):
         return "model=%s" % self.name
+
+    def __str__(self):
+        return self.name
+
+
+class FlairEmbeddings(TokenEmbeddings):
+    """Contextual string embeddings (Akbik et al. 2018) at inference: a character LM reads the whole tokenised sentence and
+    the hidden state after each token's last character (forward LM) / before its first character read backwards (backward LM)
+    is that token's embedding.
+
+    Behavioural reference (restated): flair/embeddings.py FlairEmbeddings (:2271-2543): sentence text = tokens joined by one
+    blank; every string of the batch is framed as "\n" + text (reversed for a backward LM) + " " and blank-padded to the
+    longest (:2493-2510); token offsets :2520-2540.  `model` must be a local LanguageModel file (LanguageModel.save format):
+    the named models ('en-forward', 'multi-backward', ...) are downloads, unavailable offline.  Only this class's bookkeeping
+    is host code; the LM itself runs in kbner.stack.CharLM (HIP LSTM kernel)."""
+
+    def __init__(self, model, fine_tune: bool = False, chars_per_chunk: int = 512, embedding_name: str = None):
+        super().__init__()
+        if fine_tune:
+            raise NotImplementedError("fine-tuning a character LM is outside the hot path (FlairEmbeddings are frozen in config 5)")
+        from flair.models.language_model import LanguageModel
+        if isinstance(model, LanguageModel):
+            self.lm = model
+            self.name = "Task-LSTM-%s-%s-%s" % (self.lm.hidden_size, self.lm.nlayers, self.lm.is_forward_lm)
+        else:
+            if not os.path.exists(str(model)):
+                raise FileNotFoundError("FlairEmbeddings(model=%r): a local character-LM file is required -- the named models are "
+                                        "downloads (no network)" % (model,))
+            self.lm = LanguageModel.load_language_model(model)
+            self.name = str(model)
+        if embedding_name is not None:
+            self.name = embedding_name
+        self.fine_tune = False
+        self.static_embeddings = True
+        self.is_forward_lm = self.lm.is_forward_lm
+        self.chars_per_chunk = chars_per_chunk
+        self._engine = None
+
+    @property
+    def embedding_length(self) -> int:
+        return int(self.lm.hidden_size)
+
+    def char_batch(self, sentences, n):
+        """-> (char_ids int32 [steps, B], out_rows int32 [steps, B]): the framed / padded character ids and, per step, the
+        token-major feature row (b * n + token) that receives the hidden state produced at that step, else -1"""
+        texts = [s.to_tokenized_string() for s in sentences]
+        longest = max(len(t) for t in texts)
+        B = len(sentences)
+        steps = longest + 2
+        ids = np.zeros((steps, B), np.int32)
+        rows = np.full((steps, B), -1, np.int32)
+        get = self.lm.dictionary.get_idx_for_item
+        blank = get(" ")
+        for b, (s, t) in enumerate(zip(sentences, texts)):
+            framed = "\n" + (t if self.is_forward_lm else t[::-1]) + " " + " " * (longest - len(t))
+            ids[:, b] = [get(ch) for ch in framed] if framed else blank
+            off_f, off_b = 1, len(t) + 1
+            for k, tok in enumerate(s.tokens):
+                off_f += len(tok.text)
+                off = off_f if self.is_forward_lm else off_b
+                rows[off, b] = b * n + k
+                off_f += 1
+                off_b -= 1 + len(tok.text)
+        return ids, rows
+
+    def engine(self, device):
+        if self._engine is None:
+            from kbner.stack import CharLM
+            self._engine = CharLM(self.lm.state_dict(), self.lm.hidden_size, device)
+        return self._engine
+
+    def _add_embeddings_internal(self, sentences):
+        return sentences   # features are produced on the device by the tagger's stack engine
 
     def __str__(self):
         return self.name

@@ -64,17 +64,15 @@ class SequenceTagger(flair.nn.Model):
                 raise NotImplementedError("%s=True is outside the MI355X hot path (XLM-R [+ frozen stack + BiLSTM] + linear + CRF)" % k)
         if not use_crf:
             raise NotImplementedError("use_crf=False (softmax head) is not on the hot path")
-        if use_rnn:
-            raise NotImplementedError("use_rnn=True: see flair.models.sequence_tagger_model (BiLSTM head, inference only) -- not built yet")
-        if dropout or locked_dropout:
-            raise NotImplementedError("dropout / locked_dropout > 0 on the tagger head is not implemented (KB-NER YAMLs use 0.0)")
+        if use_rnn and rnn_layers != 1:
+            raise NotImplementedError("rnn_layers > 1 is not implemented (the KB-NER / ACE configs use the default of 1)")
         self.hidden_size = hidden_size
         self.embeddings = embeddings
         self.tag_dictionary = tag_dictionary
         self.tag_type = tag_type
         self.tagset_size = len(tag_dictionary)
         self.use_crf = True
-        self.use_rnn = False
+        self.use_rnn = bool(use_rnn)
         self.use_cnn = False
         self.sentence_level_loss = sentence_loss
         self.remove_x = remove_x
@@ -101,11 +99,21 @@ class SequenceTagger(flair.nn.Model):
         self.stop_idx = tag_dictionary.get_idx_for_item(STOP_TAG)
         self.x_idx = tag_dictionary.get_idx_for_item("S-X") if remove_x else None
         emb = embeddings.embeddings[0] if hasattr(embeddings, "embeddings") else embeddings
-        if hasattr(embeddings, "embeddings") and len(embeddings.embeddings) != 1:
-            raise NotImplementedError("exactly one TransformerWordEmbeddings is supported on the hot path")
         self._emb = emb
         self.engine = None
-        self._build_engine()
+        self.stack_head = None
+        if self.use_rnn:
+            # BASELINE config 5: frozen stacked embeddings -> BiLSTM -> linear -> CRF, inference only (kbner.stack)
+            if dropout:
+                raise NotImplementedError("dropout > 0 on the tagger head is not implemented")
+            self._build_stack()
+        else:
+            if hasattr(embeddings, "embeddings") and len(embeddings.embeddings) != 1:
+                raise NotImplementedError("the fine-tuning path (use_rnn: false) takes exactly one TransformerWordEmbeddings; "
+                                          "stacked embeddings go with use_rnn: true (inference)")
+            if dropout or locked_dropout:
+                raise NotImplementedError("dropout / locked_dropout > 0 on the tagger head is not implemented (KB-NER YAMLs use 0.0)")
+            self._build_engine()
 
     # ------------------------------------------------------------------ engine
     def _build_engine(self):
@@ -135,16 +143,114 @@ class SequenceTagger(flair.nn.Model):
         self._emb.model.source = self.engine
         self._emb.model._state_dict = None  # the arena is the single owner of the weights now
 
+    # ------------------------------------------------------------------ config 5: frozen stack + BiLSTM (inference)
+    def _build_stack(self):
+        """BiLSTM(sum of embedding widths -> hidden_size, bidirectional) + linear(2 * hidden -> T) + transitions, initialised
+        like the reference's torch modules (sequence_tagger_model.py:324-357,385-388,402-410); `load_stack_state` overwrites
+        them with trained values.  Feature blocks follow sorted(embedding names) -- the order forward() concatenates in (:879-891)."""
+        from kbner import stack as K
+        embs = list(self.embeddings.embeddings) if hasattr(self.embeddings, "embeddings") else [self.embeddings]
+        self._stack_embs = sorted(embs, key=lambda e: e.name)
+        blocks = [int(e.embedding_length) for e in self._stack_embs]
+        H, D, T = int(self.hidden_size), sum(blocks), self.tagset_size
+        g = torch.Generator().manual_seed(int(torch.initial_seed() % (2 ** 31)))
+        k = 1.0 / (H ** 0.5)
+        u = lambda *shape, b=k: (torch.rand(*shape, generator=g) * 2 - 1) * b   # noqa: E731
+        rnn = {}
+        for sfx in ("", "_reverse"):
+            rnn["weight_ih_l0" + sfx], rnn["weight_hh_l0" + sfx] = u(4 * H, D), u(4 * H, H)
+            rnn["bias_ih_l0" + sfx], rnn["bias_hh_l0" + sfx] = u(4 * H), u(4 * H)
+        kl = 1.0 / ((2 * H) ** 0.5)
+        tr = torch.randn(T, T, generator=g)
+        tr[self.start_idx, :] = -1e12
+        tr[:, self.stop_idx] = -1e12
+        self._stack_blocks = blocks
+        self.load_stack_state({"rnn": rnn, "linear.weight": u(T, 2 * H, b=kl), "linear.bias": u(T, b=kl), "transitions": tr})
+        self._encoders = {}
+
+    def load_stack_state(self, state):
+        """state: {"rnn": torch.nn.LSTM state dict, "linear.weight" [T, 2H], "linear.bias" [T], "transitions" [T, T]}"""
+        from kbner import stack as K
+        self._stack_state = {"rnn": {k: torch.as_tensor(v).detach().float().cpu() for k, v in state["rnn"].items()},
+                             "linear.weight": torch.as_tensor(state["linear.weight"]).detach().float().cpu(),
+                             "linear.bias": torch.as_tensor(state["linear.bias"]).detach().float().cpu(),
+                             "transitions": torch.as_tensor(state["transitions"]).detach().float().cpu()}
+        st = self._stack_state
+        self.stack_head = K.BiLSTMHead(st["rnn"], st["linear.weight"], st["linear.bias"], self._stack_blocks, self.hidden_size,
+                                       flair.device)
+        self._transitions = st["transitions"].to(flair.device).contiguous()
+
+    def _encoder_for(self, emb):
+        """frozen encoder of one TransformerWordEmbeddings on the HIP engine (weights loaded once, no gradient arenas)"""
+        enc = self._encoders.get(id(emb))
+        if enc is None:
+            from kbner import engine as E
+            hc = emb.model.config
+            cfg = E.EncoderConfig(vocab_size=hc.vocab_size, hidden_size=hc.hidden_size, num_hidden_layers=hc.num_hidden_layers,
+                                  num_attention_heads=hc.num_attention_heads, intermediate_size=hc.intermediate_size,
+                                  max_position_embeddings=hc.max_position_embeddings, type_vocab_size=getattr(hc, "type_vocab_size", 1),
+                                  pad_token_id=getattr(hc, "pad_token_id", 1) if getattr(hc, "pad_token_id", 1) is not None else 1,
+                                  layer_norm_eps=getattr(hc, "layer_norm_eps", 1e-5), hidden_dropout_prob=0.0,
+                                  attention_probs_dropout_prob=0.0)
+            enc = E.Tagger(cfg, self.tagset_size, self.start_idx, self.stop_idx, device=flair.device, inference=True)
+            enc.load_hf_state_dict(emb.model.state_dict())
+            self._encoders[id(emb)] = enc
+        return enc
+
+    def _forward_stack(self, sentences):
+        """emissions f32 [B, n, T]: every selected embedding writes its column block of X, then BiLSTM + linear"""
+        from kbner import batch as kb
+        from kbner import ops
+        from flair.embeddings import FlairEmbeddings, TransformerWordEmbeddings
+        B = len(sentences)
+        lengths = np.asarray([len(s) for s in sentences], np.int64)
+        n = int(lengths.max())
+        head = self.stack_head
+        X = head.new_input(B, n)
+        sel = self.selection if (getattr(self, "embedding_selector", False) and self.selection is not None) else None
+        for slot, emb in enumerate(self._stack_embs):
+            if sel is not None and float(sel[slot]) == 0.0:
+                continue   # features * 0 (:889): the block stays zero, the embedding is not even computed
+            if sel is not None and float(sel[slot]) != 1.0:
+                raise NotImplementedError("fractional embedding selection weights are not supported (best_action is 0/1)")
+            col = head.cols[slot]
+            if isinstance(emb, TransformerWordEmbeddings):
+                ids, am, first, lens, first_row = emb.prepare_stack_batch(sentences)
+                hb = kb.assemble(ids, am, first, np.zeros(first.shape, np.int64), lens, None, first_row=first_row)
+                db = kb.to_device(hb, flair.device)
+                enc = self._encoder_for(emb)
+                hidden = enc.encoder_forward(db["ids"], db["pos_ids"], db["maskbias"], db["R"], db["S"])
+                ops.gather_rows_into(hidden, db["row_idx"], X, col, enc.cfg.hidden_size)
+            elif isinstance(emb, FlairEmbeddings):
+                cids, rows = emb.char_batch(sentences, n)
+                emb.engine(flair.device).run(cids, rows, X, col)
+            else:
+                raise NotImplementedError("embedding class %s has no device producer" % type(emb).__name__)
+        feats = head.emissions(X, lengths, B, n)
+        # tags / remove_x bookkeeping for _calculate_loss and _obtain_labels (no encoder batch here: a 1-column dummy)
+        tags = np.zeros((B, n), np.int64)
+        for b, s in enumerate(sentences):
+            t = getattr(s, self.tag_type + "_tags", None)
+            if t is not None:
+                t = np.asarray(t)
+                tags[b, :min(n, len(t))] = t[:n]
+        hb = kb.assemble(np.zeros((B, 1), np.int64), np.ones((B, 1), np.int64), np.full((B, n), -1, np.int64), tags, lengths, self.x_idx)
+        self._last = (hb, kb.to_device(hb, flair.device))
+        self.mask = (torch.arange(n, device=feats.device)[None, :] < torch.from_numpy(lengths).to(feats.device)[:, None]).float()
+        return feats
+
     def train(self, mode: bool = True):
         """model.train() (finetune_trainer.py:938) switches the HF dropout sites and the tagger's WordDropout on; eval() off"""
         super().train(mode)
+        if getattr(self, "use_rnn", False) and mode:
+            log.warning("the BiLSTM / stacked tagger is inference-only here: train() mode has no effect")
         if getattr(self, "engine", None) is not None:
             self.engine.train(bool(mode) and bool(getattr(self._emb, "fine_tune", True)))
         return self
 
     @property
     def transitions(self):
-        return self.engine.arena.param("transitions")
+        return self._transitions if self.engine is None else self.engine.arena.param("transitions")
 
     @property
     def linear(self):
@@ -152,12 +258,22 @@ class SequenceTagger(flair.nn.Model):
             pass
 
         lin = _Lin()
-        lin.weight = self.engine.arena.param("linear.weight")
-        lin.bias = self.engine.arena.param("linear.bias")
+        if self.engine is None:
+            lin.weight, lin.bias = self._stack_state["linear.weight"], self._stack_state["linear.bias"]
+        else:
+            lin.weight = self.engine.arena.param("linear.weight")
+            lin.bias = self.engine.arena.param("linear.bias")
         return lin
 
     def named_parameters(self, prefix="", recurse=True):
         """(name, tensor view) with the reference's naming: `transitions`, `linear.*`, `embeddings.list_embedding_0.model.<hf>`"""
+        if self.engine is None:
+            yield "transitions", self._transitions
+            yield "linear.weight", self._stack_state["linear.weight"]
+            yield "linear.bias", self._stack_state["linear.bias"]
+            for k, v in self._stack_state["rnn"].items():
+                yield "rnn." + k, v
+            return
         yield "transitions", self.engine.arena.param("transitions")
         yield "linear.weight", self.engine.arena.param("linear.weight")
         yield "linear.bias", self.engine.arena.param("linear.bias")
@@ -169,7 +285,8 @@ class SequenceTagger(flair.nn.Model):
             yield p
 
     def zero_grad(self, set_to_none=False):
-        self.engine.arena.g.zero_()
+        if self.engine is not None:
+            self.engine.arena.g.zero_()
 
     def to(self, *a, **k):
         return self
@@ -198,6 +315,8 @@ class SequenceTagger(flair.nn.Model):
     # ------------------------------------------------------------------ forward / loss
     def forward(self, sentences, prediction_mode=False):
         """emissions f32 [B, n, T] for every word token (device tensor); sets self.mask to the length mask"""
+        if self.use_rnn:
+            return self._forward_stack(sentences)
         self.embeddings.embed(sentences)
         hb, db = self._device_batch(sentences)
         feats = self.engine.forward_features(db)
@@ -209,6 +328,9 @@ class SequenceTagger(flair.nn.Model):
     def forward_loss(self, data_points, sort=True, return_features=False):
         if isinstance(data_points, Sentence):
             data_points = [data_points]
+        if self.use_rnn:
+            feats = self._forward_stack(data_points)
+            return self._calculate_loss(feats, data_points, self.mask)
         self.embeddings.embed(data_points)
         hb, db = self._device_batch(data_points)
         self._last = (hb, db)
@@ -219,6 +341,8 @@ class SequenceTagger(flair.nn.Model):
         """forward_loss + backward into the gradient arena (what `loss.backward()` does at finetune_trainer.py:957).
         sentence_weights (optional, one per sentence) replace the 1/B of the batch mean: see ModelFinetuner.train's
         accumulation-group fusion.  grad_ready(lo, hi): called as soon as arena.g[lo:hi] is final (data-parallel overlap)."""
+        if self.use_rnn:
+            raise NotImplementedError("training the BiLSTM / stacked-embedding tagger (ACE) is out of scope: config 5 is inference-only")
         self.embeddings.embed(data_points)
         hb, db = self._device_batch(data_points)
         self._last = (hb, db)
@@ -242,7 +366,7 @@ class SequenceTagger(flair.nn.Model):
         nc = hb["ctags"].shape[1]
         idx = torch.from_numpy(_compact_index(hb["keep"], nc)).to(features.device)
         gathered = ops.gather_rows_f32(flat, idx)
-        logz, gold, _ = ops.crf_nll_fwd(gathered.view(B, nc, T).contiguous(), self.engine.arena.param("transitions"), db["ctags"],
+        logz, gold, _ = ops.crf_nll_fwd(gathered.view(B, nc, T).contiguous(), self.transitions, db["ctags"],
                                         db["clens"], self.start_idx, self.stop_idx)
         self.mask = torch.from_numpy(hb["keep"].astype(np.float32)).to(features.device)
         return (logz - gold).mean()
@@ -256,7 +380,7 @@ class SequenceTagger(flair.nn.Model):
             # :1182-1192,1212-1218: marginals softmax(alpha + beta) over the WHOLE token sequence (no S-X compaction);
             # positions self.mask zeroes get the all-zero score row, i.e. a uniform distribution and tag index 0
             full = torch.tensor([len(s) for s in sentences], dtype=torch.int32, device=feature.device)
-            marg = ops.crf_posterior(feature.contiguous(), self.engine.arena.param("transitions"), full, self.start_idx,
+            marg = ops.crf_posterior(feature.contiguous(), self.transitions, full, self.start_idx,
                                      self.stop_idx).cpu().numpy()
             out = []
             for b, s in enumerate(sentences):
@@ -273,7 +397,7 @@ class SequenceTagger(flair.nn.Model):
         nc = max(1, int(lens.max()))
         idx = torch.from_numpy(_compact_index(keep, nc)).to(feature.device)
         comp = ops.gather_rows_f32(feature.reshape(B * n, T).contiguous(), idx)
-        tags, conf = ops.crf_viterbi(comp.view(B, nc, T).contiguous(), self.engine.arena.param("transitions"),
+        tags, conf = ops.crf_viterbi(comp.view(B, nc, T).contiguous(), self.transitions,
                                      torch.from_numpy(lens).to(feature.device), self.start_idx, self.stop_idx)
         tags, conf = tags.cpu().numpy(), conf.cpu().numpy()
         x_item = "S-X"

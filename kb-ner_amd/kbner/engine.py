@@ -59,7 +59,7 @@ def _round_up(x, m):
 class Arena:
     """Flat fp32 parameter storage + grads + Adam state; tensors padded to 8 elements."""
 
-    def __init__(self, specs, device):
+    def __init__(self, specs, device, with_grad=True):
         self.device = device
         self.offsets = {}
         self.shapes = {}
@@ -83,7 +83,7 @@ class Arena:
             self.n_shadow = off
         self.n = off
         self.p = torch.zeros(self.n, dtype=F32, device=device)
-        self.g = torch.zeros(self.n, dtype=F32, device=device)
+        self.g = torch.zeros(self.n, dtype=F32, device=device) if with_grad else None   # frozen (inference) replicas hold no gradients
         self.m = None
         self.v = None
         self.shadow = torch.zeros(max(self.n_shadow, 8), dtype=BF16, device=device)
@@ -232,10 +232,10 @@ class Tagger:
     Reference path: TransformerWordEmbeddings (flair/embeddings.py:2906) -> FastSequenceTagger.forward /
     forward_loss / _calculate_loss (flair/models/sequence_tagger_model.py:844,1899,2426)."""
 
-    def __init__(self, cfg, num_tags, start_idx, stop_idx, device="cuda"):
+    def __init__(self, cfg, num_tags, start_idx, stop_idx, device="cuda", inference=False):
         self.cfg, self.T, self.start, self.stop = cfg, num_tags, start_idx, stop_idx
         self.device = torch.device(device)
-        self.arena = Arena(tagger_specs(cfg, num_tags), self.device)
+        self.arena = Arena(tagger_specs(cfg, num_tags), self.device, with_grad=not inference)
         self._acts = {}
         self._saved = None
         # Dropout (active only while `training`): the encoder's three HF sites (embeddings, attention probabilities,

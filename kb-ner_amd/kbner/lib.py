@@ -23,6 +23,7 @@ SIGNATURES = {
     "kbner_crf_nll_bwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P]),
     "kbner_crf_posterior": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P]),
     "kbner_gather_rows": (c_int, [P, P, P, c_int, c_int, P]),
+    "kbner_gather_rows_ld": (c_int, [P, c_int, P, P, c_int, c_int, c_int, P]),
     "kbner_gather_rows_f32": (c_int, [P, P, P, c_int, c_int, P]),
     "kbner_scatter_rows": (c_int, [P, P, P, c_int, c_int, P]),
     "kbner_scatter_rows_f32": (c_int, [P, P, P, c_int, c_int, P]),
@@ -42,6 +43,7 @@ SIGNATURES = {
     "kbner_splitk_finish": (c_int, [P, c_int, P, P, c_int, P, c_int, c_int, c_int, U32, U32, P]),
     "kbner_attn_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, U32, U32, P]),
     "kbner_attn_bwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, U32, U32, P, P]),
+    "kbner_lstm_step": (c_int, [P, c_int, P, P, P, P, P, P, c_int, c_int, P, c_int, c_int, c_int, P]),
     "kbner_sqnorm_ws_floats": (c_int, []),
     "kbner_grad_sqnorm": (c_int, [P, c_size_t, P, P, c_int, P]),
     "kbner_adamw_hf": (c_int, [P, P, P, P, P, c_size_t, c_size_t, c_float, c_float, c_float, c_float, c_float, P, c_float,

@@ -5,7 +5,7 @@ import ctypes
 import torch
 
 from . import lib as L
-from .lib import ptr, stream_ptr
+from .lib import c_void_p, ptr, stream_ptr
 
 BF16 = torch.bfloat16
 F32 = torch.float32
@@ -89,6 +89,15 @@ def gather_rows(src, idx, out=None):
         out = torch.empty((R, H), dtype=BF16, device=src.device)
     L.call("kbner_gather_rows", ptr(src), ptr(idx), ptr(out), R, H, stream_ptr())
     return out
+
+
+def gather_rows_into(src, idx, out2d, col, H):
+    """out2d[:, col:col+H] = rows of src picked by idx (-1 -> zeros); out2d bf16 [R, ld] (col % 8 == 0)"""
+    _chk(src, BF16, "src"); _chk(idx, I32, "idx"); _chk(out2d, BF16, "out2d")
+    if col % 8 or idx.numel() > out2d.shape[0]:
+        raise L.KbnerError("gather_rows_into: bad column offset / row count")
+    L.call("kbner_gather_rows_ld", ptr(src), src.shape[-1], ptr(idx), c_void_p(out2d.data_ptr() + 2 * col), out2d.shape[-1],
+           idx.numel(), H, stream_ptr())
 
 
 def gather_rows_f32(src, idx):
@@ -275,6 +284,17 @@ def attn_bwd(qkv, ctx, dctx, maskbias, lse, dws, dqkv, B, S, H, A, drop=NO_DROP,
     """dbias f32[3H] (optional): accumulates the column sums of dqkv (= d qkv.bias) inside the kernels"""
     L.call("kbner_attn_bwd", ptr(qkv), ptr(ctx), ptr(dctx), ptr(maskbias), ptr(lse), ptr(dws), ptr(dqkv), B, S, H, A,
            drop[0], drop[1], ptr(dbias), stream_ptr())
+
+
+# ---------------------------------------------------------------- LSTM (inference)
+def lstm_step(gx, gxi, whh, h_in, h_out, c, out, outi, out_dir_stride):
+    """one time step for ndir directions: gx bf16 [rows, ndir*4*Hp]; gxi / outi i32 [ndir, B]; whh bf16 [ndir, 4Hp, Hp];
+    h_in / h_out bf16 [ndir, B, Hp]; c f32 [ndir, B, Hp]; out bf16 [rows_out, ldo]"""
+    _chk(gx, BF16, "gx"); _chk(whh, BF16, "whh"); _chk(h_in, BF16, "h_in"); _chk(h_out, BF16, "h_out"); _chk(c, F32, "c")
+    _chk(out, BF16, "out"); _chk(gxi, I32, "gxi"); _chk(outi, I32, "outi")
+    ndir, B, Hp = h_in.shape
+    L.call("kbner_lstm_step", ptr(gx), gx.shape[-1], ptr(gxi), ptr(whh), ptr(h_in), ptr(h_out), ptr(c), ptr(out), out.shape[-1],
+           out_dir_stride, ptr(outi), B, Hp, ndir, stream_ptr())
 
 
 # ---------------------------------------------------------------- optimiser
