@@ -190,6 +190,30 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
   }
 }
 
+// same for wide rows (H > 1024: linear(2 * hidden -> T) behind the BiLSTM): the row is walked in 512-column chunks per tag
+// instead of being held in registers
+__global__ __launch_bounds__(256) void head_fwd_wide_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, float* __restrict__ out, int R,
+                                                            int H, int T) {
+  const int lane = threadIdx.x % 64;
+  const int wave = blockIdx.x * 4 + threadIdx.x / 64;
+  const int nwave = gridDim.x * 4;
+  for (int r = wave; r < R; r += nwave) {
+    for (int t = 0; t < T; ++t) {
+      float acc = 0.0f;
+      for (int h0 = lane * 8; h0 < H; h0 += 512) {
+        float xv[8];
+        unpack8(*reinterpret_cast<const uint4*>(x + (size_t)r * H + h0), xv);
+        const float4 a = *reinterpret_cast<const float4*>(w + (size_t)t * H + h0);
+        const float4 b = *reinterpret_cast<const float4*>(w + (size_t)t * H + h0 + 4);
+        acc += xv[0] * a.x + xv[1] * a.y + xv[2] * a.z + xv[3] * a.w + xv[4] * b.x + xv[5] * b.y + xv[6] * b.z + xv[7] * b.w;
+      }
+      acc = wave_sum(acc);
+      if (lane == 0) out[(size_t)r * T + t] = acc + bias[t];
+    }
+  }
+}
+
 static inline int rows_grid(int R) {
   int g = (R + 3) / 4;
   if (g > 2048) g = 2048;
@@ -214,9 +238,12 @@ int kbner_scatter_rows(const bf16_t* dout, const int* idx, bf16_t* dsrc, int R, 
 }
 
 int kbner_head_fwd(const bf16_t* x, const float* w, const float* bias, float* out, int R, int H, int T, void* stream) {
-  KBNER_CHECK_ARG(R >= 0 && H > 0 && H % 8 == 0 && H <= 1024 && T > 0 && T <= HEAD_MAXT);
+  KBNER_CHECK_ARG(R >= 0 && H > 0 && H % 8 == 0 && H <= 8192 && T > 0 && T <= HEAD_MAXT);
   if (R == 0) return 0;
-  hipLaunchKernelGGL(head_fwd_kernel, dim3(rows_grid(R)), dim3(256), 0, (hipStream_t)stream, x, w, bias, out, R, H, T);
+  if (H <= 1024)
+    hipLaunchKernelGGL(head_fwd_kernel, dim3(rows_grid(R)), dim3(256), 0, (hipStream_t)stream, x, w, bias, out, R, H, T);
+  else   // the BiLSTM tagger head of config 5: 2 x 1024 (padded) hidden columns
+    hipLaunchKernelGGL(head_fwd_wide_kernel, dim3(rows_grid(R)), dim3(256), 0, (hipStream_t)stream, x, w, bias, out, R, H, T);
   KBNER_LAUNCH_RET();
 }
 

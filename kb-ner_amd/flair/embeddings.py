@@ -370,6 +370,85 @@ class TransformerWordEmbeddings(TokenEmbeddings):
         return self.name
 
 
+class BertEmbeddings(TokenEmbeddings):
+    """BERT word embeddings (e.g. multilingual BERT in the ACE embedding pool), frozen, at inference.
+
+    Behavioural reference (restated): flair/embeddings.py BertEmbeddings (:2667-2905): every word token is word-piece tokenised
+    ON ITS OWN (:2733-2736), the pieces are framed [CLS] ... [SEP] and cut to max_sequence_length (:2737-2749), ids and mask are
+    zero-padded (:2755-2758), the model runs with absolute positions and token type 0, and a token's embedding is the
+    concatenation over `layers` (default the last four, '-1,-2,-3,-4') of the hidden state of its FIRST piece (:2861-2867;
+    index = 1 + pieces of all earlier tokens -- also for a token that received no piece, which therefore borrows the next
+    token's first piece).  `bert_model_or_path` must be a local directory (tokenizer files, config.json, weights)."""
+
+    def __init__(self, bert_model_or_path: str = "bert-base-uncased", layers: str = "-1,-2,-3,-4", pooling_operation: str = "first",
+                 use_scalar_mix: bool = False, fine_tune: bool = False, sentence_feat: bool = False, max_sequence_length=510):
+        super().__init__()
+        if not os.path.isdir(str(bert_model_or_path)):
+            raise FileNotFoundError("BertEmbeddings(%r): a local model directory is required (no network)" % (bert_model_or_path,))
+        if pooling_operation != "first" or use_scalar_mix or fine_tune or sentence_feat:
+            raise NotImplementedError("BertEmbeddings: only frozen, pooling_operation='first', no scalar mix is on the MI355X path")
+        from transformers import AutoTokenizer
+        self.tokenizer = AutoTokenizer.from_pretrained(str(bert_model_or_path))
+        config, sd = _load_hf_dir(str(bert_model_or_path))
+        self.model = _EncoderHandle(config, sd)
+        self.layer_indexes = [int(x) for x in str(layers).split(",")]
+        if any(li >= 0 or -li > config.num_hidden_layers + 1 for li in self.layer_indexes):
+            raise ValueError("layers must be negative indexes into the %d hidden states" % (config.num_hidden_layers + 1))
+        self.pooling_operation = pooling_operation
+        self.use_scalar_mix = False
+        self.name = str(bert_model_or_path)
+        self.fine_tune = False
+        self.static_embeddings = True
+        self.sentence_feat = False
+        self.max_sequence_length = int(max_sequence_length)
+        self._hidden = int(config.hidden_size)
+        self._cls = self.tokenizer.convert_tokens_to_ids(self.tokenizer.cls_token)
+        self._sep = self.tokenizer.convert_tokens_to_ids(self.tokenizer.sep_token)
+
+    @property
+    def embedding_length(self) -> int:
+        return len(self.layer_indexes) * self._hidden
+
+    def prepare_stack_batch(self, sentences):
+        """-> ids, mask [B, S0], first [B, n] (position of each token's first piece, -1 padding), lengths [B]"""
+        cache = self.__dict__.setdefault("_piece_cache", {})
+        rows, counts = [], []
+        for s in sentences:
+            pieces, cnt = [], []
+            for tok in s:
+                p = cache.get(tok.text)
+                if p is None:
+                    p = cache[tok.text] = self.tokenizer.convert_tokens_to_ids(self.tokenizer.tokenize(tok.text))
+                pieces.extend(p)
+                cnt.append(len(p))
+            rows.append(pieces)
+            counts.append(cnt)
+        longest = min(max(len(self.tokenizer.tokenize(s.to_tokenized_string())) for s in sentences), self.max_sequence_length)
+        S0 = longest + 2
+        B, n = len(sentences), max(len(s) for s in sentences)
+        ids = np.zeros((B, S0), np.int64)
+        am = np.zeros((B, S0), np.int64)
+        first = np.full((B, n), -1, np.int64)
+        for b, (pieces, cnt) in enumerate(zip(rows, counts)):
+            pieces = pieces[:longest]
+            row = [self._cls] + list(pieces) + [self._sep]
+            ids[b, :len(row)] = row
+            am[b, :len(row)] = 1
+            pos = 1
+            for k, c in enumerate(cnt):
+                if pos >= S0:
+                    raise IndexError("token %d of sentence %d lies beyond max_sequence_length (the reference fails here too)" % (k, b))
+                first[b, k] = pos
+                pos += c
+        return ids, am, first, np.asarray([len(s) for s in sentences], np.int64)
+
+    def _add_embeddings_internal(self, sentences):
+        return sentences   # features are produced on the device by the tagger's stack engine
+
+    def __str__(self):
+        return self.name
+
+
 class FlairEmbeddings(TokenEmbeddings):
     """Contextual string embeddings (Akbik et al. 2018) at inference: a character LM reads the whole tokenised sentence and
     the hidden state after each token's last character (forward LM) / before its first character read backwards (backward LM)

@@ -200,8 +200,27 @@ class SequenceTagger(flair.nn.Model):
     def _forward_stack(self, sentences):
         """emissions f32 [B, n, T]: every selected embedding writes its column block of X, then BiLSTM + linear"""
         from kbner import batch as kb
+        X, lengths, B, n = self._stack_input(sentences)
+        head = self.stack_head
+        feats = head.emissions(X, lengths, B, n)
+        # tags / remove_x bookkeeping for _calculate_loss and _obtain_labels (no encoder batch here: a 1-column dummy)
+        tags = np.zeros((B, n), np.int64)
+        for b, s in enumerate(sentences):
+            t = getattr(s, self.tag_type + "_tags", None)
+            if t is not None:
+                t = np.asarray(t)
+                tags[b, :min(n, len(t))] = t[:n]
+        hb = kb.assemble(np.zeros((B, 1), np.int64), np.ones((B, 1), np.int64), np.full((B, n), -1, np.int64), tags, lengths, self.x_idx)
+        self._last = (hb, kb.to_device(hb, flair.device))
+        self.mask = (torch.arange(n, device=feats.device)[None, :] < torch.from_numpy(lengths).to(feats.device)[:, None]).float()
+        return feats
+
+    def _stack_input(self, sentences):
+        """the concatenated feature matrix X bf16 [rows, Dp] (token-major rows b*n + t; block `slot` at columns
+        stack_head.cols[slot]), filled in place by the selected embeddings' device producers -> (X, lengths, B, n)"""
+        from kbner import batch as kb
         from kbner import ops
-        from flair.embeddings import FlairEmbeddings, TransformerWordEmbeddings
+        from flair.embeddings import BertEmbeddings, FlairEmbeddings, TransformerWordEmbeddings
         B = len(sentences)
         lengths = np.asarray([len(s) for s in sentences], np.int64)
         n = int(lengths.max())
@@ -221,23 +240,22 @@ class SequenceTagger(flair.nn.Model):
                 enc = self._encoder_for(emb)
                 hidden = enc.encoder_forward(db["ids"], db["pos_ids"], db["maskbias"], db["R"], db["S"])
                 ops.gather_rows_into(hidden, db["row_idx"], X, col, enc.cfg.hidden_size)
+            elif isinstance(emb, BertEmbeddings):
+                ids, am, first, lens = emb.prepare_stack_batch(sentences)
+                hb = kb.assemble(ids, am, first, np.zeros(first.shape, np.int64), lens, None, position_mode="absolute")
+                db = kb.to_device(hb, flair.device)
+                enc = self._encoder_for(emb)
+                enc.encoder_forward(db["ids"], db["pos_ids"], db["maskbias"], db["R"], db["S"])
+                states = enc.acts(db["R"], db["S"]).x      # hidden_states[0..L] (0 = embedding output)
+                Hh = enc.cfg.hidden_size
+                for j, li in enumerate(emb.layer_indexes):  # concatenated in the order `layers` lists them (:2843-2858)
+                    ops.gather_rows_into(states[len(states) + li], db["row_idx"], X, col + j * Hh, Hh)
             elif isinstance(emb, FlairEmbeddings):
                 cids, rows = emb.char_batch(sentences, n)
                 emb.engine(flair.device).run(cids, rows, X, col)
             else:
                 raise NotImplementedError("embedding class %s has no device producer" % type(emb).__name__)
-        feats = head.emissions(X, lengths, B, n)
-        # tags / remove_x bookkeeping for _calculate_loss and _obtain_labels (no encoder batch here: a 1-column dummy)
-        tags = np.zeros((B, n), np.int64)
-        for b, s in enumerate(sentences):
-            t = getattr(s, self.tag_type + "_tags", None)
-            if t is not None:
-                t = np.asarray(t)
-                tags[b, :min(n, len(t))] = t[:n]
-        hb = kb.assemble(np.zeros((B, 1), np.int64), np.ones((B, 1), np.int64), np.full((B, n), -1, np.int64), tags, lengths, self.x_idx)
-        self._last = (hb, kb.to_device(hb, flair.device))
-        self.mask = (torch.arange(n, device=feats.device)[None, :] < torch.from_numpy(lengths).to(feats.device)[:, None]).float()
-        return feats
+        return X, lengths, B, n
 
     def train(self, mode: bool = True):
         """model.train() (finetune_trainer.py:938) switches the HF dropout sites and the tagger's WordDropout on; eval() off"""

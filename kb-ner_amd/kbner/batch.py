@@ -14,7 +14,8 @@ def round_up(x, m):
     return (x + m - 1) // m * m
 
 
-def assemble(input_ids, attention_mask, first_idx, tags, lengths, x_idx, pad_id=1, s_multiple=64, first_row=None):
+def assemble(input_ids, attention_mask, first_idx, tags, lengths, x_idx, pad_id=1, s_multiple=64, first_row=None,
+             position_mode="roberta"):
     """input_ids/attention_mask int[R,S0] (R encoder rows; R == B unless sentences were split into sliding windows);
     first_idx int[B,n] (sub-token position of each word token's first piece inside its row, -1 = none/padding);
     first_row int[B,n] (encoder row of that piece; default: row b); tags int[B,n]; lengths int[B] (word tokens per
@@ -34,12 +35,17 @@ def assemble(input_ids, attention_mask, first_idx, tags, lengths, x_idx, pad_id=
     am = np.zeros((R, S), np.int64)
     ids[:, :S0] = input_ids
     am[:, :S0] = attention_mask
-    nz = (ids != pad_id).astype(np.int64)       # RoBERTa position ids from ids != pad (transformers modeling_roberta)
-    pos = np.cumsum(nz, axis=1) * nz + pad_id
+    if position_mode == "roberta":
+        nz = (ids != pad_id).astype(np.int64)   # RoBERTa position ids from ids != pad (transformers modeling_roberta)
+        pos = np.cumsum(nz, axis=1) * nz + pad_id
+    elif position_mode == "absolute":           # BERT: position = index in the row (transformers modeling_bert)
+        pos = np.tile(np.arange(S, dtype=np.int64)[None, :], (R, 1))
+    else:
+        raise ValueError("position_mode must be 'roberta' or 'absolute'")
     M = R * S
     Mp = round_up(M, 256)
     ids_f = np.zeros(Mp, np.int32)
-    pos_f = np.full(Mp, pad_id, np.int32)
+    pos_f = np.full(Mp, pad_id if position_mode == "roberta" else 0, np.int32)
     ids_f[:M] = ids.reshape(-1)
     pos_f[:M] = pos.reshape(-1)
     maskbias = ((1 - am) * -10000.0).astype(np.float32)

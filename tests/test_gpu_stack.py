@@ -38,20 +38,21 @@ def assets(tmp_path_factory, g13):
     return d
 
 
-@pytest.mark.parametrize("B,n,D,H", [(3, 7, 40, 24), (5, 19, 96, 100), (33, 12, 64, 32)])
+@pytest.mark.parametrize("B,n,D,H", [(3, 7, 40, 24), (5, 19, 96, 100), (33, 12, 64, 32), (4, 9, 128, 1000)])   # last: config 5's hidden_size 1000 -> 1024
 def test_bilstm_head_vs_oracle(B, n, D, H):
     """input GEMM + per-step recurrence kernel (both directions, ragged lengths, hidden padded to 32) + linear vs the numpy LSTM"""
     from kbner import stack as K
     from oracle import stack as ost
     rng = np.random.default_rng(B * 100 + n)
     T = 9
+    ws = 0.3 if H <= 100 else 1.5 / H ** 0.5     # keep the gates out of saturation at the real hidden size (torch's init is U(+-1/sqrt(H)))
     rnn = {}
     for sfx in ("", "_reverse"):
-        rnn["weight_ih_l0" + sfx] = rng.standard_normal((4 * H, D)).astype(np.float32) * 0.3
-        rnn["weight_hh_l0" + sfx] = rng.standard_normal((4 * H, H)).astype(np.float32) * 0.3
+        rnn["weight_ih_l0" + sfx] = rng.standard_normal((4 * H, D)).astype(np.float32) * ws
+        rnn["weight_hh_l0" + sfx] = rng.standard_normal((4 * H, H)).astype(np.float32) * ws
         rnn["bias_ih_l0" + sfx] = rng.standard_normal(4 * H).astype(np.float32) * 0.2
         rnn["bias_hh_l0" + sfx] = rng.standard_normal(4 * H).astype(np.float32) * 0.2
-    lw = rng.standard_normal((T, 2 * H)).astype(np.float32) * 0.3
+    lw = rng.standard_normal((T, 2 * H)).astype(np.float32) * ws
     lb = rng.standard_normal(T).astype(np.float32)
     lengths = rng.integers(1, n + 1, size=B)
     lengths[0] = n
@@ -131,6 +132,34 @@ def test_stack_tagger_vs_reference_golden(assets, g13):
     print("stack emissions worst rel L2", worst, "labels", tot, "flips", flips)
     assert worst < 2.1e-2, worst      # observed 6.9e-3 (114 labels, 0 flips)
     assert flips <= max(1, tot // 50), (flips, tot)
+
+
+def test_bert_embeddings_device_features_vs_reference_golden(tmp_path):
+    """G14 on the device: a BERT-shaped encoder (absolute positions, token-type row 0, LayerNorm eps 1e-12) on the HIP engine,
+    last four layers of every token's first piece written into X == the reference BertEmbeddings' features (bf16 tolerance)"""
+    import tiny_assets
+    from flair.data import Dictionary, Sentence
+    from flair.embeddings import BertEmbeddings, StackedEmbeddings
+    from flair.models import FastSequenceTagger
+    g = np.load(os.path.join(GOLD, "bert_embeddings.npz"))
+    mdir = tiny_assets.build_bert_dir(str(tmp_path / "bert-tiny"), seed=9)
+    emb = BertEmbeddings(bert_model_or_path=mdir, layers="-1,-2,-3,-4", pooling_operation="first")
+    td = Dictionary(add_unk=False)
+    for it in ("<unk>", "O", "S-PER", "<START>", "<STOP>"):
+        td.add_item(it)
+    tagger = FastSequenceTagger(hidden_size=32, embeddings=StackedEmbeddings([emb]), tag_dictionary=td, tag_type="ner", use_crf=True,
+                                use_rnn=True, dropout=0.0)
+    sents = [Sentence(str(t)) for t in g["texts"]]
+    X, lengths, B, n = tagger._stack_input(sents)
+    D = emb.embedding_length
+    mine = X[:B * n, :D].float().cpu().numpy().reshape(B, n, D)
+    ref = g["features"]
+    num = sum(float(((mine[b, :L] - ref[b, :L]) ** 2).sum()) for b, L in enumerate(lengths))
+    den = sum(float((ref[b, :L] ** 2).sum()) for b, L in enumerate(lengths))
+    rel = (num / den) ** 0.5
+    print("bert features rel L2", rel)
+    assert rel < 2e-2, rel
+    assert not mine[1, lengths[1]:].any() and not mine[2, lengths[2]:].any()      # padding rows stay zero
 
 
 def test_config5_yaml_route(assets, tmp_path):

@@ -123,3 +123,28 @@ def test_mirror_char_batch_and_internal_doc_index(g13, tmp_path):
     np.testing.assert_array_equal(ids, ids_doc)                       # the encoder reads the unchunked sentence
     assert first.shape == (len(sents), n) and lengths.tolist() == [len(s) for s in sents]
     assert all((first[b, :len(s)] >= 0).all() and (first[b, len(s):] < 0).all() for b, s in enumerate(sents))
+
+
+def test_bert_embeddings_index_matches_reference_features(tmp_path):
+    """G14: the mirror's BertEmbeddings.prepare_stack_batch feeds the encoder the reference's ids / mask, and gathering the
+    reference's hidden states (layers -1..-4) at the mirror's first-piece positions reproduces the reference's features --
+    including the token made of a control character, which gets no piece and borrows the next token's first piece"""
+    import tiny_assets
+    from flair.data import Sentence
+    from flair.embeddings import BertEmbeddings
+    g = np.load(os.path.join(GOLD, "bert_embeddings.npz"))
+    mdir = tiny_assets.build_bert_dir(str(tmp_path / "bert-tiny"), seed=9)
+    emb = BertEmbeddings(bert_model_or_path=mdir, layers="-1,-2,-3,-4", pooling_operation="first")
+    assert emb.embedding_length == int(g["embedding_length"])
+    sents = [Sentence(str(t)) for t in g["texts"]]
+    assert [len(s) for s in sents] == g["n_tokens"].tolist()
+    ids, am, first, lengths = emb.prepare_stack_batch(sents)
+    np.testing.assert_array_equal(ids, g["ids"])
+    np.testing.assert_array_equal(am, g["mask"])
+    hs = [g["hs%d" % i] for i in range(5)]
+    feats = g["features"]
+    mine = np.zeros_like(feats)
+    for b in range(len(sents)):
+        for k in range(int(lengths[b])):
+            mine[b, k] = np.concatenate([hs[len(hs) + li][b, first[b, k]] for li in emb.layer_indexes])
+    np.testing.assert_array_equal(mine, feats)

@@ -154,3 +154,45 @@ def build_wordpiece_tokenizer_dir(path, seed=0):
                                    model_max_length=512)
     fast.save_pretrained(path)
     return fast
+
+
+def build_bert_dir(path, hidden=128, layers=4, heads=2, inter=256, seed=0):
+    """tiny BERT-shaped model directory (word-piece tokenizer + vocab.txt, config.json with model_type bert, random-init weights
+    under HF BertModel names): what flair's BertEmbeddings (config 5's mBERT slot) loads"""
+    import torch
+    from safetensors.torch import save_file
+    tok = build_wordpiece_tokenizer_dir(path, seed=seed)
+    vocab = sorted(tok.get_vocab().items(), key=lambda kv: kv[1])
+    with open(os.path.join(path, "vocab.txt"), "w") as f:
+        f.write("\n".join(w for w, _ in vocab) + "\n")
+    V = len(vocab)
+    cfg = dict(model_type="bert", architectures=["BertModel"], vocab_size=V, hidden_size=hidden, num_hidden_layers=layers,
+               num_attention_heads=heads, intermediate_size=inter, max_position_embeddings=512, type_vocab_size=2, pad_token_id=1,
+               layer_norm_eps=1e-12, hidden_act="gelu", hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    with open(os.path.join(path, "config.json"), "w") as f:
+        json.dump(cfg, f)
+    g = torch.Generator().manual_seed(seed)
+
+    def w(*shape, std=0.05):
+        return torch.empty(*shape).normal_(0, std, generator=g)
+
+    sd = {"embeddings.word_embeddings.weight": w(V, hidden), "embeddings.position_embeddings.weight": w(512, hidden),
+          "embeddings.token_type_embeddings.weight": w(2, hidden), "embeddings.LayerNorm.weight": torch.ones(hidden) + w(hidden),
+          "embeddings.LayerNorm.bias": w(hidden)}
+    for i in range(layers):
+        p = "encoder.layer.%d." % i
+        for nm in ("query", "key", "value"):
+            sd[p + "attention.self.%s.weight" % nm] = w(hidden, hidden, std=0.08)
+            sd[p + "attention.self.%s.bias" % nm] = w(hidden)
+        sd[p + "attention.output.dense.weight"] = w(hidden, hidden, std=0.08)
+        sd[p + "attention.output.dense.bias"] = w(hidden)
+        sd[p + "attention.output.LayerNorm.weight"] = torch.ones(hidden) + w(hidden)
+        sd[p + "attention.output.LayerNorm.bias"] = w(hidden)
+        sd[p + "intermediate.dense.weight"] = w(inter, hidden, std=0.08)
+        sd[p + "intermediate.dense.bias"] = w(inter)
+        sd[p + "output.dense.weight"] = w(hidden, inter, std=0.08)
+        sd[p + "output.dense.bias"] = w(hidden)
+        sd[p + "output.LayerNorm.weight"] = torch.ones(hidden) + w(hidden)
+        sd[p + "output.LayerNorm.bias"] = w(hidden)
+    save_file(sd, os.path.join(path, "model.safetensors"), metadata={"format": "pt"})
+    return path
