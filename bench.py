@@ -104,6 +104,8 @@ def main():
     ap.add_argument("--blocking-allreduce", action="store_true", help="N>1: no overlap, everything exchanged after backward (A/B)")
     ap.add_argument("--compress-embedding-grad", action="store_true",
                     help="N>1: all-reduce the word-embedding gradient as bf16 when it is not row-sparse (deviation from the fp32 mean)")
+    ap.add_argument("--dynamic-tiles", action="store_true", help="N=1: run the GEMMs with the dynamic tile scheduler the N>1 runs use (A/B)")
+    ap.add_argument("--static-tiles", action="store_true", help="N>1: keep the static tile walk (A/B)")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (small micro-batches, dropout)")
     ap.add_argument("--dropout", type=float, default=0.0,
                     help="train with this dropout probability at the encoder's three HF sites + WordDropout (default 0: "
@@ -157,6 +159,8 @@ def main():
     # is enqueued; only embeddings + vectors + head are exchanged after backward.  --blocking-allreduce restores round 1's
     # single 2.24 GB all-reduce for A/B.
     reducer = None
+    if world > 1 or args.dynamic_tiles:
+        tg.dynamic_tiles = not args.static_tiles
     if world > 1:
         from kbner import dp
         a = tg.arena

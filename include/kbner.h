@@ -135,6 +135,12 @@ typedef struct kbner_gemm_problem {
   uint32_t drop_seed, drop_thresh; /* KBNER_EPI_DROP */
 } kbner_gemm_problem;
 int kbner_gemm_bf16_grouped(int layout, int nprob, const kbner_gemm_problem* probs, void* stream);
+/* The same launch with DYNAMIC tile scheduling: workgroups draw their tiles from 8 per-XCD counters (`sched`, device ints the
+ * caller zeroed on this stream since their last use) instead of a static walk, so a workgroup the dispatcher places late -- its
+ * CU was running an RCCL collective of the overlapped gradient exchange -- takes fewer tiles instead of doubling the launch time.
+ * Bit-identical outputs (each output tile is computed the same way whoever computes it).  New capability: the reference has no
+ * data-parallel path (flair/trainers/finetune_trainer.py:466,699-700). */
+int kbner_gemm_bf16_grouped_dyn(int layout, int nprob, const kbner_gemm_problem* probs, int* sched, void* stream);
 /* Split-K for small micro-batches (a few dozen output tiles, long K): the K range is cut into `splits` problems of ONE grouped
  * launch, each writing an fp32 slab ws[s] (f32[M,N], KBNER_EPI_STORE32); this folds them:
  * C = bf16(dropout(sum_s ws[s] + bias) + addend).  bias / addend nullable, drop_thresh 0 = no dropout. */

@@ -48,6 +48,7 @@ struct GroupArgs {
   int total_tiles;
   int ncu;
   int pad_;
+  int* sched;  // dynamic tile scheduling (DYN kernels): 8 per-XCD counters, zeroed by the caller before the launch
   int tile_begin[G2_MAXP];  // compact copy of p[i].tile_begin: one s_load_dwordx16 picks the problem
   GemmProblem p[G2_MAXP];
 };
@@ -381,19 +382,47 @@ __device__ unsigned long long g2_trace[256 * 32 * 4];
 #define G2_T(slot)
 #endif
 
-template <bool A_KS, bool B_KS>
+// Dynamic tile scheduling (DYN = true; data-parallel training, where RCCL's kernels take CUs away while a bucket is in flight):
+// a workgroup DRAWS its tiles from per-XCD counters instead of walking id, id + grid, ...  A workgroup that the dispatcher could
+// only place late (its CU was busy with a collective) then simply finds fewer tiles left; with the static walk it would run its
+// full share after everybody else had finished and double the launch time.  XCD locality is kept: the workgroup on XCD x draws
+// from x's share {x, x+8, ...} first (same tile->XCD map as the static walk) and steals from the other shares when x's is empty.
+// Returns an id >= total when nothing is left.  Called by thread 0 only; the id travels to the other waves through LDS.
+static __device__ __forceinline__ int draw_tile(int* sched, int xcd, int total) {
+#pragma unroll 1
+  for (int s = 0; s < 8; ++s) {
+    const int y = (xcd + s) & 7;
+    const int share = (total - y + 7) >> 3;
+    if (share <= 0) continue;
+    const int n = __hip_atomic_fetch_add(sched + y, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (n < share) return n * 8 + y;
+  }
+  return total;
+}
+
+template <bool A_KS, bool B_KS, bool DYN = false>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GroupArgs ga) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid >> 2, wn = wid & 3;
+  // DYN: the drawn tile id is handed to the other waves through the last word of wave 0's epilogue scratch -- written by
+  // thread 0 only between its own epilogue and the next tile's first barrier, read by everybody after that barrier
+  volatile int* s_next = reinterpret_cast<volatile int*>(smem + 2 * STAGE2_BYTES + 4092);
 
   // Persistent: this workgroup walks tiles id, id + gridDim.x, ... (grid = min(tiles, #CUs)).  The first K tile
   // of the NEXT output tile is DMA'd during the last K iteration of the current one, so the epilogue's loads and
   // stores run under that flight and the next main loop starts without a cold prologue.
   const int total = ga.total_tiles;
   int id = blockIdx.x;
+  if (DYN) {
+    if (tid == 0) *s_next = draw_tile(ga.sched, blockIdx.x & 7, total);
+    __syncthreads();
+    id = __builtin_amdgcn_readfirstlane(*s_next);
+    __syncthreads();
+    if (id >= total) return;   // a late workgroup: every tile has been taken
+  }
   int it = 0;    // running K-iteration counter: LDS stage parity
   int pend = 0;  // epilogue stores issued after the DMA that is in flight at a tile boundary
   {
@@ -422,8 +451,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GroupArgs ga) {
     lda = gm.lda;
     ldb = gm.ldb;
   }
-  const int id_next = id + (int)gridDim.x;
-  const bool has_next = id_next < total;
+  int id_next = id + (int)gridDim.x;
+  bool has_next = id_next < total;
+  // DYN: the next tile is drawn one tile ahead; thread 0 waits for its atomic here, before the tile's first barrier, and all
+  // waves read the id after that barrier.  (Measured on MI355X, whole training step: static walk 880 sentences/s, this 863;
+  // issuing the atomic here but consuming it two K steps later -- to hide its round trip under the DMA wait -- ran at 739: a
+  // compiler-visible VMEM result in flight across the K loop makes hipcc drain vmcnt(0) around the hand-counted waits.)
+  if (DYN && tid == 0) *s_next = draw_tile(ga.sched, blockIdx.x & 7, total);
 
   f4v acc[8][4];
 #pragma unroll
@@ -446,6 +480,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GroupArgs ga) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    if (DYN && t == 0) {
+      if (nt == 1) __builtin_amdgcn_s_barrier();   // (K = 64: the draw was written after this tile's only barrier was passed)
+      id_next = __builtin_amdgcn_readfirstlane(*s_next);
+      has_next = id_next < total;
+    }
     unsigned char* cur = smem + (it & 1) * STAGE2_BYTES;
     unsigned char* nxt = smem + ((it + 1) & 1) * STAGE2_BYTES;
     if (t + 1 < nt) {
@@ -523,17 +562,17 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GroupArgs ga) {
   }  // persistent tile loop
 }
 
-template <bool A_KS, bool B_KS>
+template <bool A_KS, bool B_KS, bool DYN>
 static int launch256(const GroupArgs& ga, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<A_KS, B_KS>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<A_KS, B_KS, DYN>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES);
     if (e != hipSuccess) return -(int)e;
     attr_set = true;
   }
   const int grid = ga.total_tiles < ga.ncu ? ga.total_tiles : ga.ncu;
-  hipLaunchKernelGGL((gemm256_kernel<A_KS, B_KS>), dim3(grid), dim3(512), G2_LDS_BYTES, stream, ga);
+  hipLaunchKernelGGL((gemm256_kernel<A_KS, B_KS, DYN>), dim3(grid), dim3(512), G2_LDS_BYTES, stream, ga);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }
@@ -578,7 +617,22 @@ extern "C" {
 
 // Grouped GEMM: nprob (1..16) problems of the SAME layout in one launch.
 // Constraints per problem: M % 256 == 0, N % 256 == 0, K % 64 == 0, lda/ldb % 8 == 0.
+static int gemm_grouped_impl(int layout, int nprob, const kbner_gemm_problem* probs, int* sched, void* stream);
+
 int kbner_gemm_bf16_grouped(int layout, int nprob, const kbner_gemm_problem* probs, void* stream) {
+  return gemm_grouped_impl(layout, nprob, probs, nullptr, stream);
+}
+
+// Same launch with DYNAMIC tile scheduling (see draw_tile): sched = 8 device ints the caller zeroed (on this stream) since their
+// last use.  Meant for steps whose GEMMs share the GPU with RCCL collectives; identical results, static tile->XCD affinity kept.
+int kbner_gemm_bf16_grouped_dyn(int layout, int nprob, const kbner_gemm_problem* probs, int* sched, void* stream) {
+  KBNER_CHECK_ARG(sched != nullptr);
+  return gemm_grouped_impl(layout, nprob, probs, sched, stream);
+}
+
+}  // extern "C"
+
+static int gemm_grouped_impl(int layout, int nprob, const kbner_gemm_problem* probs, int* sched, void* stream) {
   KBNER_CHECK_ARG(layout >= 0 && layout <= 2 && nprob >= 1 && nprob <= G2_MAXP && probs != nullptr);
   GroupArgs ga;
   ga.nprob = nprob;
@@ -615,12 +669,18 @@ int kbner_gemm_bf16_grouped(int layout, int nprob, const kbner_gemm_problem* pro
   ga.total_tiles = tiles;
   ga.ncu = device_cu_count();
   ga.pad_ = 0;
+  ga.sched = sched;
   hipStream_t st = (hipStream_t)stream;
+  if (sched != nullptr) {
+    switch (layout) {
+      case 0: return launch256<false, false, true>(ga, st);
+      case 1: return launch256<false, true, true>(ga, st);
+      default: return launch256<true, true, true>(ga, st);
+    }
+  }
   switch (layout) {
-    case 0: return launch256<false, false>(ga, st);
-    case 1: return launch256<false, true>(ga, st);
-    default: return launch256<true, true>(ga, st);
+    case 0: return launch256<false, false, false>(ga, st);
+    case 1: return launch256<false, true, false>(ga, st);
+    default: return launch256<true, true, false>(ga, st);
   }
 }
-
-}  // extern "C"

@@ -178,6 +178,8 @@ class ModelFinetuner:
         V, Hh = arena.shapes["emb.word"]
         reducer = dp.GradReducer(arena.g, emb_range=(emb_lo, emb_lo + V * Hh), emb_width=Hh,
                                  compress_embedding=bool(kwargs.get("compress_embedding_grad", False))) if W > 1 else None
+        if W > 1 and overlap_allreduce:
+            self.model.engine.dynamic_tiles = True   # GEMM tiles drawn dynamically: robust to CUs taken by the overlapped collectives
         log_line(log)
         log.info('Model: "XLM-R encoder + linear + CRF on kbner HIP engine", tags=%d', len(self.model.tag_dictionary))
         log.info('Parameters: learning_rate "%s", mini_batch_size "%s", accumulate "%s", max_epochs "%s", world_size "%s", '

@@ -244,6 +244,10 @@ class Tagger:
         self.training = False
         self.word_dropout = 0.0
         self.seed_dropout(20220711)
+        # data-parallel runs: the persistent GEMM draws its tiles dynamically (kbner_gemm_bf16_grouped_dyn) so that CUs taken
+        # by an overlapped RCCL collective cost their share of the launch, not a second pass; off for a single process
+        self.dynamic_tiles = False
+        self._sched_ring = None
 
     def seed_dropout(self, seed):
         import numpy as np
@@ -474,7 +478,16 @@ class Tagger:
         weights: optional f32[B] per-sentence weights replacing the 1/B of the mean (the trainer uses it to run the
         micro-batches of one gradient-accumulation group as ONE batch with weights 1/(accumulate * |micro-batch|))."""
         with L_.stream_scope():
-            return self._forward_loss(batch, loss_scale, backward, weights, grad_ready)
+            if not self.dynamic_tiles:
+                return self._forward_loss(batch, loss_scale, backward, weights, grad_ready)
+            if self._sched_ring is None:
+                self._sched_ring = torch.zeros((512, 8), dtype=I32, device=self.device)
+            self._sched_ring.zero_()     # one memset per micro-batch covers its ~200 GEMM launches
+            ops.sched_ring_reset(self._sched_ring)
+            try:
+                return self._forward_loss(batch, loss_scale, backward, weights, grad_ready)
+            finally:
+                ops.sched_ring_reset(None)
 
     def _forward_loss(self, batch, loss_scale, backward, weights, grad_ready=None):
         B, S = batch["B"], batch["S"]

@@ -40,6 +40,7 @@ SIGNATURES = {
     "kbner_gemm_bf16": (c_int, [c_int, P, c_int, P, c_int, c_int, c_int, c_int, P, c_int, P, c_int, P, P, c_int, P, c_int,
                                 P, c_int, c_int, c_int, c_float, U32, U32, P]),
     "kbner_gemm_bf16_grouped": (c_int, [c_int, c_int, P, P]),
+    "kbner_gemm_bf16_grouped_dyn": (c_int, [c_int, c_int, P, P, P]),
     "kbner_splitk_finish": (c_int, [P, c_int, P, P, c_int, P, c_int, c_int, c_int, U32, U32, P]),
     "kbner_attn_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, U32, U32, P]),
     "kbner_attn_bwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, U32, U32, P, P]),

@@ -196,6 +196,16 @@ def uses_256(M, N, occupancy=False):
     ok = M % 256 == 0 and N % 256 == 0 and not FORCE_128
     return ok and (not occupancy or (M // 256) * (N // 256) >= MIN_TILES_256)
 GEMM_HOOK = None  # bench.py sets this to a list to time every GEMM launch with HIP events on the launch stream
+# Dynamic tile scheduling of the 256x256 kernel (data-parallel steps, see include/kbner.h): a ring of 8-int counter slots,
+# int32 [slots, 8], zeroed by its owner (the engine, once per micro-batch); every grouped launch takes the next slot.
+SCHED_RING = None
+_sched_pos = 0
+
+
+def sched_ring_reset(ring):
+    """make `ring` (or None) the current scheduler ring; the caller has zeroed it on the current stream"""
+    global SCHED_RING, _sched_pos
+    SCHED_RING, _sched_pos = ring, 0
 
 
 def _addr(t):
@@ -224,7 +234,14 @@ def gemm_grouped(layout, problems):
     if hook is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    L.call("kbner_gemm_bf16_grouped", layout, n, ctypes.cast(arr, ctypes.c_void_p), stream_ptr())
+    global _sched_pos
+    ring = SCHED_RING
+    if ring is not None and _sched_pos < ring.shape[0]:
+        slot = c_void_p(ring.data_ptr() + 32 * _sched_pos)
+        _sched_pos += 1
+        L.call("kbner_gemm_bf16_grouped_dyn", layout, n, ctypes.cast(arr, ctypes.c_void_p), slot, stream_ptr())
+    else:
+        L.call("kbner_gemm_bf16_grouped", layout, n, ctypes.cast(arr, ctypes.c_void_p), stream_ptr())
     if hook is not None:
         ev1.record()
         hook.append((ev0, ev1, sum(2.0 * p.M * p.N * p.K for p in problems), layout))

@@ -340,3 +340,53 @@ def test_optimizer_steps_vs_oracle_trainer(st):
 def test_gemm_splitk(st, layout, M, N, K, splits, drop_p):
     """small-micro-batch path: K cut into fp32 slabs by one grouped launch (KBNER_EPI_STORE32) + kbner_splitk_finish"""
     assert st.check_gemm_splitk(layout, M, N, K, splits, drop_p=drop_p) < 6e-3
+
+
+
+def test_gemm_dynamic_tile_scheduling_is_bit_identical(st):
+    """kbner_gemm_bf16_grouped_dyn (tiles drawn from per-XCD counters: the data-parallel mode) == the static walk, bit for bit,
+    for every layout and a grouped launch; and a whole training micro-batch gives the same loss and gradients"""
+    import torch
+    from kbner import ops
+    from kbner.lib import GEMM_NN, GEMM_NT, GEMM_TN, EPI_RMW32
+    torch.manual_seed(0)
+    for layout, (M, N, K) in ((GEMM_NT, (1024, 768, 256)), (GEMM_NN, (768, 512, 1024)), (GEMM_TN, (512, 768, 2048)), (GEMM_NT, (256, 256, 64))):
+        A = (torch.randn(M, K, device="cuda") * 0.5).to(torch.bfloat16)
+        B = (torch.randn(N, K, device="cuda") * 0.5).to(torch.bfloat16)
+        if layout == GEMM_TN:
+            A = A.t().contiguous()
+        if layout != GEMM_NT:
+            B = B.t().contiguous()
+        outs = []
+        for dyn in (False, True):
+            ring = torch.zeros((4, 8), dtype=torch.int32, device="cuda")
+            ops.sched_ring_reset(ring if dyn else None)
+            try:
+                if layout == GEMM_TN:
+                    C32 = torch.zeros(M, N, device="cuda")
+                    ops.gemm(layout, A, B, M, N, K, C32=C32, epi=EPI_RMW32)
+                    outs.append(C32)
+                else:
+                    C = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+                    ops.gemm(layout, A, B, M, N, K, C=C)
+                    outs.append(C)
+            finally:
+                ops.sched_ring_reset(None)
+            if dyn:   # every tile was drawn exactly once: the 8 counters hold at least the tile count (overshoot = the draws that found nothing)
+                assert int(ring[0].sum()) >= (M // 256) * (N // 256)
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0], outs[1]), (layout, M, N, K)
+    cfg, tg, b, _ = st.tiny_setup(B=4, S=128, L=2, H=256, A=4, F_=512)
+    from kbner import batch as kb
+    bd = kb.to_device(b, "cuda")
+    res = []
+    for dyn in (False, True):
+        tg.arena.g.zero_()
+        tg.dynamic_tiles = dyn
+        loss = tg.forward_loss(bd, backward=True)
+        torch.cuda.synchronize()
+        res.append((float(loss), tg.arena.g.clone()))
+    tg.dynamic_tiles = False
+    assert res[0][0] == res[1][0]
+    rel = float((res[0][1] - res[1][1]).norm() / res[0][1].norm())
+    assert rel < 1e-6, rel      # identical tiles; only the fp32 atomics of bias / embedding gradients may reorder
