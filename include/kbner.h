@@ -50,6 +50,13 @@ int kbner_crf_nll_bwd(const float* emit, const float* trans, const int* tags, co
  * argument may be all zeros).  marg f32[B,n,T], rows at or past lens[b] are zero-filled. */
 int kbner_crf_posterior(const float* emit, const float* trans, const int* lens, const float* alpha, const float* logz, int B,
                         int n, int T, int start, int stop, float* marg, void* stream);
+/* n-best Viterbi (SequenceTagger._viterbi_decode_nbest, sequence_tagger_model.py:1660-1818; called on KD teachers at
+ * finetune_trainer.py:1600, distillation_trainer.py:819): decode i32 [B, n, nbest] tag indices and path_score f32 [B, nbest]
+ * (softmax over the nbest end scores).  The NCRF++ decoder's conventions are kept as they are: trans indexed [from, to],
+ * padded positions decode to 0 except the last column.  ws: kbner_crf_viterbi_nbest_ws_bytes(B, n, T, nbest) bytes. */
+size_t kbner_crf_viterbi_nbest_ws_bytes(int B, int n, int T, int nbest);
+int kbner_crf_viterbi_nbest(const float* emit, const float* trans, const int* lens, int B, int n, int T, int start, int stop,
+                            int nbest, void* ws, int* decode, float* path_score, void* stream);
 
 /* ---------------- row moves: pooling, compaction, emission head ---------------- */
 /* first-subtoken pooling + assign_batch_features (flair/embeddings.py:3288-3345,108-124) and the remove_x

@@ -434,6 +434,14 @@ class SequenceTagger(flair.nn.Model):
             out.append([Label(p, c) for p, c in zip(path, cf)])
         return out, []
 
+    def _viterbi_decode_nbest(self, feats, mask, nbest):
+        """(path_score [B, nbest], decode_idx [B, n, nbest]) -- the NCRF++ n-best decoder of sequence_tagger_model.py:1660, as the
+        KD trainers call it on a teacher (finetune_trainer.py:1600): HIP kernel, conventions and quirks of the reference kept"""
+        from kbner import ops
+        lens = mask.to(feats.device).long().sum(1).to(torch.int32).contiguous()
+        score, dec = ops.crf_viterbi_nbest(feats.contiguous().float(), self.transitions, lens, self.start_idx, self.stop_idx, int(nbest))
+        return score, dec.long()
+
     def _gold_x_token_ids(self, sentence):
         """1-based ids of the tokens whose gold tag is exactly 'S-X' (:2663; from the loader's tag-id row when present)"""
         row = getattr(sentence, self.tag_type + "_tags", None)

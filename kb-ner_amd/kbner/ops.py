@@ -69,6 +69,18 @@ def crf_nll_bwd(emit, trans, tags, lens, alpha, logz, dloss, start, stop, dtrans
     return demit
 
 
+def crf_viterbi_nbest(emit, trans, lens, start, stop, nbest):
+    """emit f32[B,n,T] -> (path_score f32[B,nbest], decode i32[B,n,nbest]) -- _viterbi_decode_nbest"""
+    _chk(emit, F32, "emit"); _chk(trans, F32, "trans"); _chk(lens, I32, "lens")
+    B, n, T = emit.shape
+    ws = torch.empty(max(1, L.load().kbner_crf_viterbi_nbest_ws_bytes(B, n, T, nbest) // 2), dtype=torch.int16, device=emit.device)
+    decode = torch.zeros((B, n, nbest), dtype=I32, device=emit.device)
+    score = torch.zeros((B, nbest), dtype=F32, device=emit.device)
+    L.call("kbner_crf_viterbi_nbest", ptr(emit), ptr(trans), ptr(lens), B, n, T, start, stop, nbest, ptr(ws), ptr(decode), ptr(score),
+           stream_ptr())
+    return score, decode
+
+
 def crf_posterior(emit, trans, lens, start, stop):
     """token marginals f32[B,n,T] (zero rows past lens) -- _obtain_labels' predict_posterior branch"""
     _chk(emit, F32, "emit"); _chk(trans, F32, "trans"); _chk(lens, I32, "lens")

@@ -390,3 +390,37 @@ def test_gemm_dynamic_tile_scheduling_is_bit_identical(st):
     assert res[0][0] == res[1][0]
     rel = float((res[0][1] - res[1][1]).norm() / res[0][1].norm())
     assert rel < 1e-6, rel      # identical tiles; only the fp32 atomics of bias / embedding gradients may reorder
+
+
+
+def test_viterbi_nbest_vs_reference_golden(golden_dir):
+    """kbner_crf_viterbi_nbest against tests/golden/viterbi_nbest.npz (captured from the reference's _viterbi_decode_nbest on
+    tie-free inputs, ragged lengths incl. sentences shorter than the batch maximum): tag indices bit-exact, path scores 1e-6"""
+    import torch
+    from kbner import ops
+    g = np.load(os.path.join(golden_dir, "viterbi_nbest.npz"))
+    start, stop = int(g["start"]), int(g["stop"])
+    for c in range(int(g["n_cases"])):
+        feats, trans, lengths, nbest = g["c%d_feats" % c], g["c%d_trans" % c], g["c%d_lengths" % c], int(g["c%d_nbest" % c])
+        score, dec = ops.crf_viterbi_nbest(torch.from_numpy(feats).cuda(), torch.from_numpy(trans).cuda(),
+                                           torch.from_numpy(lengths.astype(np.int32)).cuda(), start, stop, nbest)
+        np.testing.assert_array_equal(dec.cpu().numpy(), g["c%d_decode" % c], err_msg="case %d" % c)
+        np.testing.assert_allclose(score.cpu().numpy(), g["c%d_path_score" % c], rtol=2e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("B,n,nbest", [(32, 40, 10), (7, 3, 16), (64, 1, 2)])
+def test_viterbi_nbest_vs_oracle(B, n, nbest):
+    import torch
+    from kbner import ops
+    from oracle import crf as ocrf
+    rng = np.random.default_rng(B + n)
+    T, start, stop = 29, 27, 28
+    feats = (rng.standard_normal((B, n, T)) * 2).astype(np.float32)
+    trans = rng.standard_normal((T, T)).astype(np.float32)
+    lengths = rng.integers(1, n + 1, size=B)
+    lengths[0] = n
+    score, dec = ops.crf_viterbi_nbest(torch.from_numpy(feats).cuda(), torch.from_numpy(trans).cuda(),
+                                       torch.from_numpy(lengths.astype(np.int32)).cuda(), start, stop, nbest)
+    ps, want = ocrf.viterbi_nbest(feats, lengths, trans, start, stop, nbest)
+    np.testing.assert_array_equal(dec.cpu().numpy(), want)
+    np.testing.assert_allclose(score.cpu().numpy(), ps, rtol=2e-5, atol=1e-7)
