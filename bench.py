@@ -106,6 +106,7 @@ def main():
                     help="N>1: all-reduce the word-embedding gradient as bf16 when it is not row-sparse (deviation from the fp32 mean)")
     ap.add_argument("--dynamic-tiles", action="store_true", help="N=1: run the GEMMs with the dynamic tile scheduler the N>1 runs use (A/B)")
     ap.add_argument("--static-tiles", action="store_true", help="N>1: keep the static tile walk (A/B)")
+    ap.add_argument("--gemm-shapes", action="store_true", help="print a per-shape GEMM timing table to stderr")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (small micro-batches, dropout)")
     ap.add_argument("--dropout", type=float, default=0.0,
                     help="train with this dropout probability at the encoder's three HF sites + WordDropout (default 0: "
@@ -224,12 +225,22 @@ def main():
         tot_fl = sum(r[2] for r in recs)
         tot_ms = sum(r[0].elapsed_time(r[1]) for r in recs)
         by = {}
-        for s_ev, e_ev, fl, layout in recs:
+        for s_ev, e_ev, fl, layout, _shape in recs:
             d = by.setdefault(layout, [0.0, 0.0, 0])
             d[0] += fl
             d[1] += s_ev.elapsed_time(e_ev)
             d[2] += 1
         ach = tot_fl / (tot_ms * 1e-3) / 1e12
+        if args.gemm_shapes and rank == 0:   # per-shape breakdown of the same launches (stderr; not part of the JSON contract)
+            sh = {}
+            for s_ev, e_ev, fl, layout, shape in recs:
+                d = sh.setdefault((layout,) + shape, [0.0, 0.0, 0])
+                d[0] += fl
+                d[1] += s_ev.elapsed_time(e_ev)
+                d[2] += 1
+            for k, v in sorted(sh.items(), key=lambda kv: -kv[1][1]):
+                print("gemm layout %d nprob %2d M %6d N %5d K %6d epi %3d : %3d launches %8.3f ms %7.1f TFLOP/s"
+                      % (k + (v[2], v[1], v[0] / (v[1] * 1e-3) / 1e12)), file=sys.stderr)
         # HBM-side bytes per launch of the same kernel family, from the committed rocprofv3 PMC passes of THIS command at its
         # default configuration (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE; tools/pmc_traffic.py); None otherwise
         traffic, traffic_src = None, None

@@ -48,15 +48,22 @@ def format_sentence(tokens: Sequence[Tuple[str, str, str, str]], contexts: Seque
     return lines
 
 
-def write_file(path: str, sentences: Iterable[dict], count: Callable[[str], int], length_limit: int = 510) -> int:
+def write_file(path: str, sentences: Iterable[dict], count: Callable[[str], int], length_limit: int = 510,
+               max_lines: Optional[int] = None) -> int:
     """sentences: dicts with 'tokens' [(word, pos, upos, ner)], 'contexts' [str, ...] in rank order, optional 'id'.
-    `count(text)` = number of XLM-R sub-tokens of a space-joined string (tokenizer.tokenize).  Returns #sentences."""
+    `count(text)` = number of XLM-R sub-tokens of a space-joined string (tokenizer.tokenize).  max_lines: sentences with more
+    lines (word tokens incl. <EOS> and context) are dropped, as kb/context_process.py's write_file(max_len) does -- it passes
+    length_limit for train files and 999 for dev / test (:995-1000).  Returns #sentences written.
+    The sentence's own sub-token count is taken on its lower-cased text (`keyword.lower()` for wiki retrieval, :296-306)."""
     n = 0
     with open(path, "w", encoding="utf-8") as f:
         for s in sentences:
             text = " ".join(t[0] for t in s["tokens"])
             used = select_contexts(count(text), s.get("contexts", ()), count, length_limit)
-            f.write("\n".join(format_sentence(s["tokens"], used, s.get("id"))) + "\n\n")
+            lines = format_sentence(s["tokens"], used, s.get("id"))
+            if max_lines is not None and len([ln for ln in lines if not ln.startswith("# id")]) > max_lines:
+                continue
+            f.write("\n".join(lines) + "\n\n")
             n += 1
     return n
 

@@ -256,7 +256,8 @@ def gemm_grouped(layout, problems):
         L.call("kbner_gemm_bf16_grouped", layout, n, ctypes.cast(arr, ctypes.c_void_p), stream_ptr())
     if hook is not None:
         ev1.record()
-        hook.append((ev0, ev1, sum(2.0 * p.M * p.N * p.K for p in problems), layout))
+        hook.append((ev0, ev1, sum(2.0 * p.M * p.N * p.K for p in problems), layout,
+                     (len(problems), problems[0].M, problems[0].N, problems[0].K, problems[0].epi)))
 
 
 def gemm(layout, A, B, M, N, K, C=None, C32=None, bias=None, addend=None, aux=None, out2=None, epi=0, splitk=1, alpha=1.0,
@@ -285,7 +286,7 @@ def gemm(layout, A, B, M, N, K, C=None, C32=None, bias=None, addend=None, aux=No
            epi, splitk, alpha, drop[0], drop[1], stream_ptr())
     if hook is not None:
         ev1.record()
-        hook.append((ev0, ev1, 2.0 * M * N * K, layout))
+        hook.append((ev0, ev1, 2.0 * M * N * K, layout, (1, M, N, K, epi)))
 
 
 def gemm_splitk(layout, A, B, M, N, K, splits, ws, C, bias=None, addend=None, drop=NO_DROP):

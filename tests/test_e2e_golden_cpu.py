@@ -170,3 +170,27 @@ def test_speed_test_order_writes_nothing_and_scores_nothing(e2e, tmp_path):
     res, loss = tagger.evaluate(batches, out_path=tmp_path / "x.tsv", speed_test=True)
     assert loss == 0.0 and res.main_score == 0.0
     assert open(tmp_path / "x.tsv").read() == ""
+
+
+def test_context_file_writer_matches_kb_context_process(tmp_path):
+    """f-2: kbner.context_format.write_file against files produced by the reference's own kb/context_process.py
+    `process_google` + `write_file` (tests/golden/context_format.json, oracle/gen_golden_context.py): the same retrieval
+    dictionary and sub-token budget give byte-identical files -- contexts that do not fit are skipped while later shorter ones
+    are taken, non-printable characters are dropped, a sentence without a hit is written bare, the scan stops below 10 free
+    sub-tokens, and a train file (max_len = length_limit) drops sentences with more lines than the limit"""
+    import tiny_assets
+    from kbner import context_format as cf
+    g = json.load(open(os.path.join(GOLD, "context_format.json"), encoding="utf-8"))
+    tok = tiny_assets.build_tokenizer_dir(str(tmp_path / "tok"))
+    count = lambda text: len(tok.tokenize(text))   # noqa: E731
+    sents = []
+    for s in g["sentences"]:
+        toks = [tuple(line.split()) for line in s]
+        key = " ".join(t[0] for t in toks).lower()
+        sents.append({"tokens": toks, "contexts": g["google_dict"].get(key, [])})
+    for run in g["runs"]:
+        path = tmp_path / ("out_%d_%d.txt" % (run["length_limit"], run["max_len"]))
+        cf.write_file(str(path), sents, count, length_limit=run["length_limit"], max_lines=run["max_len"])
+        assert open(path, encoding="utf-8").read() == run["file"], (run["length_limit"], run["max_len"])
+        st = cf.validate_file(str(path), count, length_limit=run["length_limit"], eos_text="</s>")
+        assert st["over_budget"] == 0
