@@ -148,8 +148,11 @@ class TransformerWordEmbeddings(TokenEmbeddings):
                                     "hold the tokenizer files, config.json and model.safetensors / pytorch_model.bin" % model)
         if [int(x) for x in str(layers).split(",")] != [-1] or pooling_operation != "first" or use_scalar_mix:
             raise NotImplementedError("only layers='-1', pooling_operation='first' (the KB-NER configs) are on the MI355X path")
-        if document_extraction or v2_doc or ext_doc or sentence_feat:
-            raise NotImplementedError("document-level variants are outside the hot path (SURVEY.md §8f-3)")
+        if document_extraction or ext_doc or sentence_feat:
+            raise NotImplementedError("document_extraction / ext_doc / sentence_feat are outside the hot path (SURVEY.md §8f-3); "
+                                      "v2_doc (document windows) is supported")
+        self.v2_doc = bool(v2_doc)        # also settable later: train.py --v2doc does `embedding.v2_doc = True` (:223-224)
+        self.doc_batch_size = doc_batch_size
         from transformers import AutoTokenizer
         self.tokenizer = AutoTokenizer.from_pretrained(model, **kwargs)
         config, sd = _load_hf_dir(model)
@@ -311,10 +314,78 @@ class TransformerWordEmbeddings(TokenEmbeddings):
 
         return windows, where
 
+    # ------------------------------------------------------------------ document windows (v2_doc)
+    def _doc_pieces(self, sentence):
+        """(sub-token ids, per-token counts) of one sentence of a document, cached on the Sentence like the reference caches
+        `subtoken_ids_sentence` / `token_subtoken_lengths` (embeddings.py:3700-3737); the v2 path tokenises the plain
+        tokenised string -- no <EOS> substitution, no maximum_subtoken_length clamp"""
+        cache = sentence.__dict__.setdefault("_kbner_doc", {})
+        hit = cache.get(self.name)
+        if hit is None:
+            pieces = self.tokenizer.tokenize(sentence.to_tokenized_string())
+            counts = self.reconstruct_tokens_from_subtokens(sentence.tokens, pieces) if pieces else [0] * len(sentence)
+            hit = cache[self.name] = (list(self.tokenizer.convert_tokens_to_ids(pieces)), counts)
+        return hit
+
+    def _v2_window(self, sentence, max_sequence_length):
+        """add_document_embeddings_v2 (embeddings.py:3657-3812): the sentence sits inside its document's sub-token stream
+        (`sentence.doc`, position `sentence.doc_pos`); up to max_sequence_length ids are cut around it -- half of the free room
+        on each side, the shorter side's slack going to the other -- and framed [CLS] .. [SEP].
+        -> (row ids, position of the sentence's first sub-token inside the row, its per-token counts)"""
+        stream, start, end = [], None, None
+        counts = None
+        for pos, ds in enumerate(sentence.doc):
+            ids, cnt = self._doc_pieces(ds)
+            if pos == sentence.doc_pos:
+                start, counts = len(stream), cnt
+            stream += ids
+            if pos == sentence.doc_pos:
+                end = len(stream)
+        left, right, slen = start, len(stream) - end, end - start
+        half = int((max_sequence_length - slen) / 2)
+        if left < right:
+            lc = min(left, half)
+            rc = min(right, max_sequence_length - lc - slen)
+        else:
+            rc = min(right, half)
+            lc = min(left, max_sequence_length - rc - slen)
+        off = start - lc
+        cls_id = self.tokenizer.convert_tokens_to_ids(self.tokenizer.cls_token)
+        sep_id = self.tokenizer.convert_tokens_to_ids(self.tokenizer.sep_token)
+        return [cls_id] + stream[off:end + rc] + [sep_id], start - off + 1, counts
+
+    def _prepare_batch_v2doc(self, sentences):
+        model_max = min(int(getattr(self.tokenizer, "model_max_length", 512) or 512) - 2, 510)
+        B, n = len(sentences), max(len(s) for s in sentences)
+        rows, firsts = [], []
+        for s in sentences:
+            if not hasattr(s, "doc") or len(self._doc_pieces(s)[0]) > self.max_subtokens_sequence_length:
+                raise NotImplementedError("v2_doc: every sentence needs `.doc` / `.doc_pos` (ModelFinetuner(assign_doc_id=True, "
+                                          "train_with_doc=True)) and must fit one window; over-long single sentences take the "
+                                          "sliding-window path with v2_doc off")
+            row, pos, counts = self._v2_window(s, model_max)
+            f = []
+            for c in counts:
+                f.append(pos if c > 0 else -1)
+                pos += c
+            rows.append(row)
+            firsts.append(f)
+        S0 = max(len(r) for r in rows)
+        ids = np.zeros((B, S0), np.int64)
+        am = np.zeros((B, S0), np.int64)
+        first = np.full((B, n), -1, np.int64)
+        for b, (r, f) in enumerate(zip(rows, firsts)):
+            ids[b, :len(r)] = r
+            am[b, :len(r)] = 1
+            first[b, :len(f)] = f
+        return ids, am, first, np.asarray([len(s) for s in sentences], np.int64), np.tile(np.arange(B)[:, None], (1, n))
+
     def prepare_batch(self, sentences):
         """numpy integer batch: input_ids / attention_mask [R,S0] (R >= B encoder rows: a sentence longer than one window
         contributes several; padded with 0 like the reference), first_idx [B,n] (position inside the row, -1 pad),
         lengths [B], first_row [B,n] (which encoder row holds each word token's first sub-token)."""
+        if getattr(self, "v2_doc", False):
+            return self._prepare_batch_v2doc(sentences)
         toks = [self.tokenize_sentence(s) for s in sentences]
         B = len(toks)
         R = sum(len(t[0]) for t in toks)

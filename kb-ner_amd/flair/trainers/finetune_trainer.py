@@ -65,6 +65,12 @@ class ModelFinetuner:
             for part in ("train_list", "dev_list", "test_list"):
                 for s in getattr(corpus, part)[i]:
                     s.lang_id = i
+        self.sentence_level_pretrained_data = sentence_level_pretrained_data
+        if assign_doc_id:   # finetune_trainer.py:108-150: group sentences into documents at -DOCSTART- lines
+            for i, name in enumerate(getattr(corpus, "targets", [])):
+                docs = {}
+                for part, lst in (("train_", corpus.train_list), ("dev_", corpus.dev_list), ("test_", corpus.test_list)):
+                    self.assign_documents(lst[i], part, docs, name, train_with_doc)
         if assign_doc_for_ext_context:
             self.assign_ext_context_doc(self.corpus)   # finetune_trainer.py:373-377
 
@@ -360,6 +366,26 @@ class ModelFinetuner:
             scores.append(res.main_score)
         log_line(log)
         return sum(scores) / max(1, len(scores))
+
+    def assign_documents(self, data_list, doc_name, doc_sentence_dict, corpus_name, train_with_doc=False):
+        """distillation_trainer.py:655-674: a `-DOCSTART-` sentence opens a new document; with train_with_doc every sentence gets
+        `.doc` (the list of its document's sentences), `.doc_pos`, `.doc_name` -- what TransformerWordEmbeddings(v2_doc) reads"""
+        doc_idx = -1
+        for sentence in data_list:
+            if "-DOCSTART-" in sentence[0].text:
+                doc_idx += 1
+                doc_key = "start"
+            else:
+                doc_key = corpus_name + doc_name + str(doc_idx)
+            if getattr(self, "sentence_level_pretrained_data", False):
+                doc_idx += 1
+                doc_key = corpus_name + doc_name + str(doc_idx)
+            doc_sentence_dict.setdefault(doc_key, []).append(sentence)
+            if train_with_doc:
+                sentence.doc_name = doc_key
+                sentence.doc = doc_sentence_dict[doc_key]
+                sentence.doc_pos = len(doc_sentence_dict[doc_key]) - 1
+        return doc_sentence_dict
 
     def assign_ext_context_doc(self, corpus):
         """config 5 (`assign_doc_for_ext_context: true`, distillation_trainer.py:675-686): every sentence keeps an unchunked copy

@@ -194,3 +194,33 @@ def test_context_file_writer_matches_kb_context_process(tmp_path):
         assert open(path, encoding="utf-8").read() == run["file"], (run["length_limit"], run["max_len"])
         st = cf.validate_file(str(path), count, length_limit=run["length_limit"], eos_text="</s>")
         assert st["over_budget"] == 0
+
+
+def test_v2_doc_windows_match_reference(tmp_path):
+    """f-3: TransformerWordEmbeddings(v2_doc=True): the document window cut around every sentence (ids, mask) and the positions
+    of its first sub-tokens reproduce add_document_embeddings_v2's input and features (tests/golden/v2doc.npz, captured by
+    running the reference): sentences at the document's ends get the other side's slack"""
+    import tiny_assets
+    from flair.data import Sentence
+    from flair.embeddings import TransformerWordEmbeddings
+    g = np.load(os.path.join(GOLD, "v2doc.npz"))
+    mdir = tiny_assets.build_model_dir(str(tmp_path / "enc"), seed=0)
+    tj = os.path.join(mdir, "tokenizer_config.json")
+    cfg = json.load(open(tj))
+    cfg["model_max_length"] = int(g["model_max_length"])
+    json.dump(cfg, open(tj, "w"))
+    emb = TransformerWordEmbeddings(model=mdir, layers="-1", pooling_operation="first", v2_doc=True)
+    doc = [Sentence(str(t)) for t in g["texts"]]
+    for i, s in enumerate(doc):
+        s.doc, s.doc_pos = doc, i
+    ids, am, first, lengths, first_row = emb.prepare_batch(doc)
+    np.testing.assert_array_equal(ids, g["ids"])
+    np.testing.assert_array_equal(am, g["mask"])
+    assert [int(first[b, 0]) for b in range(len(doc))] == [int(p[0]) for p in g["batch_pos"]]
+    hidden, feats = g["hidden"], g["features"]
+    mine = np.zeros_like(feats)
+    for b in range(len(doc)):
+        for k in range(int(lengths[b])):
+            if first[b, k] >= 0:
+                mine[b, k] = hidden[first_row[b, k], first[b, k]]
+    np.testing.assert_array_equal(mine, feats)

@@ -515,3 +515,27 @@ def test_checkpoint_resume_equals_uninterrupted(g12, tmp_path):
         # the embedding backward's fp32 atomics make two runs differ by rounding, which Adam's normalisation turns into a few
         # 1e-3 of the (small) distance a bias has moved from 0: observed <= 2.1e-3 (embeddings.LayerNorm.bias), losses 4e-4
         assert rel < 7e-3, (k, rel)
+
+
+def test_v2_doc_forward_on_device(workdir):
+    """train.py --v2doc (`embedding.v2_doc = True`, :223-224) with documents assigned by the trainer (assign_doc_id /
+    train_with_doc): every sentence is encoded inside its document window; emissions are finite and shaped like the batch"""
+    from flair.config_parser import ConfigParser
+    from flair.custom_data_loader import ColumnDataLoader
+    from flair.trainers import ModelFinetuner
+    from flair.utils.from_params import Params
+    cp = ConfigParser(Params.from_file(str(workdir / "cfg.yaml")))
+    student = cp.create_student()
+    trainer = ModelFinetuner(student, None, cp.corpus, config=cp.config, assign_doc_id=True, train_with_doc=True,
+                             **cp.config["ModelFinetuner"])
+    sents = list(trainer.corpus.test)
+    assert all(hasattr(s, "doc") and s.doc[s.doc_pos] is s for s in sents)
+    for emb in student.embeddings.embeddings:
+        emb.v2_doc = True
+    student.eval()
+    dl = ColumnDataLoader(sents, 4, sort_data=False, sentence_level_batch=True, model=student)
+    dl.assign_tags(student.tag_type, student.tag_dictionary)
+    feats = student.forward(dl[0])
+    assert feats.shape[0] == len(dl[0]) and feats.shape[1] == max(len(s) for s in dl[0]) and torch.isfinite(feats).all()
+    res, loss = student.evaluate(dl, embeddings_storage_mode="none")
+    assert np.isfinite(loss)
