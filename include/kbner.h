@@ -125,6 +125,8 @@ int kbner_gemm_bf16(int layout, const kbner_bf16* A, int lda, const kbner_bf16* 
 #define KBNER_EPI_RMW32 32 /* C32 += result by non-atomic 16-byte read-modify-write */
 #define KBNER_EPI_STORE32 256 /* C32 = result, fp32 plain stores (must be the only flag): one split-K slab */
 #define KBNER_EPI_COLSUM 64 /* also accumulate the output's column sums (the producing layer's bias gradient) */
+#define KBNER_EPI_COLSUM_WS 512 /* with KBNER_EPI_COLSUM: `colsum` is a workspace f32 [2 * M/256, N] written by plain stores (one
+                                   line per tile row and wave row) instead of atomics; fold it with kbner_colsum_rows_f32 */
 typedef struct kbner_gemm_problem {
   const kbner_bf16* A;
   const kbner_bf16* B;
@@ -142,6 +144,8 @@ typedef struct kbner_gemm_problem {
   uint32_t drop_seed, drop_thresh; /* KBNER_EPI_DROP */
 } kbner_gemm_problem;
 int kbner_gemm_bf16_grouped(int layout, int nprob, const kbner_gemm_problem* probs, void* stream);
+/* out[n] += sum_r ws[r, n], rows = 2 * M / 256: the second half of KBNER_EPI_COLSUM_WS */
+int kbner_colsum_rows_f32(const float* ws, int rows, int N, float* out, void* stream);
 /* The same launch with DYNAMIC tile scheduling: workgroups draw their tiles from 8 per-XCD counters (`sched`, device ints the
  * caller zeroed on this stream since their last use) instead of a static walk, so a workgroup the dispatcher places late -- its
  * CU was running an RCCL collective of the overlapped gradient exchange -- takes fewer tiles instead of doubling the launch time.

@@ -191,9 +191,21 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const bf16_t* __restri
   const float scale2 = scale * 1.4426950408889634f;
   const uint32_t bhS = (uint32_t)((b * A + h) * S);
   const float dscale = DROP ? drop_scale(drop_thresh) : 1.0f;
-  for (int i = tid; i < S; i += 512) {
-    sMask[i] = maskbias[(size_t)b * S + i] * 1.4426950408889634f;
-    if (DROP) sCk[i] = drop_colkey(drop_seed, bhS + (uint32_t)i);
+  // sMask holds maskbias / scale: it is added to the RAW score sums q.k (the softmax runs on scale2 * (q.k + mask / scale)), and
+  // only in 16-key fragments at or behind the first masked key (`nfree16` leading fragments are mask-free: for the prefix masks
+  // of padded batches that is every fragment but the tail, for full-length sentences all of them)
+  __shared__ int s_first_masked;
+  if (tid == 0) s_first_masked = S;
+  __syncthreads();
+  {
+    int fm = S;
+    for (int i = tid; i < S; i += 512) {
+      const float m = maskbias[(size_t)b * S + i];
+      sMask[i] = m * (1.0f / scale);
+      if (m != 0.0f && i < fm) fm = i;
+      if (DROP) sCk[i] = drop_colkey(drop_seed, bhS + (uint32_t)i);
+    }
+    if (fm < S) atomicMin(&s_first_masked, fm);
   }
   stage_panel(base + H, ld, S, sK, wid, lane);
   stage_panel(base + 2 * H, ld, S, sV, wid, lane);
@@ -209,6 +221,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const bf16_t* __restri
   // K has landed when at most the V pieces (S/64 per wave, issued after K) are still in flight
   wait_vm(S / 64);
   __syncthreads();
+  const int nfree16 = s_first_masked >> 4;   // fragments f < nfree16 hold no masked key
   bool v_ready = false;
 #pragma unroll 1
   for (int pass = 0; pass < rpw / 128; ++pass) {
@@ -219,29 +232,41 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const bf16_t* __restri
     if (active) {
       const bf16x8 qf0 = glb_frag(base, ld, q0, 0, lane);
       const bf16x8 qf1 = glb_frag(base, ld, q0, 1, lane);
+      // two straight-line copies of the score pass (a per-fragment test would cut the unrolled body into 32 basic blocks):
+      // full-length sentences -- no masked key anywhere -- skip the mask add altogether
+      if (nfree16 >= NKB) {
 #pragma unroll
-      for (int f = 0; f < NKB; ++f) {
-        f4v a = (f4v){0.f, 0.f, 0.f, 0.f};
-        a = MFMA(__builtin_bit_cast(bf16x8, *reinterpret_cast<const s8v*>(kb0 + f * 2048)), qf0, a);
-        a = MFMA(__builtin_bit_cast(bf16x8, *reinterpret_cast<const s8v*>(kb1 + f * 2048)), qf1, a);
-        const float4 mb = *reinterpret_cast<const float4*>(sMask + f * 16 + g * 4);
-        // scores in the log2 domain (scale and mask pre-multiplied by log2 e): exp becomes a bare v_exp_f32
-        a[0] = a[0] * scale2 + mb.x;
-        a[1] = a[1] * scale2 + mb.y;
-        a[2] = a[2] * scale2 + mb.z;
-        a[3] = a[3] * scale2 + mb.w;
-        mx = fmaxf(mx, fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])));
-        st[f] = a;
+        for (int f = 0; f < NKB; ++f) {
+          f4v a = (f4v){0.f, 0.f, 0.f, 0.f};
+          a = MFMA(__builtin_bit_cast(bf16x8, *reinterpret_cast<const s8v*>(kb0 + f * 2048)), qf0, a);
+          a = MFMA(__builtin_bit_cast(bf16x8, *reinterpret_cast<const s8v*>(kb1 + f * 2048)), qf1, a);
+          // the row maximum is taken on the RAW sums (scale2 > 0 commutes with max): two v_max3 per fragment, no multiply
+          mx = fmaxf(fmaxf(mx, a[0]), a[1]);
+          mx = fmaxf(fmaxf(mx, a[2]), a[3]);
+          st[f] = a;
+        }
+      } else {
+#pragma unroll
+        for (int f = 0; f < NKB; ++f) {
+          f4v a = *reinterpret_cast<const f4v*>(sMask + f * 16 + g * 4);   // accumulators start at mask / scale
+          a = MFMA(__builtin_bit_cast(bf16x8, *reinterpret_cast<const s8v*>(kb0 + f * 2048)), qf0, a);
+          a = MFMA(__builtin_bit_cast(bf16x8, *reinterpret_cast<const s8v*>(kb1 + f * 2048)), qf1, a);
+          mx = fmaxf(fmaxf(mx, a[0]), a[1]);
+          mx = fmaxf(fmaxf(mx, a[2]), a[3]);
+          st[f] = a;
+        }
       }
       mx = group4_max(mx);
+      const float nmx = -mx * scale2;            // exp2(scale2 * s - scale2 * max): one fma + one v_exp per probability
+      mx = mx * scale2;                          // log2-domain maximum, what the stored lse needs
       const uint32_t rk = DROP ? drop_rowkey(drop_seed, bhS + (uint32_t)(q0 + li)) : 0u;
 #pragma unroll
       for (int f = 0; f < NKB; ++f) {
         f4v a = st[f];
-        a[0] = __builtin_amdgcn_exp2f(a[0] - mx);
-        a[1] = __builtin_amdgcn_exp2f(a[1] - mx);
-        a[2] = __builtin_amdgcn_exp2f(a[2] - mx);
-        a[3] = __builtin_amdgcn_exp2f(a[3] - mx);
+        a[0] = __builtin_amdgcn_exp2f(a[0] * scale2 + nmx);
+        a[1] = __builtin_amdgcn_exp2f(a[1] * scale2 + nmx);
+        a[2] = __builtin_amdgcn_exp2f(a[2] * scale2 + nmx);
+        a[3] = __builtin_amdgcn_exp2f(a[3] * scale2 + nmx);
         if (DROP) {
           sum += (a[0] + a[1]) + (a[2] + a[3]);  // normaliser of the UNdropped softmax
           const uint4 ck = *reinterpret_cast<const uint4*>(sCk + f * 16 + g * 4);

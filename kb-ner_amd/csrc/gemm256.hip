@@ -19,6 +19,8 @@
 #define EPI_RMW32 32  // C32[m,n] += result, non-atomic 16-byte RMW (each output element owned by one lane)
 #define EPI_COLSUM 64  // colsum[n] += sum_m out[m,n] (bias gradient of the producing layer), fp32 atomics, 2 per column per tile
 #define EPI_STORE32 256  // C32[m,n] = result (fp32, plain stores): one split-K slab, summed by kbner_splitk_finish
+#define EPI_COLSUM_WS 512  // with EPI_COLSUM: colsum is a workspace f32 [2 * M/256, N]; row 2*tile_row + wave_row receives this
+                           // tile's column sums by plain stores (no atomics); kbner_colsum_rows_f32 folds the rows afterwards
 #define EPI_DROP 128   // dropout on (acc*alpha + bias) BEFORE the residual add (BertSelfOutput / BertOutput); not with COLSUM
 
 #define G2_MAXP 16
@@ -357,9 +359,16 @@ static __device__ __forceinline__ void epilogue256(const GemmProblem& g, f4v (&a
     __builtin_amdgcn_sched_barrier(0);
   }
   if (epi & EPI_COLSUM) {
-    // this wave's 128 rows: 8 in registers (mi), 16 across the lanes of a group (xor-shuffle), then one atomic per column
+    // this wave's 128 rows: 8 in registers (mi), 16 across the lanes of a group (xor-shuffle); then either one atomic per
+    // column, or -- EPI_COLSUM_WS -- two 16-byte stores into this (tile row, wave row)'s line of a workspace that a reduce
+    // kernel folds afterwards.  The atomics were the epilogue: 512 device-scope fp32 atomics per tile onto 4096 addresses that
+    // every CU hits made the FFN-down dgrad (GELU' + bias gradient) the slowest GEMM of the step, 752 TFLOP/s against 1040-1250
+    // for the other dgrad shapes.
+    const bool to_ws = (epi & EPI_COLSUM_WS) != 0;
+    float* wrow = g.colsum + (to_ws ? (size_t)((m0 >> 8) * 2 + wm) * g.N : 0);
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
+    for (int q = 0; q < 2; ++q) {
+      float red[8];
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
         float x = csum[q][r];
@@ -367,8 +376,19 @@ static __device__ __forceinline__ void epilogue256(const GemmProblem& g, f4v (&a
         x += __shfl_xor(x, 2, 64);
         x += __shfl_xor(x, 4, 64);
         x += __shfl_xor(x, 8, 64);
-        if ((lane & 15) == 0) atomicAdd(g.colsum + ncol + q * 32 + r, x);
+        red[r] = x;
       }
+      if ((lane & 15) == 0) {
+        if (to_ws) {
+          float4* d = reinterpret_cast<float4*>(wrow + ncol + q * 32);
+          d[0] = make_float4(red[0], red[1], red[2], red[3]);
+          d[1] = make_float4(red[4], red[5], red[6], red[7]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 8; ++r) atomicAdd(g.colsum + ncol + q * 32 + r, red[r]);
+        }
+      }
+    }
   }
 }
 
@@ -651,6 +671,7 @@ static int gemm_grouped_impl(int layout, int nprob, const kbner_gemm_problem* pr
     if (s.epi & EPI_DGELU) KBNER_CHECK_ARG(s.aux != nullptr && s.ldaux % 8 == 0);
     if (s.epi & EPI_GELU) KBNER_CHECK_ARG(s.out2 != nullptr && s.ldout2 % 8 == 0);
     if (s.epi & EPI_COLSUM) KBNER_CHECK_ARG(s.colsum != nullptr && !(s.epi & (EPI_ATOMIC32 | EPI_RMW32 | EPI_STORE32)));
+    if (s.epi & EPI_COLSUM_WS) KBNER_CHECK_ARG((s.epi & EPI_COLSUM) != 0 && s.N % 4 == 0);
     if (s.epi & EPI_STORE32) KBNER_CHECK_ARG(s.epi == EPI_STORE32);
     if (s.epi & EPI_DROP) KBNER_CHECK_ARG(!(s.epi & (EPI_ATOMIC32 | EPI_RMW32 | EPI_COLSUM | EPI_GELU | EPI_DGELU)));
     GemmProblem& d = ga.p[i];

@@ -316,6 +316,26 @@ extern "C" int kbner_gather_rows_ld(const bf16_t* src, int ld_src, const int* id
   KBNER_LAUNCH_RET();
 }
 
+// out[n] += sum_r ws[r, n]: folds the per-(tile row, wave row) column sums a GEMM launched with KBNER_EPI_COLSUM_WS left in
+// its workspace (rows = 2 * M / 256).  grid (ceil(N / 256)), block 256 x 4 row-lanes: 1 KiB coalesced per row step.
+__global__ __launch_bounds__(1024) void colsum_rows_f32_kernel(const float* __restrict__ ws, int rows, int N, float* __restrict__ out) {
+  __shared__ float part[4][256];
+  const int tx = threadIdx.x & 255, ty = threadIdx.x >> 8;
+  const int n = blockIdx.x * 256 + tx;
+  float acc = 0.0f;
+  if (n < N)
+    for (int r = ty; r < rows; r += 4) acc += ws[(size_t)r * N + n];
+  part[ty][tx] = acc;
+  __syncthreads();
+  if (ty == 0 && n < N) out[n] += (part[0][tx] + part[1][tx]) + (part[2][tx] + part[3][tx]);
+}
+
+extern "C" int kbner_colsum_rows_f32(const float* ws, int rows, int N, float* out, void* stream) {
+  KBNER_CHECK_ARG(ws != nullptr && out != nullptr && rows > 0 && N > 0);
+  hipLaunchKernelGGL(colsum_rows_f32_kernel, dim3((N + 255) / 256), dim3(1024), 0, (hipStream_t)stream, ws, rows, N, out);
+  KBNER_LAUNCH_RET();
+}
+
 // fp32 row scatter (data-parallel exchange of the touched word-embedding gradient rows, kbner/dp.py): dst[idx[r],:] = rows[r,:];
 // indices unique, 16-byte accesses (W % 4 == 0)
 __global__ __launch_bounds__(256) void scatter_rows_f32_kernel(const float4* __restrict__ rows, const int* __restrict__ idx,

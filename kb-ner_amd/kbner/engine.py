@@ -16,7 +16,7 @@ import torch
 
 from . import lib as L_
 from . import ops
-from .lib import EPI_ADD, EPI_ATOMIC32, EPI_BIAS, EPI_COLSUM, EPI_DGELU, EPI_GELU, EPI_RMW32, GEMM_NN, GEMM_NT, GEMM_TN
+from .lib import EPI_ADD, EPI_ATOMIC32, EPI_BIAS, EPI_COLSUM, EPI_COLSUM_WS, EPI_DGELU, EPI_GELU, EPI_RMW32, GEMM_NN, GEMM_NT, GEMM_TN
 
 BF16, F32, I32 = torch.bfloat16, torch.float32, torch.int32
 
@@ -206,6 +206,7 @@ class _Acts:
         self._z, self._H = z, H
         self.dhm = self.dh1m = None
         self.splitk_ws = None  # f32 [4, Mp, H] split-K slabs, allocated on first use (small micro-batches only)
+        self.colsum_ws = None  # f32 [2 * Mp/256, F] column-sum lines of the FFN-down dgrad epilogue (EPI_COLSUM_WS)
 
     def drop_buffers(self):
         """masked copies of dh / dh1 (the dY of the two GEMMs whose outputs were dropped); allocated on first training use"""
@@ -421,10 +422,16 @@ class Tagger:
             # FFN down dgrad: dpre = (dh W2) * gelu'(pre)   (the derivative itself was saved by the forward epilogue)
             # (its column sums = d ffn1.bias are accumulated by the same epilogue when the 256^2 kernel runs)
             fused = ops.uses_256(Mp, F_, occupancy=True)
-            ops.gemm(GEMM_NN, dhm, a.bf(p + "ffn2.weight"), Mp, F_, H, C=dpre, aux=ac.dact[l],
-                     epi=EPI_DGELU | (EPI_COLSUM if fused else 0), colsum=a.grad(p + "ffn1.bias") if fused else None, occupancy=True)
-            # FFN up
-            if not fused:
+            if fused:
+                # column sums (= d ffn1.bias) leave the epilogue as plain stores into a [2 * Mp/256, F] workspace, folded by a
+                # small reduce kernel: per-tile atomics onto the same 4096 addresses were what made this the slowest GEMM
+                if ac.colsum_ws is None:
+                    ac.colsum_ws = torch.empty((2 * (Mp // 256), F_), dtype=F32, device=self.device)
+                ops.gemm(GEMM_NN, dhm, a.bf(p + "ffn2.weight"), Mp, F_, H, C=dpre, aux=ac.dact[l],
+                         epi=EPI_DGELU | EPI_COLSUM | EPI_COLSUM_WS, colsum=ac.colsum_ws, occupancy=True)
+                ops.colsum_rows_f32(ac.colsum_ws, 2 * (Mp // 256), a.grad(p + "ffn1.bias"))
+            else:
+                ops.gemm(GEMM_NN, dhm, a.bf(p + "ffn2.weight"), Mp, F_, H, C=dpre, aux=ac.dact[l], epi=EPI_DGELU, occupancy=True)
                 ops.colsum(dpre, a.grad(p + "ffn1.bias"))
             self._long_k_gemm(GEMM_NN, dpre, a.bf(p + "ffn1.weight"), Mp, H, F_, ac.dx1, ac, addend=dh)
             # LN1 backward; fused: d o.bias

@@ -42,6 +42,7 @@ SIGNATURES = {
     "kbner_gemm_bf16": (c_int, [c_int, P, c_int, P, c_int, c_int, c_int, c_int, P, c_int, P, c_int, P, P, c_int, P, c_int,
                                 P, c_int, c_int, c_int, c_float, U32, U32, P]),
     "kbner_gemm_bf16_grouped": (c_int, [c_int, c_int, P, P]),
+    "kbner_colsum_rows_f32": (c_int, [P, c_int, c_int, P, P]),
     "kbner_gemm_bf16_grouped_dyn": (c_int, [c_int, c_int, P, P, P]),
     "kbner_splitk_finish": (c_int, [P, c_int, P, P, c_int, P, c_int, c_int, c_int, U32, U32, P]),
     "kbner_attn_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, U32, U32, P]),
@@ -61,6 +62,7 @@ SIGNATURES = {
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 EPI_BIAS, EPI_GELU, EPI_ADD, EPI_DGELU, EPI_ATOMIC32, EPI_RMW32, EPI_COLSUM, EPI_DROP = 1, 2, 4, 8, 16, 32, 64, 128
 EPI_STORE32 = 256
+EPI_COLSUM_WS = 512
 
 
 class GemmProblem(ctypes.Structure):

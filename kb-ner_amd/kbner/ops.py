@@ -152,6 +152,12 @@ def head_bwd(de, x, w, dw, db):
     return dx
 
 
+def colsum_rows_f32(ws, rows, out):
+    """out f32[N] += sum over the first `rows` rows of ws f32[>= rows, N] (the EPI_COLSUM_WS workspace)"""
+    _chk(ws, F32, "ws"); _chk(out, F32, "out")
+    L.call("kbner_colsum_rows_f32", ptr(ws), rows, out.numel(), ptr(out), stream_ptr())
+
+
 def colsum(x, out, M=None):
     _chk(x, BF16, "x"); _chk(out, F32, "out")
     rows, N = x.shape

@@ -56,6 +56,17 @@ def test_gemm_colsum_epilogue(st):
     torch.cuda.synchronize()
     ref = C.float().sum(0) + 3.0
     assert float((cs - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
+    # EPI_COLSUM_WS: the same sums through the store-only workspace + reduce kernel (what the engine uses); the two paths add the
+    # same fp32 partials in a different order only
+    from kbner.lib import EPI_COLSUM_WS
+    ws = torch.full((2 * (M // 256), N), float("nan"), device="cuda")
+    cs2 = torch.full((N,), 3.0, device="cuda")
+    C2 = torch.zeros_like(C)
+    ops.gemm(GEMM_NN, A, W, M, N, K, C=C2, aux=aux, epi=EPI_DGELU | EPI_COLSUM | EPI_COLSUM_WS, colsum=ws)
+    ops.colsum_rows_f32(ws, ws.shape[0], cs2)
+    torch.cuda.synchronize()
+    assert torch.equal(C2, C)
+    assert float((cs2 - cs).abs().max()) <= 1e-5 * float(ref.abs().max())
 
 
 def test_gemm_grouped_wgrad(st):
