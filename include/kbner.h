@@ -144,8 +144,8 @@ typedef struct kbner_gemm_problem {
   uint32_t drop_seed, drop_thresh; /* KBNER_EPI_DROP */
 } kbner_gemm_problem;
 int kbner_gemm_bf16_grouped(int layout, int nprob, const kbner_gemm_problem* probs, void* stream);
-/* out[n] += sum_r ws[r, n], rows = 2 * M / 256: the second half of KBNER_EPI_COLSUM_WS */
-int kbner_colsum_rows_f32(const float* ws, int rows, int N, float* out, void* stream);
+/* out[n] += sum_r ws[r, n], rows = 2 * M / 256: the second half of KBNER_EPI_COLSUM_WS (ws is folded in place: clobbered) */
+int kbner_colsum_rows_f32(float* ws, int rows, int N, float* out, void* stream);
 /* The same launch with DYNAMIC tile scheduling: workgroups draw their tiles from 8 per-XCD counters (`sched`, device ints the
  * caller zeroed on this stream since their last use) instead of a static walk, so a workgroup the dispatcher places late -- its
  * CU was running an RCCL collective of the overlapped gradient exchange -- takes fewer tiles instead of doubling the launch time.

@@ -317,22 +317,39 @@ extern "C" int kbner_gather_rows_ld(const bf16_t* src, int ld_src, const int* id
 }
 
 // out[n] += sum_r ws[r, n]: folds the per-(tile row, wave row) column sums a GEMM launched with KBNER_EPI_COLSUM_WS left in
-// its workspace (rows = 2 * M / 256).  grid (ceil(N / 256)), block 256 x 4 row-lanes: 1 KiB coalesced per row step.
-__global__ __launch_bounds__(1024) void colsum_rows_f32_kernel(const float* __restrict__ ws, int rows, int N, float* __restrict__ out) {
+// its workspace (rows = 2 * M / 256).  Two deterministic passes of one kernel: grid (ceil(N / 256), rows / chunk) blocks each
+// fold `chunk` consecutive rows IN PLACE into the first row of their chunk (a block reads only its own chunk), then one row of
+// blocks folds those first rows into out.  (A single pass with 16 blocks ran at 150 GB/s: 55 us for 8 MB.)
+// block 256 columns x 4 row-lanes.
+__global__ __launch_bounds__(1024) void colsum_fold_kernel(float* __restrict__ ws, int first_stride, int stride, int count, int N,
+                                                           float* __restrict__ out) {
   __shared__ float part[4][256];
   const int tx = threadIdx.x & 255, ty = threadIdx.x >> 8;
   const int n = blockIdx.x * 256 + tx;
+  float* base = ws + (size_t)blockIdx.y * first_stride * N;
   float acc = 0.0f;
   if (n < N)
-    for (int r = ty; r < rows; r += 4) acc += ws[(size_t)r * N + n];
+    for (int i = ty; i < count; i += 4) acc += base[(size_t)i * stride * N + n];
   part[ty][tx] = acc;
   __syncthreads();
-  if (ty == 0 && n < N) out[n] += (part[0][tx] + part[1][tx]) + (part[2][tx] + part[3][tx]);
+  if (ty == 0 && n < N) {
+    const float t = (part[0][tx] + part[1][tx]) + (part[2][tx] + part[3][tx]);
+    if (out != nullptr) out[n] += t;
+    else base[n] = t;
+  }
 }
 
-extern "C" int kbner_colsum_rows_f32(const float* ws, int rows, int N, float* out, void* stream) {
+extern "C" int kbner_colsum_rows_f32(float* ws, int rows, int N, float* out, void* stream) {
   KBNER_CHECK_ARG(ws != nullptr && out != nullptr && rows > 0 && N > 0);
-  hipLaunchKernelGGL(colsum_rows_f32_kernel, dim3((N + 255) / 256), dim3(1024), 0, (hipStream_t)stream, ws, rows, N, out);
+  const int chunk = 16;
+  const dim3 gx((N + 255) / 256);
+  if (rows > chunk && rows % chunk == 0) {
+    hipLaunchKernelGGL(colsum_fold_kernel, dim3(gx.x, rows / chunk), dim3(1024), 0, (hipStream_t)stream, ws, chunk, 1, chunk, N,
+                       (float*)nullptr);
+    hipLaunchKernelGGL(colsum_fold_kernel, gx, dim3(1024), 0, (hipStream_t)stream, ws, 0, chunk, rows / chunk, N, out);
+  } else {
+    hipLaunchKernelGGL(colsum_fold_kernel, gx, dim3(1024), 0, (hipStream_t)stream, ws, 0, 1, rows, N, out);
+  }
   KBNER_LAUNCH_RET();
 }
 

@@ -41,12 +41,14 @@ def test_gemm(st, layout, M, N, K, epi, sk):
     assert st.check_gemm(layout, M, N, K, epi, sk) < 6e-3
 
 
-def test_gemm_colsum_epilogue(st):
-    """EPI_COLSUM: the dgrad GEMM also accumulates its output's column sums (bias gradient of the producing layer)."""
+@pytest.mark.parametrize("M", [768, 4096])
+def test_gemm_colsum_epilogue(st, M):
+    """EPI_COLSUM: the dgrad GEMM also accumulates its output's column sums (bias gradient of the producing layer); M = 4096
+    takes the two-pass fold of the workspace variant (32 workspace rows), 768 the single pass."""
     from kbner import ops
-    from kbner.lib import EPI_COLSUM, EPI_DGELU, GEMM_NN
+    from kbner.lib import EPI_COLSUM, EPI_COLSUM_WS, EPI_DGELU, GEMM_NN
     g = torch.Generator(device="cpu").manual_seed(0)
-    M, N, K = 768, 512, 256
+    N, K = 512, 256
     A = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16).cuda()
     W = (torch.randn(K, N, generator=g) * 0.5).to(torch.bfloat16).cuda()
     aux = torch.randn(M, N, generator=g).to(torch.bfloat16).cuda()
@@ -54,19 +56,22 @@ def test_gemm_colsum_epilogue(st):
     cs = torch.full((N,), 3.0, device="cuda")
     ops.gemm(GEMM_NN, A, W, M, N, K, C=C, aux=aux, epi=EPI_DGELU | EPI_COLSUM, colsum=cs)
     torch.cuda.synchronize()
-    ref = C.float().sum(0) + 3.0
-    assert float((cs - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
-    # EPI_COLSUM_WS: the same sums through the store-only workspace + reduce kernel (what the engine uses); the two paths add the
-    # same fp32 partials in a different order only
-    from kbner.lib import EPI_COLSUM_WS
-    ws = torch.full((2 * (M // 256), N), float("nan"), device="cuda")
-    cs2 = torch.full((N,), 3.0, device="cuda")
-    C2 = torch.zeros_like(C)
-    ops.gemm(GEMM_NN, A, W, M, N, K, C=C2, aux=aux, epi=EPI_DGELU | EPI_COLSUM | EPI_COLSUM_WS, colsum=ws)
-    ops.colsum_rows_f32(ws, ws.shape[0], cs2)
-    torch.cuda.synchronize()
-    assert torch.equal(C2, C)
-    assert float((cs2 - cs).abs().max()) <= 1e-5 * float(ref.abs().max())
+    ref = C.double().sum(0) + 3.0
+    assert float((cs.double() - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
+    # EPI_COLSUM_WS: the same sums through the store-only workspace + fold kernel (what the engine uses): deterministic, and
+    # the same fp32 partials as the atomic path added in another order
+    res = []
+    for _ in range(2):
+        ws = torch.full((2 * (M // 256), N), float("nan"), device="cuda")
+        cs2 = torch.full((N,), 3.0, device="cuda")
+        C2 = torch.zeros_like(C)
+        ops.gemm(GEMM_NN, A, W, M, N, K, C=C2, aux=aux, epi=EPI_DGELU | EPI_COLSUM | EPI_COLSUM_WS, colsum=ws)
+        ops.colsum_rows_f32(ws, ws.shape[0], cs2)
+        torch.cuda.synchronize()
+        assert torch.equal(C2, C)
+        res.append(cs2)
+    assert torch.equal(res[0], res[1])
+    assert float((res[0] - cs).abs().max()) <= 1e-5 * float(ref.abs().max())
 
 
 def test_gemm_grouped_wgrad(st):
