@@ -168,8 +168,6 @@ def test_yaml_keyword_sets_are_explicit_parameters(section):
             # need external weight files that do not exist offline; the classes exist and say so when constructed
             assert cls is not None
             return
-        if cls is None and name == "FlairEmbeddings":
-            pytest.xfail("FlairEmbeddings (config 5 char-LM stack, SURVEY §8f-1) is being built this round")
         assert cls is not None, name
         params = _explicit_params(cls.__init__)
     assert keys <= params, sorted(keys - params)
