@@ -50,6 +50,18 @@ int kbner_crf_nll_bwd(const float* emit, const float* trans, const int* tags, co
  * argument may be all zeros).  marg f32[B,n,T], rows at or past lens[b] are zero-filled. */
 int kbner_crf_posterior(const float* emit, const float* trans, const int* lens, const float* alpha, const float* logz, int B,
                         int n, int T, int start, int stop, float* marg, void* stream);
+
+/* Multi-view ("cooperative learning") posterior distillation between two views of the same sentences -- the `distill_posterior`
+   branch of FastSequenceTagger._calculate_multi_view_loss (flair/models/sequence_tagger_model.py:2080-2093, loss form
+   :2384-2398), called by ModelFinetuner.train (flair/trainers/finetune_trainer.py:959-966).  loss[b] = T^2 * sum_i KL(softmax(
+   g^t_i / T) || softmax(g^s_i / T)), g = forward_var + backward_var of the view's emissions; emit_t (the context view's emissions at
+   the real tokens) is a constant.  Forward and backward in one launch: d(sum_b wgt[b] loss[b]) / d emit_s is WRITTEN to demit
+   f32[B,n,T] (rows >= lens[b] zero), the transition gradient ADDED to dtrans f32[T,T].  T <= 32.
+   ws: kbner_crf_posterior_kl_ws_floats(B, n, T) floats. */
+size_t kbner_crf_posterior_kl_ws_floats(int B, int n, int T);
+int kbner_crf_posterior_kl(const float* emit_s, const float* emit_t, const float* trans, const int* lens, const float* wgt,
+                           float tau, int B, int n, int T, int start, int stop, float* loss, float* demit, float* dtrans,
+                           float* ws, void* stream);
 /* n-best Viterbi (SequenceTagger._viterbi_decode_nbest, sequence_tagger_model.py:1660-1818; called on KD teachers at
  * finetune_trainer.py:1600, distillation_trainer.py:819): decode i32 [B, n, nbest] tag indices and path_score f32 [B, nbest]
  * (softmax over the nbest end scores).  The NCRF++ decoder's conventions are kept as they are: trans indexed [from, to],

@@ -22,6 +22,8 @@ SIGNATURES = {
     "kbner_crf_nll_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, P]),
     "kbner_crf_nll_bwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P]),
     "kbner_crf_posterior": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P]),
+    "kbner_crf_posterior_kl_ws_floats": (c_size_t, [c_int, c_int, c_int]),
+    "kbner_crf_posterior_kl": (c_int, [P, P, P, P, P, c_float, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P]),
     "kbner_crf_viterbi_nbest_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "kbner_crf_viterbi_nbest": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P]),
     "kbner_gather_rows": (c_int, [P, P, P, c_int, c_int, P]),

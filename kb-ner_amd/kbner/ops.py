@@ -93,6 +93,23 @@ def crf_posterior(emit, trans, lens, start, stop):
     return marg
 
 
+def crf_posterior_kl(emit_s, emit_t, trans, lens, weights, tau, start, stop, dtrans):
+    """multi-view posterior distillation (FastSequenceTagger._calculate_multi_view_loss, distill_posterior branch):
+    -> (loss f32[B] = tau^2 * sum_i KL(teacher || student tempered marginals), demit f32[B,n,T] = d(sum_b weights[b] loss[b]) /
+    d emit_s); the transition gradient is ADDED to dtrans f32[T,T].  emit_t is a constant (the detached context view)."""
+    _chk(emit_s, F32, "emit_s"); _chk(emit_t, F32, "emit_t"); _chk(trans, F32, "trans"); _chk(lens, I32, "lens")
+    _chk(weights, F32, "weights"); _chk(dtrans, F32, "dtrans")
+    if emit_s.shape != emit_t.shape:
+        raise L.KbnerError("the two views must have the same [B, n, T] emissions shape")
+    B, n, T = emit_s.shape
+    loss = torch.empty((B,), dtype=F32, device=emit_s.device)
+    demit = torch.empty_like(emit_s)
+    ws = torch.empty((int(L.load().kbner_crf_posterior_kl_ws_floats(B, n, T)),), dtype=F32, device=emit_s.device)
+    L.call("kbner_crf_posterior_kl", ptr(emit_s), ptr(emit_t), ptr(trans), ptr(lens), ptr(weights), float(tau), B, n, T, start, stop,
+           ptr(loss), ptr(demit), ptr(dtrans), ptr(ws), stream_ptr())
+    return loss, demit
+
+
 # ---------------------------------------------------------------- rows / head
 def gather_rows(src, idx, out=None):
     _chk(src, BF16, "src"); _chk(idx, I32, "idx")
