@@ -29,10 +29,10 @@ STOP_TAG: str = "<STOP>"
 # constructor switches of the reference that select code outside the hot path (KD / MFVI / attention variants / ACE controller
 # training): accepted by name, rejected when switched on
 _UNSUPPORTED_TRUE = ("use_mfvi", "use_cnn", "distill_crf", "crf_attention", "biaf_attention", "use_language_attention",
-                     "token_level_attention", "distill_with_gold", "exp_score", "distill_posterior", "distill_prob",
+                     "token_level_attention", "distill_with_gold", "exp_score", "distill_prob",
                      "distill_emission", "distill_exact", "posterior_constraint", "use_language_vector", "enhanced_crf",
                      "use_language_id", "use_transition_attention", "unlabel_entropy_loss", "relearn_embeddings", "map_embeddings",
-                     "no_encoder", "new_drop", "use_embedding_masks", "use_gumbel", "embedding_attention", "multi_view_training",
+                     "no_encoder", "new_drop", "use_embedding_masks", "use_gumbel", "embedding_attention",
                      "calculate_l2_loss", "l2_loss_only", "train_initial_hidden_state")
 
 
@@ -66,6 +66,14 @@ class SequenceTagger(flair.nn.Model):
             raise NotImplementedError("use_crf=False (softmax head) is not on the hot path")
         if use_rnn and rnn_layers != 1:
             raise NotImplementedError("rnn_layers > 1 is not implemented (the KB-NER / ACE configs use the default of 1)")
+        # multi-view ("cooperative learning") training: the shipped *_multiview_posterior_* YAMLs set multi_view_training +
+        # distill_posterior + temperature; the other branches of _calculate_multi_view_loss (distill_exact, L2) stay out of scope,
+        # and distill_posterior WITHOUT multi_view_training only matters to the distillation trainers (out of scope)
+        if multi_view_training and not (distill_posterior and remove_x and not use_rnn):
+            raise NotImplementedError("multi_view_training is implemented for the posterior-distillation form of the shipped "
+                                      "configs: distill_posterior: true, remove_x: true, use_rnn: false")
+        if distill_posterior and not multi_view_training:
+            raise NotImplementedError("distill_posterior without multi_view_training belongs to the distillation trainers (out of scope)")
         self.hidden_size = hidden_size
         self.embeddings = embeddings
         self.tag_dictionary = tag_dictionary
@@ -90,7 +98,10 @@ class SequenceTagger(flair.nn.Model):
         self.biaf_attention = False
         self.use_language_attention = False
         self.use_language_vector = False
-        self.distill_crf = self.distill_posterior = self.distill_prob = self.distill_exact = False
+        self.distill_crf = self.distill_prob = self.distill_exact = False
+        self.distill_posterior = bool(distill_posterior)
+        self.multi_view_training = bool(multi_view_training)
+        self.calculate_l2_loss = self.l2_loss_only = False
         self.crf_attention = False
         self.selection = None
         self.mask = None
@@ -355,17 +366,66 @@ class SequenceTagger(flair.nn.Model):
         self.mask = torch.from_numpy(hb["keep"].astype(np.float32)).to(flair.device)
         return self.engine.forward_loss(db, backward=False)
 
-    def forward_backward(self, data_points, loss_scale=1.0, sentence_weights=None, grad_ready=None):
+    def forward_backward(self, data_points, loss_scale=1.0, sentence_weights=None, grad_ready=None, multi_view=None):
         """forward_loss + backward into the gradient arena (what `loss.backward()` does at finetune_trainer.py:957).
         sentence_weights (optional, one per sentence) replace the 1/B of the batch mean: see ModelFinetuner.train's
-        accumulation-group fusion.  grad_ready(lo, hi): called as soon as arena.g[lo:hi] is final (data-parallel overlap)."""
+        accumulation-group fusion.  grad_ready(lo, hi): called as soon as arena.g[lo:hi] is final (data-parallel overlap).
+
+        multi_view = (indices, weights): the second half of a multi-view step (finetune_trainer.py:959-966 ->
+        multi_view_loss -> _calculate_multi_view_loss, sequence_tagger_model.py:1923,1958-2093): for the sentences
+        data_points[indices] (those with an `orig_sent` and S-X context) the bare sentence is encoded as a second batch and the
+        tempered posteriors of its CRF are pulled towards those of the context view just computed (constant), each sentence
+        weighted by `weights`.  Returns the NLL term + the distillation term (both weighted as given) as one 0-d tensor."""
         if self.use_rnn:
             raise NotImplementedError("training the BiLSTM / stacked-embedding tagger (ACE) is out of scope: config 5 is inference-only")
         self.embeddings.embed(data_points)
         hb, db = self._device_batch(data_points)
         self._last = (hb, db)
         self.mask = torch.from_numpy(hb["keep"].astype(np.float32)).to(flair.device)
-        return self.engine.forward_loss(db, loss_scale=loss_scale, backward=True, weights=sentence_weights, grad_ready=grad_ready)
+        if not multi_view or len(multi_view[0]) == 0:
+            loss = self.engine.forward_loss(db, loss_scale=loss_scale, backward=True, weights=sentence_weights, grad_ready=grad_ready)
+            self.last_loss_parts = (loss, None)
+            return loss
+        idx, kw = multi_view
+        loss = self.engine.forward_loss(db, loss_scale=loss_scale, backward=True, weights=sentence_weights, grad_ready=None)
+        teacher = self.engine.last_emissions.index_select(0, torch.as_tensor(list(idx), dtype=torch.long, device=flair.device))
+        t_lens = hb["clens"][list(idx)]
+        orig = [data_points[i].orig_sent for i in idx]
+        self.embeddings.embed(orig)
+        ohb, odb = self._device_batch(orig)
+        if not np.array_equal(ohb["clens"], t_lens):
+            # the reference asserts the same thing (`assert (new_mask == self.mask).all()`, :2062): the context file's sentence
+            # part and the plain file's sentence must be the same tokens
+            raise ValueError("multi-view pair mismatch: real-token counts %s (context view) vs %s (orig_sent)" %
+                             (t_lens.tolist(), ohb["clens"].tolist()))
+        kd = self.engine.distill_loss(odb, teacher, float(self.temperature), loss_scale=loss_scale, backward=True,
+                                      weights=kw, grad_ready=grad_ready)
+        store_embeddings(orig, "none")
+        self.last_loss_parts = (loss, kd)   # (weighted NLL of the context view, weighted distillation term): 0-d device tensors
+        return loss + kd
+
+    def check_multi_view(self, sentences):
+        """sequence_tagger_model.py:1928-1956: False unless some sentence of the batch carries an `orig_sent` and the batch's tags
+        contain S-X; otherwise the [B, n] tag tensor"""
+        if sum(hasattr(s, "orig_sent") for s in sentences) == 0:
+            return False
+        n = max(len(s) for s in sentences)
+        tags = np.zeros((len(sentences), n), np.int64)
+        for b, s in enumerate(sentences):
+            tags[b, :len(s)] = [self.tag_dictionary.get_idx_for_item(t.get_tag(self.tag_type).value) for t in s]
+        x = self.tag_dictionary.get_idx_for_item("S-X")
+        if not (tags == x).any():
+            return False
+        return torch.from_numpy(tags)
+
+    def multi_view_plan(self, sentences):
+        """-> indices of the sentences that take part in the distillation term of this (micro-)batch: those with an `orig_sent`
+        whose own tags contain S-X (:2023); [] when check_multi_view is False (the batch is then a plain NLL batch)"""
+        tags = self.check_multi_view(sentences)
+        if tags is False:
+            return []
+        x = self.tag_dictionary.get_idx_for_item("S-X")
+        return [b for b, s in enumerate(sentences) if hasattr(s, "orig_sent") and bool((tags[b, :len(s)] == x).any())]
 
     def touched_word_ids(self, sentences):
         """the word-embedding rows a list of sentences looks up (host integers): what the data-parallel gradient exchange

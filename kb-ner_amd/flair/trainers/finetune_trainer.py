@@ -71,8 +71,39 @@ class ModelFinetuner:
                 docs = {}
                 for part, lst in (("train_", corpus.train_list), ("dev_", corpus.dev_list), ("test_", corpus.test_list)):
                     self.assign_documents(lst[i], part, docs, name, train_with_doc)
+        if getattr(self.model, "multi_view_training", False):
+            self._pair_multi_view_corpora()
         if assign_doc_for_ext_context:
             self.assign_ext_context_doc(self.corpus)   # finetune_trainer.py:373-377
+
+    def _pair_multi_view_corpora(self):
+        """finetune_trainer.py:316-344: with `multi_view_training`, every corpus whose NAME contains 'doc' is the context view of
+        the (one) corpus whose name does not: sentence k of its train / dev / test split gets `orig_sent` = sentence k of the
+        source corpus' split.  ('unlabel' corpora -- the semi-supervised variant, :345-365 -- are not implemented.)"""
+        source, targets = None, []
+        for name in self.corpus2id:
+            low = name.lower()
+            if "doc" in low:
+                targets.append(name)
+            elif "unlabel" in low:
+                raise NotImplementedError("multi-view training with an unlabeled corpus (%s) is not implemented" % name)
+            else:
+                source = name
+        if source is None or not targets:
+            log.warning("multi_view_training: no (source, *doc*) corpus pair among %s -- training without the second view",
+                        list(self.corpus2id))
+            return
+        si = self.corpus2id[source]
+        for tname in targets:
+            ti = self.corpus2id[tname]
+            log.info("%s -> %s", source, tname)
+            for part in ("train_list", "dev_list", "test_list"):
+                src, dst = getattr(self.corpus, part)[si], getattr(self.corpus, part)[ti]
+                if len(src) < len(dst):
+                    raise ValueError("multi-view pairing: %s has %d sentences but its source %s only %d (%s)" %
+                                     (tname, len(dst), source, len(src), part))
+                for k, sentence in enumerate(dst):
+                    sentence.orig_sent = src[k]
 
     @classmethod
     def load_from_checkpoint(cls, checkpoint: dict, corpus, **kwargs):
@@ -80,6 +111,23 @@ class ModelFinetuner:
         the trainer restarts at checkpoint['epoch'] with the saved Adam moments, step count, LR-schedule position and RNG streams"""
         return cls(checkpoint["model"], None, corpus, epoch=checkpoint["epoch"], optimizer_state=checkpoint["optimizer_state_dict"],
                    scheduler_state=checkpoint["scheduler_state_dict"], **kwargs)
+
+    def _group_weights(self, group, multi_view_rate):
+        """per-sentence loss weights of one accumulation group encoded as a single batch: 1 / (|group| * |micro-batch|), i.e.
+        the mean over each micro-batch and the 1/accumulate of the group (finetune_trainer.py:939-946).  With multi-view
+        training (finetune_trainer.py:909-914,959-966) a micro-batch that carries a second view has its NLL scaled by
+        (1 - rate) and adds rate * KL, the KL averaged over ITS paired sentences (:2394-2395) ->
+        (weights, (indices into the concatenated group, KL weights) or None)"""
+        G = len(group)
+        wts, idx, kw, base = [], [], [], 0
+        for bt in group:
+            sel = self.model.multi_view_plan(bt) if multi_view_rate is not None else []
+            f = (1.0 - multi_view_rate) if sel else 1.0
+            wts += [f / (G * len(bt))] * len(bt)
+            idx += [base + k for k in sel]
+            kw += [multi_view_rate / (G * len(sel))] * len(sel)
+            base += len(bt)
+        return wts, ((idx, kw) if idx else None)
 
     # ------------------------------------------------------------------ training
     def train(self, base_path: Union[Path, str], learning_rate: float = 5e-5, mini_batch_size: int = 32,
@@ -198,6 +246,10 @@ class ModelFinetuner:
             with open(loss_txt, "a") as f:
                 f.write("EPOCH\tTIMESTAMP\tLEARNING_RATE\tTRAIN_LOSS\tDEV_LOSS\tDEV_F1\tDEV_MACRO_F1\n")
 
+        multi_view = bool(getattr(self.model, "multi_view_training", False))
+        if multi_view:
+            log.info("multi-view training: (1 - %s) * NLL(context view) + %s * T^2 KL(posterior(context view) || posterior(sentence "
+                     "alone)), T = %s", multi_view_rate, multi_view_rate, self.model.temperature)
         dev_score_history, dev_loss_history, train_loss_history = [], [], []
         best_score, bad_epochs = 0.0, 0   # finetune_trainer.py: best_score starts at 0 and a TIE with it still saves (:1280-1289)
         log_every = log_interval or max(1, len(loader) // W // 10)
@@ -230,18 +282,27 @@ class ModelFinetuner:
                         # the word ids of the whole accumulation group are known now: agree on the union of touched
                         # embedding rows on the host while the GPU works (kbner.dp.GradReducer)
                         grp = [loader[b2] for b2 in mine[local_no:local_no + div]]
-                        reducer.begin(self.model.touched_word_ids([sn for bt in grp for sn in bt]))
+                        touched = [sn for bt in grp for sn in bt]
+                        if multi_view:   # the second view looks its own sub-tokens up
+                            touched += [sn.orig_sent for sn in touched if hasattr(sn, "orig_sent")]
+                        reducer.begin(self.model.touched_word_ids(touched))
                     hook = reducer.bucket_ready if (reducer is not None and flush and overlap_allreduce) else None
                     if fuse:
                         group.append(batch)
                         if flush:
                             sents = [sn for bt in group for sn in bt]
-                            wts = [1.0 / (len(group) * len(bt)) for bt in group for _ in bt]
-                            fused = self.model.forward_backward(sents, loss_scale=1.0, sentence_weights=wts, grad_ready=hook)
+                            wts, mv = self._group_weights(group, multi_view_rate if multi_view else None)
+                            fused = self.model.forward_backward(sents, loss_scale=1.0, sentence_weights=wts, grad_ready=hook,
+                                                                multi_view=mv)
                             # log the mean of the group's micro-batch losses, once per micro-batch, like the unfused loop
                             losses += [fused] * len(group)
                             scaled += [fused / div] * len(group)
                             group = []
+                    elif multi_view:
+                        wts, mv = self._group_weights([batch], multi_view_rate)
+                        losses.append(self.model.forward_backward(batch, loss_scale=1.0 / div, sentence_weights=wts,
+                                                                  grad_ready=hook, multi_view=mv))
+                        scaled.append(losses[-1] / div)
                     else:
                         losses.append(self.model.forward_backward(batch, loss_scale=1.0 / div, grad_ready=hook))
                         scaled.append(losses[-1] / div)

@@ -484,19 +484,25 @@ class Tagger:
         loss_scale * d loss into arena.g.  Returns the loss as a 0-d device tensor (no host sync).
         weights: optional f32[B] per-sentence weights replacing the 1/B of the mean (the trainer uses it to run the
         micro-batches of one gradient-accumulation group as ONE batch with weights 1/(accumulate * |micro-batch|))."""
+        return self._launch(self._forward_loss, batch, loss_scale, backward, weights, grad_ready)
+
+    def _launch(self, fn, *args):
+        """run one micro-batch's launches on the current stream, with a fresh tile-scheduling ring when the GEMMs draw their
+        tiles dynamically (data-parallel steps)"""
         with L_.stream_scope():
             if not self.dynamic_tiles:
-                return self._forward_loss(batch, loss_scale, backward, weights, grad_ready)
+                return fn(*args)
             if self._sched_ring is None:
                 self._sched_ring = torch.zeros((512, 8), dtype=I32, device=self.device)
             self._sched_ring.zero_()     # one memset per micro-batch covers its ~200 GEMM launches
             ops.sched_ring_reset(self._sched_ring)
             try:
-                return self._forward_loss(batch, loss_scale, backward, weights, grad_ready)
+                return fn(*args)
             finally:
                 ops.sched_ring_reset(None)
 
-    def _forward_loss(self, batch, loss_scale, backward, weights, grad_ready=None):
+    def _emit(self, batch):
+        """encoder -> (WordDropout) kept-token gather -> head: (em f32[B,nc,T], pooled bf16[B*nc,H], crow_idx, B, nc, R, S)"""
         B, S = batch["B"], batch["S"]
         R = batch.get("R", B)  # encoder rows (> B when long sentences were split into sliding windows)
         hidden = self.encoder_forward(batch["ids"], batch["pos_ids"], batch["maskbias"], R, S)
@@ -511,28 +517,66 @@ class Tagger:
             cpos = batch["cpos"].long()
             crow_idx = torch.where(dropped[cpos.clamp(min=0)] & (cpos >= 0), torch.full_like(crow_idx, -1), crow_idx)
         em, pooled = self.emissions(hidden, crow_idx, B, nc)
+        return em, pooled, crow_idx, B, nc, R, S
+
+    def _backprop_emissions(self, demit, pooled, crow_idx, B, nc, R, S, grad_ready):
+        """d loss / d emissions f32[B,nc,T] -> head, scatter to the encoder rows, encoder backward (all into arena.g)"""
+        a = self.arena
+        dpooled = ops.head_bwd(demit.view(B * nc, self.T), pooled, a.param("linear.weight"), a.grad("linear.weight"),
+                               a.grad("linear.bias"))
+        ac = self.acts(R, S)
+        ac.dx.zero_()
+        ops.scatter_rows(dpooled, crow_idx, ac.dx)
+        self.encoder_backward(ac.dx, grad_ready)
+
+    def _sentence_weights(self, weights, B):
+        if weights is None:
+            return torch.full((B,), 1.0 / B, dtype=F32, device=self.device)
+        w = torch.as_tensor(weights, dtype=F32, device=self.device).contiguous()
+        if w.numel() != B:
+            raise ValueError("weights must hold one value per sentence")
+        return w
+
+    def _forward_loss(self, batch, loss_scale, backward, weights, grad_ready=None):
+        em, pooled, crow_idx, B, nc, R, S = self._emit(batch)
+        self.last_emissions = em   # f32 [B, nc, T] at the kept (non-S-X) tokens: the teacher view of multi-view training
         a = self.arena
         trans = a.param("transitions")
         logz, gold, alpha = ops.crf_nll_fwd(em, trans, batch["ctags"], batch["clens"], self.start, self.stop)
-        if weights is None:
-            w = torch.full((B,), 1.0 / B, dtype=F32, device=self.device)
-        else:
-            w = torch.as_tensor(weights, dtype=F32, device=self.device).contiguous()
-            if w.numel() != B:
-                raise ValueError("weights must hold one value per sentence")
+        w = self._sentence_weights(weights, B)
         loss = torch.empty((1,), dtype=F32, device=self.device)
         ops.wdiff_sum(logz, gold, w, loss)
         if backward:
             dl = w * loss_scale
             demit = ops.crf_nll_bwd(em, trans, batch["ctags"], batch["clens"], alpha, logz, dl, self.start, self.stop,
                                     a.grad("transitions"))
-            dpooled = ops.head_bwd(demit.view(B * nc, self.T), pooled, a.param("linear.weight"), a.grad("linear.weight"),
-                                   a.grad("linear.bias"))
-            ac = self.acts(R, S)
-            ac.dx.zero_()
-            ops.scatter_rows(dpooled, crow_idx, ac.dx)
-            self.encoder_backward(ac.dx, grad_ready)
+            self._backprop_emissions(demit, pooled, crow_idx, B, nc, R, S, grad_ready)
         return loss[0]
+
+    def distill_loss(self, batch, teacher_emissions, tau, loss_scale=1.0, backward=True, weights=None, grad_ready=None):
+        """Multi-view posterior distillation (FastSequenceTagger._calculate_multi_view_loss, `distill_posterior` branch,
+        sequence_tagger_model.py:2080-2093): `batch` is the STUDENT view (the bare sentences), teacher_emissions f32[B,n_t,T] the
+        emissions of the same sentences' real tokens in the context view (a constant: the reference detaches it).  Returns
+        sum_b weights[b] * T^2 * sum_i KL(teacher || student tempered marginals) (default weights 1/B = the reference's
+        `.sum() / shape[0]`) as a 0-d device tensor and, if `backward`, accumulates loss_scale * its gradient into arena.g."""
+        return self._launch(self._distill_loss, batch, teacher_emissions, tau, loss_scale, backward, weights, grad_ready)
+
+    def _distill_loss(self, batch, te, tau, loss_scale, backward, weights, grad_ready):
+        em, pooled, crow_idx, B, nc, R, S = self._emit(batch)
+        if te.shape[0] != B or te.shape[2] != self.T:
+            raise ValueError("teacher emissions must be [B, n, T] for the same B sentences")
+        if te.shape[1] < nc:   # (a real-token count mismatch between the views is a data error; the kernel only reads < lens)
+            raise ValueError("the teacher view has fewer real tokens (%d) than the student view (%d)" % (te.shape[1], nc))
+        te = te[:, :nc].contiguous()
+        a = self.arena
+        w = self._sentence_weights(weights, B)
+        dtr = a.grad("transitions") if backward else torch.zeros((self.T, self.T), dtype=F32, device=self.device)
+        per, demit = ops.crf_posterior_kl(em, te, a.param("transitions"), batch["clens"], w * loss_scale, tau, self.start,
+                                          self.stop, dtr)
+        loss = (per * w).sum()
+        if backward:
+            self._backprop_emissions(demit, pooled, crow_idx, B, nc, R, S, grad_ready)
+        return loss
 
     def forward_features(self, batch):
         """FastSequenceTagger.forward (sequence_tagger_model.py:844): emissions for ALL word tokens."""

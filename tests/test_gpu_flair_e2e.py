@@ -539,3 +539,64 @@ def test_v2_doc_forward_on_device(workdir):
     assert feats.shape[0] == len(dl[0]) and feats.shape[1] == max(len(s) for s in dl[0]) and torch.isfinite(feats).all()
     res, loss = student.evaluate(dl, embeddings_storage_mode="none")
     assert np.isfinite(loss)
+
+
+# ------------------------------------------------------------------ G14: multi-view (cooperative-learning) training vs the reference's run
+def test_multiview_training_vs_reference_run(tmp_path):
+    """The shape of the shipped *_doc_joint_multiview_posterior_* YAMLs on the tiny paired corpora: ModelFinetuner pairs the
+    *DOC corpus with its source (`orig_sent`), and every micro-batch that carries a second view trains
+    (1 - rate) * NLL(context view) + rate * T^2 KL(posterior(context view) || posterior(sentence alone)).
+    Against tests/golden/multiview_e2e.* captured from the reference's own trainer (oracle/gen_golden_multiview_e2e.py):
+    the pairing, the sequence of NLL / KL values of the first epoch (same weights at its start), the epoch losses."""
+    import json
+    import tiny_assets
+    from flair.config_parser import ConfigParser
+    from flair.trainers import ModelFinetuner
+    from flair.utils.from_params import Params
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    ref = json.load(open(os.path.join(gold, "multiview_e2e.json"), encoding="utf-8"))
+    arrs = np.load(os.path.join(gold, "multiview_e2e.npz"))
+    cfg = tiny_assets.multiview_config(str(tmp_path), **ref["config_kwargs"])
+    with open(tmp_path / "cfg.yaml", "w") as f:
+        yaml.safe_dump(cfg, f)
+    cp = ConfigParser(Params.from_file(str(tmp_path / "cfg.yaml")))
+    assert cp.tag_dictionary.get_items() == ref["tag_dictionary"]
+    student = cp.create_student()
+    assert student.multi_view_training and student.distill_posterior and float(student.temperature) == ref["temperature"]
+    for k in ("linear.weight", "linear.bias", "transitions"):
+        student.engine.set_param(k, torch.from_numpy(arrs["init/" + k]))
+    trainer = ModelFinetuner(student, None, cp.corpus, config=cp.config, **cp.config["ModelFinetuner"])
+    # the pairing of finetune_trainer.py:316-344
+    for name, ci in trainer.corpus2id.items():
+        for part in ("train_list", "dev_list", "test_list"):
+            got = [s.orig_sent.to_tokenized_string() if hasattr(s, "orig_sent") else None for s in getattr(cp.corpus, part)[ci]]
+            assert got == ref["pairing"]["%s/%s" % (name, part)], (name, part)
+    calls = []
+    fb = student.forward_backward
+
+    def spy(data_points, *a, **k):
+        out = fb(data_points, *a, **k)
+        nll, kd = student.last_loss_parts
+        mv = kd is not None
+        rate = ref["multi_view_rate"]
+        calls.append(["nll", float(nll) / ((1.0 - rate) if mv else 1.0), [s.to_tokenized_string() for s in data_points]])
+        if mv:
+            calls.append(["kl", float(kd) / rate, [s.to_tokenized_string() for s in data_points]])
+        return out
+
+    student.forward_backward = spy
+    out = trainer.train(cp.get_target_path, fuse_accumulation=False, **cp.config["train"])
+    rc = ref["calls"]
+    assert [c[0] for c in calls] == [c[0] for c in rc], "the same micro-batches must carry a second view"
+    assert [c[2] for c in calls] == [c[2] for c in rc], "same batches, same order"
+    n_ep = len(rc) // len(ref["train_loss_history"])
+    worst_nll = max(abs(a[1] - b[1]) / abs(b[1]) for a, b in zip(calls[:n_ep], rc[:n_ep]) if a[0] == "nll")
+    kl = [(a[1], b[1]) for a, b in zip(calls[:n_ep], rc[:n_ep]) if a[0] == "kl"]
+    assert len(kl) >= 3
+    worst_kl = max(abs(a - b) / max(abs(b), 1e-4) for a, b in kl)
+    hist = max(abs(a - b) / abs(b) for a, b in zip(out["train_loss_history"], ref["train_loss_history"]))
+    print("G14 first-epoch NLL rel", worst_nll, "KL rel", worst_kl, "epoch loss rel", hist, "kl pairs", kl[:4],
+          "dev", out["dev_score_history"], ref["dev_score_history"])
+    assert worst_nll < 5e-3, (calls[:n_ep], rc[:n_ep])
+    assert worst_kl < 0.15, kl
+    assert hist < 2e-2, (out["train_loss_history"], ref["train_loss_history"])

@@ -107,6 +107,43 @@ def write_conll_corpus(folder, n_train=24, n_dev=8, n_test=8, seed=0):
     return folder
 
 
+def write_multiview_corpora(folder_plain, folder_doc, n_train=12, n_dev=4, n_test=4, seed=5):
+    """the two views of a multi-view (cooperative-learning) run, sentence k of one file being sentence k of the other: the bare
+    sentences (`token _ _ NER`) and the same sentences followed by `<EOS>` + retrieved context tagged B-X (the *DOC corpus)"""
+    rng = np.random.default_rng(seed)
+    os.makedirs(folder_plain, exist_ok=True)
+    os.makedirs(folder_doc, exist_ok=True)
+    for name, k in (("train.txt", n_train), ("dev.txt", n_dev), ("test.txt", n_test)):
+        with open(os.path.join(folder_plain, name), "w") as fp, open(os.path.join(folder_doc, name), "w") as fd:
+            for i in range(k):
+                n = int(rng.integers(3, 8))
+                words = list(rng.choice(WORDS, size=n))
+                if rng.random() < 0.9:
+                    words[int(rng.integers(0, n))] = str(rng.choice(list(ENTITIES)))
+                sent = ["%s _ _ %s" % (wd, "B-" + ENTITIES[wd] if wd in ENTITIES else "O") for wd in words]
+                ctx = ["<EOS> B-X B-X B-X"] + ["%s B-X B-X B-X" % wd for wd in rng.choice(WORDS, size=int(rng.integers(4, 10)))]
+                for f, lines in ((fp, sent), (fd, sent + ctx)):
+                    f.write("# id %s-%d\tdomain=en\n" % (name, i))
+                    f.write("\n".join(lines) + "\n\n")
+
+
+def multiview_config(d, max_epochs=3, accum=2, mini_batch_size=2, temperature=4.0, n_train=12, n_dev=4, n_test=4):
+    """e2e_config with the shape of the shipped *_doc_joint_multiview_posterior_* YAMLs: a plain corpus and its *DOC twin
+    trained jointly, multi_view_training + distill_posterior + temperature on the tagger (no dropout, no shuffling, so the
+    reference's run and the mirror's can be compared step by step)"""
+    cfg = e2e_config(d, word_dropout=0.0, max_epochs=max_epochs, shuffle=False, accum=accum, mini_batch_size=mini_batch_size,
+                     save_finetuned_embedding=False)
+    d = str(d)
+    write_multiview_corpora(os.path.join(d, "mv_plain"), os.path.join(d, "mv_doc"), n_train=n_train, n_dev=n_dev, n_test=n_test)
+    fmt = {"column_format": {0: "text", 1: "pos", 2: "upos", 3: "ner"}, "comment_symbol": "# id", "tag_to_bioes": "ner"}
+    cfg["ner"] = {"Corpus": "ColumnCorpus-TINYMV:ColumnCorpus-TINYMVDOC", "tag_dictionary": os.path.join(d, "tags_mv.pkl"),
+                  "ColumnCorpus-TINYMV": dict(fmt, data_folder=os.path.join(d, "mv_plain")),
+                  "ColumnCorpus-TINYMVDOC": dict(fmt, data_folder=os.path.join(d, "mv_doc"))}
+    cfg["model"]["FastSequenceTagger"].update(multi_view_training=True, distill_posterior=True, temperature=temperature)
+    cfg["model_name"] = "tiny_mv_run"
+    return cfg
+
+
 def e2e_config(d, word_dropout=0.1, max_epochs=6, shuffle=None, n_train=32, n_dev=8, n_test=8, accum=2, mini_batch_size=4,
                save_finetuned_embedding=True):
     """The KB-NER-shaped YAML (as a dict) of the tiny end-to-end run under directory `d`: builds the model dir + corpus files
