@@ -124,8 +124,9 @@ class ModelFinetuner:
             sel = self.model.multi_view_plan(bt) if multi_view_rate is not None else []
             f = (1.0 - multi_view_rate) if sel else 1.0
             wts += [f / (G * len(bt))] * len(bt)
-            idx += [base + k for k in sel]
-            kw += [multi_view_rate / (G * len(sel))] * len(sel)
+            if sel:
+                idx += [base + k for k in sel]
+                kw += [multi_view_rate / (G * len(sel))] * len(sel)
             base += len(bt)
         return wts, ((idx, kw) if idx else None)
 

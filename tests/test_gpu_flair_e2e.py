@@ -597,6 +597,43 @@ def test_multiview_training_vs_reference_run(tmp_path):
     hist = max(abs(a - b) / abs(b) for a, b in zip(out["train_loss_history"], ref["train_loss_history"]))
     print("G14 first-epoch NLL rel", worst_nll, "KL rel", worst_kl, "epoch loss rel", hist, "kl pairs", kl[:4],
           "dev", out["dev_score_history"], ref["dev_score_history"])
-    assert worst_nll < 5e-3, (calls[:n_ep], rc[:n_ep])
-    assert worst_kl < 0.15, kl
-    assert hist < 2e-2, (out["train_loss_history"], ref["train_loss_history"])
+    # observed on MI355X (round 2): NLL 1.5e-3, KL 2.8e-2 (a second-order small quantity, 5e-4 .. 4e-3 here, computed from bf16
+    # emissions of two different batches), epoch losses 1.6e-3, dev scores identical in all epochs; thresholds = 3x
+    assert worst_nll < 4.5e-3, (calls[:n_ep], rc[:n_ep])
+    assert worst_kl < 8.4e-2, kl
+    assert hist < 4.8e-3, (out["train_loss_history"], ref["train_loss_history"])
+    same = sum(abs(a - b) < 1e-9 for a, b in zip(out["dev_score_history"], ref["dev_score_history"]))
+    assert same >= len(ref["dev_score_history"]) - 1, (out["dev_score_history"], ref["dev_score_history"])
+
+    # the accumulation-group fusion of ModelFinetuner.train carries the second view too: one weighted batch for the group's
+    # context views + one for its bare sentences == the per-micro-batch passes summed
+    loader = ColumnDataLoaderFor(trainer, cp)
+    group = [b for b in loader if student.multi_view_plan(b)][:2] + [b for b in loader if not student.multi_view_plan(b)][:1]
+    assert len(group) == 3
+    student.forward_backward = fb
+    student.train()
+    g = student.engine.arena.g
+    g.zero_()
+    tot_un = 0.0
+    for b in group:
+        wts, mv = trainer._group_weights([b], ref["multi_view_rate"])
+        tot_un += float(student.forward_backward(b, loss_scale=1.0 / len(group), sentence_weights=wts, multi_view=mv)) / len(group)
+    g_un = g.clone()
+    g.zero_()
+    wts, mv = trainer._group_weights(group, ref["multi_view_rate"])
+    tot_f = float(student.forward_backward([s for b in group for s in b], loss_scale=1.0, sentence_weights=wts, multi_view=mv))
+    torch.cuda.synchronize()
+    assert abs(tot_f - tot_un) < 2e-2 * abs(tot_un), (tot_f, tot_un)
+    a, b = g.double(), g_un.double()
+    cos = float((a @ b) / (a.norm() * b.norm()))
+    assert cos > 0.995 and abs(float(a.norm() / b.norm()) - 1.0) < 2e-2, (cos, float(a.norm() / b.norm()))
+
+
+def ColumnDataLoaderFor(trainer, cp):
+    """the training loader ModelFinetuner.train builds (same arguments)"""
+    from flair.custom_data_loader import ColumnDataLoader
+    data = [s for ds in cp.corpus.train_list for s in ds]
+    dl = ColumnDataLoader(data, cp.config["train"]["mini_batch_size"], False, use_bert=False, model=trainer.model,
+                          sentence_level_batch=trainer.sentence_level_batch, sort_data=True)
+    dl.assign_tags(trainer.model.tag_type, trainer.model.tag_dictionary)
+    return dl
