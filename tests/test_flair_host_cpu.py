@@ -277,3 +277,44 @@ def test_get_spans_skip_class_equals_filtering():
         full = [(sp.tag, str(sp)) for sp in s.get_spans("ner") if sp.tag != "X"]
         fast = [(sp.tag, str(sp)) for sp in s.get_spans("ner", skip_class="X") if sp.tag != "X"]
         assert full == fast, (row, full, fast)
+
+
+def test_multi_view_pairing_and_weights_host_logic():
+    """ModelFinetuner's multi-view bookkeeping without a GPU: the *doc* corpus is paired with the source corpus sentence by
+    sentence (finetune_trainer.py:316-344) and an accumulation group's per-sentence weights put (1 - rate) on the NLL of the
+    micro-batches that carry a second view, rate / |paired sentences of that micro-batch| on their KL terms (:909-914,959-966)"""
+    from flair.trainers.finetune_trainer import ModelFinetuner
+
+    class S:
+        def __init__(self, name):
+            self.name = name
+
+    class Corpus:
+        targets = ["ColumnCorpus-NEWS", "ColumnCorpus-NEWSDOC"]
+        train_list = [[S("a0"), S("a1"), S("a2")], [S("d0"), S("d1"), S("d2")]]
+        dev_list = [[S("b0")], [S("e0")]]
+        test_list = [[S("c0")], [S("f0")]]
+
+    class Model:
+        multi_view_training = True
+
+        def multi_view_plan(self, batch):   # paired sentences that have context
+            return [i for i, s in enumerate(batch) if hasattr(s, "orig_sent")]
+
+    t = ModelFinetuner.__new__(ModelFinetuner)
+    t.model, t.corpus = Model(), Corpus()
+    t.corpus2id = {n: i for i, n in enumerate(Corpus.targets)}
+    t._pair_multi_view_corpora()
+    assert [s.orig_sent.name for s in Corpus.train_list[1]] == ["a0", "a1", "a2"]
+    assert Corpus.dev_list[1][0].orig_sent.name == "b0" and Corpus.test_list[1][0].orig_sent.name == "c0"
+    assert not any(hasattr(s, "orig_sent") for s in Corpus.train_list[0])
+    a, d = Corpus.train_list
+    group = [[a[0], a[1]], [d[0], a[2]], [d[1], d[2]]]            # plain, mixed, all paired
+    wts, mv = t._group_weights(group, 0.25)
+    G = 3
+    assert np.allclose(wts, [1 / (G * 2)] * 2 + [0.75 / (G * 2)] * 2 + [0.75 / (G * 2)] * 2)
+    assert mv[0] == [2, 4, 5] and np.allclose(mv[1], [0.25 / (G * 1), 0.25 / (G * 2), 0.25 / (G * 2)])
+    wts, mv = t._group_weights(group[:1], 0.25)
+    assert mv is None and np.allclose(wts, [0.5, 0.5])
+    wts, mv = t._group_weights(group, None)                        # multi-view off: the plain fused weights
+    assert mv is None and np.allclose(wts, [1 / 6] * 6)
