@@ -171,3 +171,47 @@ def test_yaml_keyword_sets_are_explicit_parameters(section):
         assert cls is not None, name
         params = _explicit_params(cls.__init__)
     assert keys <= params, sorted(keys - params)
+
+
+def test_every_shipped_yaml_block_is_accepted():
+    """tests/golden/shipped_yaml_blocks.json = the model / train / trainer / embeddings blocks of all 16 YAMLs the reference ships
+    (data extracted by oracle/gen_shipped_yaml_blocks.py).  Every key must be an explicit parameter of the mirror's constructor /
+    train() (unknown keys would only be warned about), and no key may switch on a path the mirror refuses -- except in the one ACE
+    YAML, which is inference-only here (ReinforcementTrainer.train raises; its ELMo / fastText embeddings need downloads)."""
+    import inspect
+    import json
+    import flair.embeddings as E
+    from flair.models.sequence_tagger_model import _UNSUPPORTED_TRUE, FastSequenceTagger
+    from flair.trainers import ModelFinetuner, ReinforcementTrainer
+    blocks = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "shipped_yaml_blocks.json")))
+    assert len(blocks) == 16
+    refused_train = ("use_amp", "use_autocast", "rootschedule", "freezing", "use_unlabeled_data", "unlabeled_data_for_zeroshot",
+                     "gold_reward", "language_attention_warmup", "language_attention_warmup_and_fix")
+    n_finetune = n_multiview = 0
+    for name, b in blocks.items():
+        ace = b["trainer"] == "ReinforcementTrainer"
+        cls = {"ModelFinetuner": ModelFinetuner, "ReinforcementTrainer": ReinforcementTrainer}[b["trainer"]]
+        init_p = set(inspect.signature(cls.__init__).parameters)
+        assert set(b["trainer_block"]) <= init_p, (name, sorted(set(b["trainer_block"]) - init_p))
+        assert not any(b["trainer_block"].get(k) for k in ("distill_mode", "ensemble_distill_mode", "train_with_professor")), name
+        (mcls, mkw), = b["model"].items()
+        assert mcls == "FastSequenceTagger"
+        mp = set(inspect.signature(FastSequenceTagger.__init__).parameters)
+        assert set(mkw) <= mp, (name, sorted(set(mkw) - mp))
+        assert not [k for k in mkw if k in _UNSUPPORTED_TRUE and mkw[k]], name
+        if mkw.get("multi_view_training"):
+            assert mkw.get("distill_posterior") and mkw.get("remove_x") and not mkw.get("use_rnn"), name   # the implemented form
+            n_multiview += 1
+        for ekey, ekw in b["embeddings"].items():
+            ecls = getattr(E, ekey.split("-")[0], None)
+            assert ecls is not None, (name, ekey)
+            ep = set(inspect.signature(ecls.__init__).parameters)
+            assert set(ekw or {}) <= ep, (name, ekey, sorted(set(ekw or {}) - ep))
+        if ace:
+            continue
+        n_finetune += 1
+        tp = set(inspect.signature(ModelFinetuner.train).parameters)
+        assert set(b["train"]) <= tp, (name, sorted(set(b["train"]) - tp))
+        assert not [k for k in refused_train if b["train"].get(k)], name
+        assert list(b["embeddings"]) == ["TransformerWordEmbeddings-0"] and not mkw.get("use_rnn"), name
+    assert n_finetune == 15 and n_multiview == 3
