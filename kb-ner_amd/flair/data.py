@@ -175,6 +175,91 @@ class Span:
 _BIOES = ("B-", "I-", "O-", "E-", "S-")
 
 
+def span_tables(items: List[str]):
+    """per tag id of a tag dictionary: (prefix code, class id) under get_spans' normalisation ('' / 'O' -> outside, a bare class
+    name -> a single-token span), + the class names.  Prefix codes: 0 O, 1 B, 2 I, 3 E, 4 S."""
+    import numpy as np
+    code = {"O-": 0, "B-": 1, "I-": 2, "E-": 3, "S-": 4}
+    pref, cls, names = [], [], []
+    for val in items:
+        if val in ("", "O"):
+            val = "O-"
+        if val[:2] not in _BIOES:
+            val = "S-" + val
+        pref.append(code[val[:2]])
+        c = val[2:]
+        if c not in names:
+            names.append(c)
+        cls.append(names.index(c))
+    return np.asarray(pref, np.int8), np.asarray(cls, np.int32), names
+
+
+def batch_spans(sentences, ids, scores, tables, min_score: float = -1, skip_class: str = None, drop_flags=None):
+    """Sentence.get_spans for a whole batch from TAG-ID arrays instead of per-token Label objects: ids int[B, n] (tag ids of
+    `tables`' dictionary; columns >= len(sentence) ignored), scores float[B, n] or None (= 1.0).  Returns, per sentence, the
+    same Span list get_spans(tag_type, min_score, skip_class, drop_touching) returns for tokens carrying those tags
+    (drop_flags bool[B, n]: token positions whose presence drops a span).  The segmentation rule of flair/data.py:455-532 --
+    a span is a maximal run of non-O tokens, cut before every B- / S- token and before a token that follows an S- of another
+    class -- is evaluated with numpy over the flattened batch; Python only touches the spans that survive the filters, which
+    is what makes evaluate() cheap on sentences that are 95 % single-token S-X context."""
+    import numpy as np
+    pref_t, cls_t, names = tables
+    ids = np.asarray(ids)
+    B, n = ids.shape
+    lens = np.asarray([len(s) for s in sentences], np.int64)
+    n1 = n + 1                                       # one outside column per row: spans never run across rows
+    valid = np.zeros((B, n1), bool)
+    valid[:, :n] = np.arange(n)[None, :] < lens[:, None]
+    pref = np.zeros((B, n1), np.int8)
+    cls = np.full((B, n1), -1, np.int32)
+    pref[:, :n] = np.where(valid[:, :n], pref_t[ids], 0)
+    cls[:, :n] = np.where(valid[:, :n], cls_t[ids], -1)
+    inside = (pref != 0).ravel()
+    pref, cls = pref.ravel(), cls.ravel()
+    prev_pref = np.concatenate(([0], pref[:-1]))
+    prev_cls = np.concatenate(([-1], cls[:-1]))
+    prev_inside = np.concatenate(([False], inside[:-1]))
+    opens = (pref == 1) | (pref == 4) | ((prev_pref == 4) & (prev_cls != cls) & inside)
+    starts = inside & (opens | ~prev_inside)
+    spos = np.flatnonzero(starts)
+    out = [[] for _ in range(B)]
+    if spos.size == 0:
+        return out
+    bpos = np.flatnonzero(starts | ~inside)          # where a running span ends (exclusive)
+    epos = bpos[np.searchsorted(bpos, spos, side="right")]
+    length = epos - spos
+    keep = np.ones(spos.size, bool)
+    if skip_class is not None and skip_class in names:
+        keep &= ~((length == 1) & (cls[spos] == names.index(skip_class)))       # (longer spans: voted class, decided below)
+    if drop_flags is not None:
+        fl = np.zeros((B, n1), np.int64)
+        fl[:, :n] = np.asarray(drop_flags, bool)
+        cs = np.concatenate(([0], np.cumsum(fl.ravel())))
+        keep &= (cs[epos] - cs[spos]) == 0
+    if scores is not None:
+        scores = np.asarray(scores)
+    for s0, e0 in zip(spos[keep].tolist(), epos[keep].tolist()):
+        b, i0 = divmod(s0, n1)
+        i1 = i0 + (e0 - s0)
+        if e0 - s0 == 1:
+            best = names[cls[s0]]
+        else:
+            votes: Dict[str, float] = defaultdict(float)
+            for j in range(s0, e0):
+                votes[names[cls[j]]] += 1.1 if opens[j] else 1.0
+            best = sorted(votes.items(), key=lambda kv: kv[1], reverse=True)[0][0]
+            if skip_class is not None and best == skip_class:
+                continue
+        mean = 1.0
+        if scores is not None:
+            # the same float arithmetic as get_spans: python sum of the token scores / count
+            vals = [float(x) for x in scores[b, i0:i1]]
+            mean = sum(vals) / len(vals)
+        if mean > min_score:
+            out[b].append(Span(sentences[b].tokens[i0:i1], tag=best, score=mean))
+    return out
+
+
 class Sentence:
     """A list of Tokens (+ sentence-level labels).  `Sentence("a b c")` splits on whitespace."""
 

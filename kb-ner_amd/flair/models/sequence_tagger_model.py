@@ -442,11 +442,13 @@ class SequenceTagger(flair.nn.Model):
         B, n, T = features.shape
         flat = features.reshape(B * n, T).contiguous()
         nc = hb["ctags"].shape[1]
-        idx = torch.from_numpy(_compact_index(hb["keep"], nc)).to(features.device)
-        gathered = ops.gather_rows_f32(flat, idx)
+        # (compaction index and keep mask travelled with the batch: no host->device copy here, which would block the host until
+        # the forward pass has drained and serialise evaluate()'s host / device pipeline)
+        gathered = ops.gather_rows_f32(flat, db["cfeat_idx"])
         logz, gold, _ = ops.crf_nll_fwd(gathered.view(B, nc, T).contiguous(), self.transitions, db["ctags"],
                                         db["clens"], self.start_idx, self.stop_idx)
-        self.mask = torch.from_numpy(hb["keep"].astype(np.float32)).to(features.device)
+        self.mask = db["keep_f"]
+        self._last_compact = gathered.view(B, nc, T)
         return (logz - gold).mean()
 
     def _obtain_labels(self, feature, sentences, get_all_tags: bool = False):
@@ -515,45 +517,34 @@ class SequenceTagger(flair.nn.Model):
     def evaluate(self, data_loader, out_path: Path = None, embeddings_storage_mode: str = "cpu", prediction_mode=False,
                  speed_test=False):
         """sequence_tagger_model.py:2593-2729.  Under speed_test only forward + decode run (no loss, so self.mask keeps ALL
-        tokens and Viterbi decodes the context too; no prediction lines, no metric) -- as in the reference."""
+        tokens and Viterbi decodes the context too; no prediction lines, no metric) -- as in the reference.
+
+        Host / device pipeline: batch k+1's encoder + loss + Viterbi are ENQUEUED (with the device->host copy of its tags into
+        pinned memory) before batch k's labels, prediction lines, spans and metric are built on the host, so the two overlap;
+        spans come from tag-id arrays (flair.data.batch_spans), not from per-token Label objects -- a KB-NER sentence is
+        ~95 % single-token S-X context that the remove_x rule discards anyway."""
         import time
+        from flair.data import span_tables
         eval_loss, batch_no = 0.0, 0
         metric = Metric("Evaluation")
         outfile = open(out_path, "w", encoding="utf-8") if out_path is not None else None
+        env = {"items": self.tag_dictionary.get_items(), "metric": metric, "outfile": outfile, "speed_test": speed_test}
+        env["tables"] = span_tables(env["items"])
+        env["x_id"] = env["items"].index("S-X") if "S-X" in env["items"] else None
+        env["unk_id"] = env["items"].index("<unk>") if "<unk>" in env["items"] else None
         t0 = time.time()
         try:
+            pending = None
             for batch in data_loader:
                 batch_no += 1
-                features = self.forward(batch, prediction_mode=prediction_mode)
-                if not speed_test:
-                    loss = self._calculate_loss(features, batch, self.mask)
-                tags, _ = self._obtain_labels(features, batch)
-                if not speed_test:
-                    eval_loss += float(loss)
-                    for sentence, sent_tags in zip(batch, tags):
-                        for token, tag in zip(sentence.tokens, sent_tags):
-                            token.add_tag_label("predicted", tag)
-                            if outfile is not None:
-                                outfile.write("{} {} {} {}\n".format(token.text, token.get_tag(self.tag_type).value, tag.value,
-                                                                     tag.score))
-                        if outfile is not None:
-                            outfile.write("\n")
-                    for sentence in batch:
-                        if self.remove_x:
-                            # :2653-2672: a predicted span is dropped iff it contains a token whose GOLD tag is exactly 'S-X'
-                            # (predicted X-class spans on other tokens stay and count as false positives); gold spans of class
-                            # X are dropped.  Both filters run inside get_spans so the context tokens never become Spans.
-                            gold = [(s.tag, str(s)) for s in sentence.get_spans(self.tag_type, skip_class="X")]
-                            pred = [(s.tag, str(s)) for s in sentence.get_spans("predicted",
-                                                                               drop_touching=self._gold_x_token_ids(sentence))]
-                        else:
-                            gold = [(s.tag, str(s)) for s in sentence.get_spans(self.tag_type)]
-                            pred = [(s.tag, str(s)) for s in sentence.get_spans("predicted")]
-                        for tag, span in pred:
-                            (metric.add_tp if (tag, span) in gold else metric.add_fp)(tag)
-                        for tag, span in gold:
-                            (metric.add_fn if (tag, span) not in pred else metric.add_tn)(tag)
-                store_embeddings(batch, embeddings_storage_mode)
+                st = self._eval_enqueue(batch, prediction_mode, speed_test)
+                if pending is not None:
+                    eval_loss += self._eval_finish(pending[0], pending[1], env)
+                    store_embeddings(pending[0], embeddings_storage_mode)
+                pending = (batch, st)
+            if pending is not None:
+                eval_loss += self._eval_finish(pending[0], pending[1], env)
+                store_embeddings(pending[0], embeddings_storage_mode)
         finally:
             if outfile is not None:
                 outfile.close()
@@ -572,6 +563,121 @@ class SequenceTagger(flair.nn.Model):
                                                                                            metric.micro_avg_f_score()),
                         log_header="PRECISION\tRECALL\tF1", detailed_results=detailed, macro_score=metric.macro_avg_f_score())
         return result, eval_loss
+
+    def _eval_enqueue(self, batch, prediction_mode, speed_test):
+        """device half of one evaluate() batch: everything is enqueued, nothing is waited for"""
+        from kbner import ops
+        features = self.forward(batch, prediction_mode=prediction_mode)
+        last = getattr(self, "_last", None)
+        if last is None or features is None or getattr(self, "use_rnn", False) or getattr(self, "predict_posterior", False):
+            # posterior decoding, the stacked-embedding tagger (and test doubles that replace forward / _obtain_labels): the
+            # generic synchronous path, labels -> per-token spans
+            loss = None if speed_test else self._calculate_loss(features, batch, self.mask)
+            return {"labels": self._obtain_labels(features, batch)[0], "loss": loss}
+        hb, db = last
+        B, n, T = features.shape
+        loss = None
+        if not speed_test:
+            loss = self._calculate_loss(features, batch, self.mask)       # narrows self.mask to the non-S-X tokens
+            keep = hb["keep"]
+            lens, nc = hb["clens"], hb["ctags"].shape[1]
+            comp, lens_d = self._last_compact.contiguous(), db["clens"]   # the kept rows the loss just gathered
+        else:
+            keep = np.arange(n)[None, :] < np.asarray([len(s) for s in batch])[:, None]
+            lens, nc = keep.sum(1).astype(np.int32), n
+            comp, lens_d = features.contiguous(), db["lengths"]           # every token is decoded (:2612-2622)
+        tags, conf = ops.crf_viterbi(comp, self.transitions, lens_d, self.start_idx, self.stop_idx)
+        tags_h = torch.empty(tags.shape, dtype=tags.dtype, pin_memory=True)
+        conf_h = torch.empty(conf.shape, dtype=conf.dtype, pin_memory=True)
+        tags_h.copy_(tags, non_blocking=True)
+        conf_h.copy_(conf, non_blocking=True)
+        loss_h = None
+        if loss is not None:
+            loss_h = torch.empty((), dtype=torch.float32, pin_memory=True)
+            loss_h.copy_(loss.detach().float().reshape(()), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return {"tags": tags_h, "conf": conf_h, "loss_h": loss_h, "event": ev, "keep": keep, "lens": lens, "hb": hb, "nc": nc}
+
+    def _eval_finish(self, batch, st, env):
+        """host half: labels on every token, prediction lines, spans, metric.  Returns this batch's loss (0.0 under speed_test)."""
+        from flair.data import batch_spans
+        items, outfile = env["items"], env["outfile"]
+        loss_val = 0.0
+        fast = False
+        if "labels" in st:       # labels were built synchronously (see _eval_enqueue)
+            all_labels = st["labels"]
+            if st["loss"] is not None:
+                loss_val = float(st["loss"])
+        else:
+            keep, hb = st["keep"], st["hb"]
+            B, n = keep.shape
+            st["event"].synchronize()
+            tags, conf, lens = st["tags"].numpy(), st["conf"].numpy(), st["lens"]
+            if st["loss_h"] is not None:
+                loss_val = float(st["loss_h"])
+            x_id = env["x_id"] if env["x_id"] is not None else 0
+            # the reference re-pads around the decoded tags with S-X / the INTEGER confidence 1: `before` = the first kept
+            # position, the k decoded tags follow contiguously, S-X up to the sentence length (:1202-1208)
+            first = np.where(keep.any(1), keep.argmax(1), 0)
+            col = np.arange(n)[None, :]
+            sel = (col >= first[:, None]) & (col < (first + lens)[:, None])
+            valid_c = np.arange(st["nc"])[None, :] < lens[:, None]
+            pred_ids = np.full((B, n), x_id, np.int64)
+            pred_sc = np.ones((B, n), np.float32)
+            pred_ids[sel] = tags[valid_c]
+            pred_sc[sel] = conf[valid_c]
+            x_label = Label("S-X", 1)      # ONE object for every padded token of the batch (a Label is a value)
+            all_labels = []
+            for b, s in enumerate(batch):
+                L, k, f = len(s), int(lens[b]), int(first[b])
+                if k >= L:
+                    row = [Label(items[t], float(c)) for t, c in zip(tags[b, :k], conf[b, :k])]
+                else:
+                    row = [x_label] * f + [Label(items[t], float(c)) for t, c in zip(tags[b, :k], conf[b, :k])] + \
+                          [x_label] * (L - f - k)
+                all_labels.append(row)
+        if env["speed_test"]:
+            return 0.0
+        tag_type = self.tag_type
+        for sentence, sent_tags in zip(batch, all_labels):
+            for token, tag in zip(sentence.tokens, sent_tags):
+                token.add_tag_label("predicted", tag)
+            if outfile is not None:
+                outfile.write("".join("{} {} {} {}\n".format(token.text, token.get_tag(tag_type).value, tag.value, tag.score)
+                                      for token, tag in zip(sentence.tokens, sent_tags)) + "\n")
+        if "labels" not in st:
+            gold_ids = hb["tags"]
+            # (a gold tag missing from the dictionary maps to <unk> in the id row: then the per-token string path below decides)
+            in_len = np.arange(n)[None, :] < np.asarray([len(s) for s in batch])[:, None]
+            fast = gold_ids.shape == keep.shape and not (env["unk_id"] is not None and
+                                                         bool(((gold_ids == env["unk_id"]) & in_len).any()))
+        if fast:
+            if self.remove_x:
+                # :2653-2672: a predicted span is dropped iff it contains a token whose GOLD tag is exactly 'S-X' (predicted
+                # X-class spans on other tokens stay and count as false positives); gold spans of class X are dropped
+                gx = (gold_ids == env["x_id"]) if env["x_id"] is not None else np.zeros_like(keep)
+                gold_sp = batch_spans(batch, gold_ids, None, env["tables"], skip_class="X")
+                pred_sp = batch_spans(batch, pred_ids, pred_sc, env["tables"], drop_flags=gx)
+            else:
+                gold_sp = batch_spans(batch, gold_ids, None, env["tables"])
+                pred_sp = batch_spans(batch, pred_ids, pred_sc, env["tables"])
+        metric = env["metric"]
+        for b, sentence in enumerate(batch):
+            if fast:
+                gold = [(s.tag, str(s)) for s in gold_sp[b]]
+                pred = [(s.tag, str(s)) for s in pred_sp[b]]
+            elif self.remove_x:
+                gold = [(s.tag, str(s)) for s in sentence.get_spans(tag_type, skip_class="X")]
+                pred = [(s.tag, str(s)) for s in sentence.get_spans("predicted", drop_touching=self._gold_x_token_ids(sentence))]
+            else:
+                gold = [(s.tag, str(s)) for s in sentence.get_spans(tag_type)]
+                pred = [(s.tag, str(s)) for s in sentence.get_spans("predicted")]
+            for tag, span in pred:
+                (metric.add_tp if (tag, span) in gold else metric.add_fp)(tag)
+            for tag, span in gold:
+                (metric.add_fn if (tag, span) not in pred else metric.add_tn)(tag)
+        return loss_val
 
     def predict(self, sentences, mini_batch_size=32, embedding_storage_mode="none"):
         from flair.custom_data_loader import BatchedData

@@ -58,18 +58,20 @@ def assemble(input_ids, attention_mask, first_idx, tags, lengths, x_idx, pad_id=
     crow = np.full((B, nc), -1, np.int32)
     ctags = np.zeros((B, nc), np.int32)
     cpos = np.full((B, nc), -1, np.int32)       # word-token position of each compacted row (WordDropout drops positions)
+    cfeat = np.full((B, nc), -1, np.int32)      # row of the [B * n, T] all-token emissions each compacted row comes from
     for b in range(B):
         k = np.nonzero(keep[b])[0]
         crow[b, :len(k)] = row_idx[b, k]
         ctags[b, :len(k)] = tags[b, k]
         cpos[b, :len(k)] = k
-    return dict(B=B, R=R, S=S, ids=ids_f, pos_ids=pos_f, maskbias=maskbias, row_idx=row_idx.reshape(-1), lengths=lengths.astype(np.int32),
+        cfeat[b, :len(k)] = b * n + k
+    return dict(cfeat_idx=cfeat.reshape(-1), keep_f=keep.astype(np.float32), B=B, R=R, S=S, ids=ids_f, pos_ids=pos_f, maskbias=maskbias, row_idx=row_idx.reshape(-1), lengths=lengths.astype(np.int32),
                 tags=tags.astype(np.int32), keep=keep, crow_idx=crow.reshape(-1), ctags=ctags, clens=clens,
                 cpos=cpos.reshape(-1), n_tokens=n,
                 input_ids=ids, attention_mask=am, first_idx=first_idx)
 
 
-_DEVICE_KEYS = ("ids", "pos_ids", "maskbias", "row_idx", "lengths", "tags", "crow_idx", "ctags", "clens", "cpos")
+_DEVICE_KEYS = ("ids", "pos_ids", "maskbias", "row_idx", "lengths", "tags", "crow_idx", "ctags", "clens", "cpos", "cfeat_idx", "keep_f")
 
 
 def to_device(batch, device="cuda"):

@@ -318,3 +318,39 @@ def test_multi_view_pairing_and_weights_host_logic():
     assert mv is None and np.allclose(wts, [0.5, 0.5])
     wts, mv = t._group_weights(group, None)                        # multi-view off: the plain fused weights
     assert mv is None and np.allclose(wts, [1 / 6] * 6)
+
+
+def test_batch_spans_equals_get_spans_on_random_tag_sequences():
+    """flair.data.batch_spans (numpy over tag-id arrays, what evaluate() uses) == Sentence.get_spans (the reference's per-token
+    rule, flair/data.py:455-532) on random tag sequences: malformed BIOES (I- after O, E- without B-, S- followed by I- of the
+    same / another class), long runs of single-token S-X context, bare class names, both remove_x filters, min_score."""
+    from flair.data import Label, Sentence, batch_spans, span_tables
+    rng = np.random.default_rng(7)
+    items = ["<unk>", "O", "B-PER", "I-PER", "E-PER", "S-PER", "B-LOC", "I-LOC", "E-LOC", "S-LOC", "S-X", "B-X", "MISC", "<START>", "<STOP>"]
+    tbl = span_tables(items)
+    for trial in range(60):
+        B = int(rng.integers(1, 6))
+        n = int(rng.integers(1, 40))
+        lens = rng.integers(1, n + 1, size=B)
+        lens[0] = n
+        p = np.ones(len(items))
+        p[1] = 4.0
+        p[10] = 6.0 if trial % 2 else 1.0          # S-X-heavy in half of the trials
+        ids = rng.choice(len(items), size=(B, n), p=p / p.sum())
+        scores = np.round(rng.uniform(0.2, 1.0, size=(B, n)), 3)
+        sents = []
+        for b in range(B):
+            s = Sentence(" ".join("w%d" % i for i in range(int(lens[b]))))
+            for i, tok in enumerate(s.tokens):
+                tok.add_tag_label("t", Label(items[ids[b, i]], float(scores[b, i])))
+            sents.append(s)
+        drop = rng.random((B, n)) < 0.15
+        for kw_fast, kw_ref in ((dict(), dict()), (dict(skip_class="X"), dict(skip_class="X")), (dict(min_score=0.6), dict(min_score=0.6)),
+                                (dict(drop_flags=drop), None)):
+            got = batch_spans(sents, ids, scores, tbl, **kw_fast)
+            for b, s in enumerate(sents):
+                if kw_ref is None:
+                    ref = s.get_spans("t", drop_touching=set((np.nonzero(drop[b, :len(s)])[0] + 1).tolist()))
+                else:
+                    ref = s.get_spans("t", **kw_ref)
+                assert [(x.tag, str(x), x.score) for x in got[b]] == [(x.tag, str(x), x.score) for x in ref], (trial, b, kw_fast)

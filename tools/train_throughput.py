@@ -87,6 +87,10 @@ def main():
         tagger.eval()
         tagger.evaluate(dl)
         torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tagger.evaluate(dl)
+        torch.cuda.synchronize()
+        print("evaluate (no profiler): %.1f sentences/s" % (a.sentences / (time.perf_counter() - t0)))
         import cProfile
         import pstats
         pr = cProfile.Profile()
