@@ -1000,16 +1000,6 @@ static int set_lds(const void* f, int bytes) {
 
 #define AT_LDS_BYTES (2 * AT_MAXS * 128 + 3 * AT_MAXS * 4)
 
-// KBNER_ATTN_V1=1 (experiments / A-B measurements only): keep the 16-row kernels
-static bool at_force_v1() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("KBNER_ATTN_V1");
-    v = (e != nullptr && e[0] == '1') ? 1 : 0;
-  }
-  return v == 1;
-}
-
 // rows per workgroup: the whole head (one DMA of each panel per head) when the grid still covers the
 // chip several times over, otherwise smaller row tiles so small batches spread over more CUs
 static inline int pick_rpw(int B, int S, int A) {
@@ -1055,7 +1045,7 @@ static int launch_attn_bwd(const bf16_t* qkv, const bf16_t* ctx, const bf16_t* d
   if (rpw < 16 * AT_NWB) rpw = 16 * AT_NWB;  // every wave owns at least one 16-row pass
   const dim3 grid((S + rpw - 1) / rpw, A, B);
   // 32-row-stationary kernels whenever a workgroup's row tile gives each of its 8 waves whole 32-row passes
-  if (rpw % 256 == 0 && S % 32 == 0 && !at_force_v1()) {
+  if (rpw % 256 == 0 && S % 32 == 0) {
     static bool once2 = false;
     if (!once2) {
       int r = set_lds(reinterpret_cast<const void*>(attn_bwd_dq2_kernel<DROP>), AT_LDS_BYTES);
