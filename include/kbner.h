@@ -196,6 +196,16 @@ int kbner_grad_sqnorm(const float* g, size_t n, float* ws, float* out, int accum
 int kbner_adamw_hf(float* p, float* g, float* m, float* v, kbner_bf16* shadow, size_t n, size_t n_shadow, float step_size,
                    float lr_wd, float b1, float b2, float eps, const float* gnorm_sq, float max_norm, float grad_scale,
                    int zero_grad, void* stream);
+/* The same update restricted to the rows of an embedding table that have ever received a gradient (flags u8[rows], set by
+   kbner_mark_rows from the looked-up ids): an unflagged row has g = m = v = 0, so with weight decay 0 HF AdamW leaves it
+   unchanged and it is not read.  (The reference's dense optimizer.step() walks all 250 002 rows of XLM-R's word embedding,
+   46 % of the parameters, finetune_trainer.py:1018.)  kbner_grad_sqnorm_rows is the clip norm's share of those rows. */
+int kbner_mark_rows(const int* ids, int n, unsigned char* flags, int rows, void* stream);
+int kbner_grad_sqnorm_rows(const float* g, const unsigned char* flags, int rows, int width, float* ws, float* out, int accumulate,
+                           void* stream);
+int kbner_adamw_hf_rows(float* p, float* g, float* m, float* v, const unsigned char* flags, int rows, int width, float step_size,
+                        float b1, float b2, float eps, const float* gnorm_sq, float max_norm, float grad_scale, int zero_grad,
+                        void* stream);
 int kbner_f32_to_bf16(const float* x, kbner_bf16* y, size_t n, void* stream);
 int kbner_bf16_to_f32(const kbner_bf16* x, float* y, size_t n, void* stream); /* n % 4 == 0 */
 int kbner_wdiff_sum(const float* a, const float* b, const float* w, int n, float* out, void* stream);

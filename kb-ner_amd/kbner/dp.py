@@ -137,8 +137,10 @@ class GradReducer:
     The result is the SUM over ranks in arena.g; the 1/W is applied by the AdamW kernel (grad_scale).  With world_size 1
     everything is a no-op."""
 
-    def __init__(self, arena_g, emb_range=None, emb_width=None, sparse_threshold=0.5, compress_embedding=False, row_ops=None):
+    def __init__(self, arena_g, emb_range=None, emb_width=None, sparse_threshold=0.5, compress_embedding=False, row_ops=None,
+                 emb_flags=None):
         self.g = arena_g
+        self.emb_flags = emb_flags          # u8[V] "row has received a gradient" flags of the optimizer (kbner.engine.Arena)
         self.emb_range = emb_range          # (lo, hi) element range of emb.word inside the arena, or None
         self.emb_width = emb_width
         self.sparse_threshold = sparse_threshold
@@ -213,6 +215,8 @@ class GradReducer:
             rows = self.ops.gather_rows(g2, idx)
             dist.all_reduce(rows, op=dist.ReduceOp.SUM)
             self.ops.scatter_rows(rows, idx, g2)
+            if self.emb_flags is not None:      # rows other ranks touched now carry a gradient here too
+                self.emb_flags[idx.long()] = 1
             self.stats["emb_rows"] = int(idx.numel())
             self.stats["bytes_tail"] += 4 * H * int(idx.numel())
         elif self.compress_embedding:
@@ -225,6 +229,8 @@ class GradReducer:
             mode = "dense"
             dist.all_reduce(self.g[lo:hi], op=dist.ReduceOp.SUM)
             self.stats["bytes_tail"] += 4 * (hi - lo)
+        if mode != "sparse" and self.emb_flags is not None:
+            self.emb_flags.fill_(1)             # dense exchange: any row may have received a gradient from another rank
         self.stats["emb_mode"] = mode
 
     def finish(self):
@@ -236,6 +242,8 @@ class GradReducer:
         if self.emb_range is not None:
             self._exchange_embedding()
             skip.append(tuple(self.emb_range))
+        elif self.emb_flags is not None:
+            self.emb_flags.fill_(1)             # the whole arena is reduced densely: every row may carry a gradient now
         for lo, hi in self._complement(skip):
             dist.all_reduce(self.g[lo:hi], op=dist.ReduceOp.SUM)
             self.stats["bytes_tail"] += 4 * (hi - lo)

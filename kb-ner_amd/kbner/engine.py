@@ -87,6 +87,11 @@ class Arena:
         self.m = None
         self.v = None
         self.shadow = torch.zeros(max(self.n_shadow, 8), dtype=BF16, device=device)
+        # u8[V]: word-embedding rows that have ever received a gradient (set by the embedding backward and by the data-parallel
+        # row exchange).  The optimizer skips the others: their g, m, v are exactly 0 (FusedAdamW.step).
+        self.emb_flags = None
+        if with_grad and "emb.word" in self.shapes:
+            self.emb_flags = torch.zeros(self.shapes["emb.word"][0], dtype=torch.uint8, device=device)
 
     def _view(self, buf, name):
         off, shape = self.offsets[name], self.shapes[name]
@@ -459,6 +464,8 @@ class Tagger:
             dx = ac.dx
         ops.embed_ln_bwd(dx, ac.h0, ac.emb_mean, ac.emb_rstd, a.param("emb.ln.g"), ids, pos_ids, a.grad("emb.ln.g"),
                          a.grad("emb.ln.b"), a.grad("emb.word"), a.grad("emb.pos"), a.grad("emb.type")[0], drop=d_emb)
+        if a.emb_flags is not None:
+            ops.mark_rows(ids, a.emb_flags)
 
     def _wgrads(self, pairs, Mp):
         a = self.arena
@@ -605,6 +612,7 @@ class FusedAdamW:
         self.ws = torch.zeros(L.load().kbner_sqnorm_ws_floats(), dtype=F32, device=arena.device)
         self.norm_sq = torch.zeros(1, dtype=F32, device=arena.device)
         self.split = arena.offsets["transitions"]
+        self.sparse_embedding = True   # skip word-embedding rows that never received a gradient (exact; see step())
 
     def state_dict(self):
         """what a resume needs (the reference stores optimizer.state_dict(), finetune_trainer.py:1261-1277): the step count and
@@ -620,6 +628,11 @@ class FusedAdamW:
         a.m.copy_(sd["m"].to(a.device))
         a.v.copy_(sd["v"].to(a.device))
         self.t = int(sd["t"])
+        if a.emb_flags is not None:
+            # a row is live iff it has ever received a gradient, i.e. iff its second moment is not identically zero
+            lo = a.offsets["emb.word"]
+            V, H = a.shapes["emb.word"]
+            a.emb_flags.copy_((a.v[lo:lo + V * H].view(V, H) != 0).any(1).to(torch.uint8))
 
     def lr_lambda(self):
         if self.t_total is None:
@@ -634,10 +647,29 @@ class FusedAdamW:
         self.t += 1
         b1, b2 = self.betas
         bc = math.sqrt(1.0 - b2 ** self.t) / (1.0 - b1 ** self.t)
-        ops.grad_sqnorm(a.g, self.ws, self.norm_sq)
         s = self.split
-        for lo, hi, lr in ((0, s, self.lr * lam), (s, a.n, self.lr * self.lr_rate * lam)):
+        # the word-embedding table (46 % of XLM-R's parameters) is updated row-sparsely: rows that never received a gradient
+        # have g = m = v = 0 and, with weight decay 0, HF AdamW leaves them where they are -- they are not read at all
+        sparse = self.sparse_embedding and a.emb_flags is not None and self.wd == 0.0
+        if sparse:
+            e0 = a.offsets["emb.word"]
+            V, H = a.shapes["emb.word"]
+            e1 = e0 + V * H
+            rows = lambda buf: buf[e0:e1].view(V, H)   # noqa: E731
+            ops.grad_sqnorm(a.g[:e0], self.ws, self.norm_sq)
+            ops.grad_sqnorm_rows(rows(a.g), a.emb_flags, self.ws, self.norm_sq, accumulate=True)
+            ops.grad_sqnorm(a.g[e1:], self.ws, self.norm_sq, accumulate=True)
+            ranges = ((0, e0, self.lr * lam), (e1, s, self.lr * lam), (s, a.n, self.lr * self.lr_rate * lam))
+        else:
+            ops.grad_sqnorm(a.g, self.ws, self.norm_sq)
+            ranges = ((0, s, self.lr * lam), (s, a.n, self.lr * self.lr_rate * lam))
+        for lo, hi, lr in ranges:
+            if hi <= lo:
+                continue
             nsh = min(a.n_shadow, hi) - lo if lo < a.n_shadow else 0
             ops.adamw(a.p[lo:hi], a.g[lo:hi], a.m[lo:hi], a.v[lo:hi], a.shadow[lo:] if nsh > 0 else None, max(nsh, 0),
                       lr * bc, lr * self.wd, b1, b2, self.eps, self.norm_sq, self.max_norm, grad_scale, True)
+        if sparse:
+            ops.adamw_rows(rows(a.p), rows(a.g), rows(a.m), rows(a.v), a.emb_flags, self.lr * lam * bc, b1, b2, self.eps,
+                           self.norm_sq, self.max_norm, grad_scale, True)
         return self.norm_sq

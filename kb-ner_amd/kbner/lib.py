@@ -52,6 +52,9 @@ SIGNATURES = {
     "kbner_lstm_step": (c_int, [P, c_int, P, P, P, P, P, P, c_int, c_int, P, c_int, c_int, c_int, P]),
     "kbner_sqnorm_ws_floats": (c_int, []),
     "kbner_grad_sqnorm": (c_int, [P, c_size_t, P, P, c_int, P]),
+    "kbner_mark_rows": (c_int, [P, c_int, P, c_int, P]),
+    "kbner_grad_sqnorm_rows": (c_int, [P, P, c_int, c_int, P, P, c_int, P]),
+    "kbner_adamw_hf_rows": (c_int, [P, P, P, P, P, c_int, c_int, c_float, c_float, c_float, c_float, P, c_float, c_float, c_int, P]),
     "kbner_adamw_hf": (c_int, [P, P, P, P, P, c_size_t, c_size_t, c_float, c_float, c_float, c_float, c_float, P, c_float,
                                c_float, c_int, P]),
     "kbner_f32_to_bf16": (c_int, [P, P, c_size_t, P]),

@@ -361,6 +361,28 @@ def adamw(p, g, m, v, shadow, n_shadow, step_size, lr_wd, b1, b2, eps, gnorm_sq,
            ptr(gnorm_sq), max_norm, grad_scale, 1 if zero_grad else 0, stream_ptr())
 
 
+U8 = torch.uint8
+
+
+def mark_rows(ids, flags):
+    """flags u8[rows]: flags[ids[i]] = 1 (negative ids ignored)"""
+    _chk(ids, I32, "ids"); _chk(flags, U8, "flags")
+    L.call("kbner_mark_rows", ptr(ids), ids.numel(), ptr(flags), flags.numel(), stream_ptr())
+
+
+def grad_sqnorm_rows(g2d, flags, ws, out, accumulate=True):
+    _chk(g2d, F32, "g"); _chk(flags, U8, "flags")
+    L.call("kbner_grad_sqnorm_rows", ptr(g2d), ptr(flags), g2d.shape[0], g2d.shape[1], ptr(ws), ptr(out), 1 if accumulate else 0,
+           stream_ptr())
+
+
+def adamw_rows(p, g, m, v, flags, step_size, b1, b2, eps, gnorm_sq, max_norm, grad_scale, zero_grad=True):
+    """HF AdamW (weight decay 0) on the flagged rows of an embedding table [rows, width]"""
+    _chk(p, F32, "p"); _chk(flags, U8, "flags")
+    L.call("kbner_adamw_hf_rows", ptr(p), ptr(g), ptr(m), ptr(v), ptr(flags), p.shape[0], p.shape[1], step_size, b1, b2, eps,
+           ptr(gnorm_sq), max_norm, grad_scale, 1 if zero_grad else 0, stream_ptr())
+
+
 def f32_to_bf16(x, y):
     L.call("kbner_f32_to_bf16", ptr(x), ptr(y), x.numel(), stream_ptr())
 

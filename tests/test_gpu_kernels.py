@@ -501,3 +501,45 @@ def test_multiview_posterior_kl_vs_oracle(B, n, T, tau):
     assert np.abs(de.cpu().numpy() - ref).max() <= tol * max(1e-3, np.abs(ref).max())
     ref = tr_t.grad.numpy()
     assert np.abs(dtr.cpu().numpy() - ref).max() <= 3 * tol * max(1e-3, np.abs(ref).max())
+
+
+def test_sparse_embedding_optimizer_equals_dense():
+    """FusedAdamW skips word-embedding rows that never received a gradient (kbner_adamw_hf_rows / kbner_grad_sqnorm_rows /
+    kbner_mark_rows).  Every one of 5 optimizer steps (different batches, clipping active) is applied twice from the SAME state --
+    row-sparse on the training replica, dense on a copy: same clip norm (to the fp32 summation order), same p / m / v; rows
+    outside the ids seen so far stay bit-identical to their initial values and the live-row set equals those ids."""
+    import torch
+    from kbner import batch as kb
+    from kbner import engine
+    T, start, stop, x_idx = 29, 27, 28, 9
+    cfg = engine.EncoderConfig(vocab_size=5000, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                               max_position_embeddings=130, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    tg = engine.Tagger(cfg, T, start, stop, device="cuda")
+    tg.init_random(seed=5)
+    opt = engine.FusedAdamW(tg.arena, lr=1e-3, lr_rate=10.0, t_total=50, max_norm=0.5)    # small max_norm: clipping is active
+    assert opt.sparse_embedding
+    ref = engine.Arena(engine.tagger_specs(cfg, T), "cuda")
+    ropt = engine.FusedAdamW(ref, lr=1e-3, lr_rate=10.0, t_total=50, max_norm=0.5)
+    ropt.sparse_embedding = False
+    p0 = tg.arena.param("emb.word").clone()
+    seen = set()
+    for step in range(5):
+        mb = kb.synthetic_batch(3, 128, vocab=700 if step < 3 else 2000, T=T, x_idx=x_idx, start=start, stop=stop, seed=100 + step)
+        seen |= set(np.unique(mb["ids"]).tolist())
+        tg.forward_loss(kb.to_device(mb, "cuda"), loss_scale=1.0, backward=True)
+        for name in ("p", "g", "m", "v"):
+            getattr(ref, name).copy_(getattr(tg.arena, name))
+        ropt.t = opt.t
+        n_sparse, n_dense = float(opt.step()), float(ropt.step())
+        assert abs(n_sparse - n_dense) <= 2e-6 * n_dense, (step, n_sparse, n_dense)
+        for name in ("p", "m", "v"):
+            a, b = getattr(tg.arena, name), getattr(ref, name)
+            assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()), (step, name)
+        assert float(tg.arena.g.abs().max()) == 0.0 and float(ref.g.abs().max()) == 0.0      # zeroed for the next step
+    torch.cuda.synchronize()
+    flags = tg.arena.emb_flags.cpu().numpy().astype(bool)
+    assert set(np.nonzero(flags)[0].tolist()) == seen and flags.sum() < cfg.vocab_size // 2
+    dead = torch.from_numpy(~flags).cuda()
+    assert torch.equal(tg.arena.param("emb.word")[dead], p0[dead])            # never read, never written
+    assert torch.equal(ref.p[ref.offsets["emb.word"]:][:p0.numel()].view_as(p0)[dead], p0[dead])   # the dense update agrees
+    assert float((tg.arena.param("emb.word")[~dead] - p0[~dead]).abs().max()) > 0
