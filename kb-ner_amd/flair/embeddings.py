@@ -595,31 +595,67 @@ class FlairEmbeddings(TokenEmbeddings):
 
 class _NeedsExternalWeights(TokenEmbeddings):
     """Embedding classes of the ACE config (config/xlmr-task-wiki-extdoc...ner6.yaml) whose weights are files this offline
-    build cannot obtain ("ELMo/FastWord need external weight files and can stay stubbed").  The classes exist
-    under the reference's names with the YAML's keywords so `getattr(Embeddings, name)(**kwargs)` (config_parser.py:156-181)
-    resolves and fails with an explanation instead of an AttributeError."""
+    build cannot obtain ("ELMo/FastWord need external weight files and can stay stubbed").  They are
+    constructible as PLACEHOLDERS: name and embedding_length as in the reference -- which is all the stacked tagger needs of an
+    embedding its controller has deselected (`features * selection[idx]` with selection 0, sequence_tagger_model.py:889: the
+    block of the concatenated input is zero whatever the embedding would have produced, and the BiLSTM's input weights keep the
+    trained layout) -- and refuse, with an explanation, the moment they are asked for actual vectors."""
     _what = ""
 
+    def _placeholder(self, name, length):
+        self.name = name
+        self.static_embeddings = True
+        self._length = None if length is None else int(length)
+        if self._length is None:
+            self._refuse()
+        log.warning("%s %r: %s are not available offline -- built as a placeholder of width %d that can only be used deselected "
+                    "(its entry of `student.selection` / best_action must be 0)", type(self).__name__, name, self._what, self._length)
+
+    @property
+    def embedding_length(self) -> int:
+        return self._length
+
     def _refuse(self):
-        raise NotImplementedError("%s needs %s, which are not available offline; drop it from the YAML's `embeddings:` block "
-                                  "(or set its entry of `student.selection` to 0 and remove it)" % (type(self).__name__, self._what))
+        raise NotImplementedError("%s needs %s, which are not available offline; it can only take part deselected (its entry of "
+                                  "`student.selection` 0), or drop it from the YAML's `embeddings:` block" %
+                                  (type(self).__name__, self._what))
+
+    def embed(self, sentences, *a, **k):
+        self._refuse()
+
+    def _add_embeddings_internal(self, sentences):
+        self._refuse()
 
 
 class ELMoEmbeddings(_NeedsExternalWeights):
-    """reference: flair/embeddings.py ELMoEmbeddings (allennlp ElmoEmbedder over options_file / weight_file)"""
-    _what = "the allennlp ELMo options/weight files (elmo_2x4096_512_2048cnn_2xhighway_5.5B_*)"
+    """reference: flair/embeddings.py:1214-1290 ELMoEmbeddings (allennlp ElmoEmbedder over options_file / weight_file); name
+    'elmo-<model>', width = 3 layers x 2 directions x the projection size (3072 for the original / 5.5B models)"""
+    _what = "the allennlp package and its ELMo options/weight files"
 
-    def __init__(self, model: str = "original", options_file: str = None, weight_file: str = None, **kwargs):
+    def __init__(self, model: str = "original", options_file: str = None, weight_file: str = None, embedding_name=None,
+                 is_hit_elmo=False, use_avg=False, embedding_length: int = None, **kwargs):
         super().__init__()
-        self._refuse()
+        import re
+        proj = {"small": 128, "medium": 256, "original": 512, "large": 512, "pt": 512, "portuguese": 512, "pubmed": 512}.get(model)
+        m = re.search(r"_(\d+)_\d+cnn", options_file or "")
+        if m:
+            proj = int(m.group(1))
+        self._placeholder(embedding_name if embedding_name is not None else "elmo-" + model,
+                          embedding_length if embedding_length is not None else (6 * proj if proj else None))
 
 
 class FastWordEmbeddings(_NeedsExternalWeights):
-    """reference: flair/embeddings.py FastWordEmbeddings (gensim KeyedVectors lookup table, `freeze`)"""
-    _what = "a gensim word-vector file for `embeddings=%r`"
+    """reference: flair/embeddings.py:416-560 FastWordEmbeddings (gensim KeyedVectors lookup table, `freeze`); name
+    'Word: <embeddings>', width = the vectors' size (300 for the fastText tables, 100 glove / twitter, 50 turian)"""
+    _what = "the gensim word-vector files"
 
     def __init__(self, embeddings: str = None, all_tokens=None, field: str = None, if_cased: bool = True, freeze: bool = False,
-                 additional_empty_embedding: bool = False, keepall: bool = False, embedding_name: str = None, **kwargs):
+                 additional_empty_embedding: bool = False, keepall: bool = False, embedding_name: str = None,
+                 embedding_length: int = None, **kwargs):
         super().__init__()
-        self._what = self._what % (embeddings,)
-        self._refuse()
+        key = (embeddings or "").lower()
+        width = {"glove": 100, "twitter": 100, "turian": 50, "extvec": 300}.get(key)
+        if width is None and (key in ("crawl", "news", "en") or len(key) == 2 or key.endswith(("-crawl", "-news", "-wiki"))):
+            width = 300     # fastText
+        self._placeholder(embedding_name if embedding_name is not None else "Word: %s" % embeddings,
+                          embedding_length if embedding_length is not None else width)

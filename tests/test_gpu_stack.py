@@ -174,7 +174,10 @@ def test_config5_yaml_route(assets, tmp_path):
     tiny_assets.write_conll_corpus(str(tmp_path / "data"), n_train=6, n_dev=3, n_test=5, seed=3)
     cfg = {"ReinforcementTrainer": {"assign_doc_for_ext_context": True, "controller_learning_rate": 0.1, "controller_optimizer": "SGD",
                                     "distill_mode": False, "optimizer": "SGD", "sentence_level_batch": True},
-           "embeddings": {"FlairEmbeddings-0": {"model": str(d / "lm_f.pt")}, "FlairEmbeddings-1": {"model": str(d / "lm_b.pt")},
+           "embeddings": {"ELMoEmbeddings-0": {"options_file": "elmo/elmo_2x4096_512_2048cnn_2xhighway_5.5B_options.json",
+                                               "weight_file": "elmo/elmo_2x4096_512_2048cnn_2xhighway_5.5B_weights.hdf5"},
+                          "FastWordEmbeddings-0": {"embeddings": "en", "freeze": True},
+                          "FlairEmbeddings-0": {"model": str(d / "lm_f.pt")}, "FlairEmbeddings-1": {"model": str(d / "lm_b.pt")},
                           "TransformerWordEmbeddings-0": {"layers": "-1", "model": str(d / "enc_a"), "pooling_operation": "first",
                                                           "use_internal_doc": True},
                           "TransformerWordEmbeddings-1": {"layers": "-1", "model": str(d / "enc_b"), "pooling_operation": "first"}},
@@ -196,7 +199,15 @@ def test_config5_yaml_route(assets, tmp_path):
     assert student.embedding_selector and student.use_rl
     for s in cp.corpus.test_list[0]:
         assert "<EOS>" not in [t.text for t in s] and "<EOS>" in [t.text for t in s.doc_sent]
-    student.selection = [1, 0, 1, 1]          # what train.py:216-217 loads from training_state.pt['best_action']
+    # the shipped ACE YAML also lists ELMo and fastText embeddings, whose weights this offline build cannot have: they are
+    # placeholders (reference name + width, so the BiLSTM's input layout is the trained one) that work only DESELECTED
+    names = [e.name for e in student._stack_embs]
+    assert names == sorted(names) and "elmo-original" in names and "Word: en" in names
+    assert student.embeddings.embedding_length == 3072 + 300 + sum(e.embedding_length for e in student._stack_embs
+                                                                   if e.name not in ("elmo-original", "Word: en"))
+    sel = [0 if n in ("elmo-original", "Word: en") else 1 for n in names]
+    sel[[i for i, n in enumerate(names) if n not in ("elmo-original", "Word: en")][1]] = 0   # + one real embedding off
+    student.selection = sel                    # what train.py:216-217 loads from training_state.pt['best_action']
     student.eval()
     loader = ColumnDataLoader(list(trainer.corpus.test), 4, use_bert=student.use_bert, model=student, sort_data=False,
                               sentence_level_batch=True)
@@ -206,5 +217,8 @@ def test_config5_yaml_route(assets, tmp_path):
     assert len(lines) == sum(len(s) for s in cp.corpus.test_list[0])
     assert all(len(l.split(" ")) == 4 and l.split(" ")[1] != "S-X" for l in lines)
     assert np.isfinite(loss) and 0.0 <= res.main_score <= 1.0
+    student.selection = [1] * len(names)
+    with pytest.raises(NotImplementedError, match="not available offline|no device producer"):
+        student.evaluate(loader, embeddings_storage_mode="none", prediction_mode=True)   # a selected placeholder refuses
     with pytest.raises(NotImplementedError):
         trainer.train(cp.get_target_path, **cp.config["train"])      # ACE controller training is out of scope
