@@ -55,7 +55,8 @@ def main():
     toks = [emb.tokenize_sentence(s) for s in list(cc.train)[:64]]
     lens = [len(t[0][0]) for t in toks]
     assert max(len(t[0]) for t in toks) == 1, "synthetic sentences must fit one window for this measurement"
-    tagger = FastSequenceTagger(hidden_size=256, embeddings=emb, tag_dictionary=td, tag_type="ner", use_crf=True, use_rnn=False,
+    from flair.embeddings import StackedEmbeddings
+    tagger = FastSequenceTagger(hidden_size=256, embeddings=StackedEmbeddings([emb]), tag_dictionary=td, tag_type="ner", use_crf=True, use_rnn=False,
                                 remove_x=True, sentence_loss=True, word_dropout=0.1, dropout=0.0, locked_dropout=0.0)
     trainer = ModelFinetuner(tagger, None, corpus, config={}, distill_mode=False, sentence_level_batch=True)
     out = {}
@@ -79,6 +80,37 @@ def main():
         pr.disable()
         print("forward_backward: %.1f ms per batch of %d" % (dt / 8 * 1e3, a.batch))
         pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
+        return
+    if os.environ.get("KBNER_STAGE"):
+        # BASELINE config 4 (multi-stage fine-tuning): what lies between two stages on the host -- the HF directory written by
+        # save_finetuned_embedding (finetune_trainer.py:1289-1312), the next stage's YAML naming it as `model:`, best-model.pt
+        import json
+        base = os.path.join(d, "stage1")
+        os.makedirs(base, exist_ok=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        trainer.save_finetuned_embedding(base)
+        t_save = time.perf_counter() - t0
+        hf_dir = os.path.join(base, os.path.basename(os.path.join(d, "enc")))
+        size = sum(os.path.getsize(os.path.join(hf_dir, f)) for f in os.listdir(hf_dir))
+        t0 = time.perf_counter()
+        emb2 = TransformerWordEmbeddings(model=hf_dir, layers="-1", pooling_operation="first", fine_tune=True)
+        tagger2 = FastSequenceTagger(hidden_size=256, embeddings=StackedEmbeddings([emb2]), tag_dictionary=td, tag_type="ner", use_crf=True, use_rnn=False,
+                                     remove_x=True, sentence_loss=True, word_dropout=0.1, dropout=0.0, locked_dropout=0.0)
+        torch.cuda.synchronize()
+        t_load = time.perf_counter() - t0
+        same = bool(torch.equal(tagger2.engine.arena.param("l0.qkv.weight"), tagger.engine.arena.param("l0.qkv.weight")))
+        t0 = time.perf_counter()
+        tagger.save(os.path.join(base, "best-model.pt"))
+        t_pt = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        FastSequenceTagger.load(os.path.join(base, "best-model.pt"))
+        torch.cuda.synchronize()
+        t_ptl = time.perf_counter() - t0
+        print(json.dumps({"what": "stage hand-over, XLM-R-%s-sized encoder" % a.model, "hf_dir_bytes": size,
+                          "save_finetuned_embedding_s": round(t_save, 2), "next_stage_load_to_gpu_s": round(t_load, 2),
+                          "weights_identical_after_reload": same, "best_model_pt_save_s": round(t_pt, 2),
+                          "best_model_pt_load_s": round(t_ptl, 2)}))
         return
     if os.environ.get("KBNER_EVAL"):
         from flair.custom_data_loader import ColumnDataLoader
