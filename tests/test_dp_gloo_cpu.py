@@ -102,13 +102,19 @@ def _worker(rank, world, port, out):
         g[lo:lo + V * H] = emb.flatten()
         want = g.clone()
         dist.all_reduce(want)
-        red = dp.GradReducer(g, emb_range=(lo, lo + V * H), emb_width=H, compress_embedding=compress, row_ops=_TorchRows)
+        flags = torch.zeros(V, dtype=torch.uint8)      # the optimizer's "row has received a gradient" flags
+        flags[touched] = 1                             # what this rank's own embedding backward marks
+        red = dp.GradReducer(g, emb_range=(lo, lo + V * H), emb_width=H, compress_embedding=compress, row_ops=_TorchRows,
+                             emb_flags=flags)
         red.begin(touched.numpy())
         red.bucket_ready(1000, 2000)     # the order backward finishes them: top layers first
         red.bucket_ready(0, 1000)
         scale = red.finish()
         tol = 2e-2 if compress else 1e-6
-        checks.append((case, red.stats["emb_mode"], float((g - want).abs().max()) <= tol * float(want.abs().max()), scale,
+        # after the exchange every row that carries a gradient on ANY rank must be live here too (row-sparse AdamW relies on it)
+        nz = (g[lo:lo + V * H].view(V, H) != 0).any(1)
+        flags_ok = bool(torch.all(flags.bool() | ~nz)) and (case != "sparse" or int(flags.sum()) <= 2 * n_touch)
+        checks.append((case, red.stats["emb_mode"], float((g - want).abs().max()) <= tol * float(want.abs().max()) and flags_ok, scale,
                        red.stats["buckets"], red.stats["bytes_overlapped"]))
     # 5. replicas start identical: broadcast of the parameter arena from rank 0
     p = torch.full((100,), float(rank + 7))
