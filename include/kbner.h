@@ -156,7 +156,10 @@ typedef struct kbner_gemm_problem {
   uint32_t drop_seed, drop_thresh; /* KBNER_EPI_DROP */
 } kbner_gemm_problem;
 int kbner_gemm_bf16_grouped(int layout, int nprob, const kbner_gemm_problem* probs, void* stream);
-/* out[n] += sum_r ws[r, n], rows = 2 * M / 256: the second half of KBNER_EPI_COLSUM_WS (ws is folded in place: clobbered) */
+/* rows of an output tile the grouped launch uses for ONE problem of this layout and shape: 256, or 128 when the 256 x 256 tiling
+   would give at most half of the CUs a tile (small micro-batches).  A KBNER_EPI_COLSUM_WS workspace has 2 * M / rows lines. */
+int kbner_gemm_tile_rows(int layout, int M, int N);
+/* out[n] += sum_r ws[r, n], rows = 2 * M / tile rows: the second half of KBNER_EPI_COLSUM_WS (ws is folded in place: clobbered) */
 int kbner_colsum_rows_f32(float* ws, int rows, int N, float* out, void* stream);
 /* The same launch with DYNAMIC tile scheduling: workgroups draw their tiles from 8 per-XCD counters (`sched`, device ints the
  * caller zeroed on this stream since their last use) instead of a static walk, so a workgroup the dispatcher places late -- its

@@ -89,14 +89,15 @@ static __device__ __forceinline__ int kcb_swz(int row) { return (((row >> 3) & 3
 // output columns per fragment pair (g*8 .. g*8+7 of each 32-column block): every epilogue access is 16 bytes
 // (dwordx4) instead of 8 -- the row-per-lane store tail is issue-bound, halving the instruction count halves it.
 
-template <bool KS, bool ISB>
+template <bool KS, bool ISB, int ROWS = 256>
 static __device__ __forceinline__ void stage256(const bf16_t* __restrict__ P, int ld, int row0, int k0, unsigned char* s, int wid,
                                                 int lane) {
+  static_assert(ROWS == 256 || (ROWS == 128 && !KS), "half-height tiles exist for the row-major (KC) A image only");
   // uniform tile origin in SGPRs
   const bf16_t* sbase = KS ? P + (size_t)k0 * ld + row0 : P + (size_t)row0 * ld + k0;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int q = wid * 4 + j;  // 32 wave-instructions x 1 KiB = 32 KiB tile
+  for (int j = 0; j < ROWS / 64; ++j) {
+    const int q = wid * (ROWS / 64) + j;  // ROWS / 8 wave-instructions x 1 KiB (32 KiB for a 256-row tile)
     unsigned voff;
     if (!KS) {
       const int row = q * 8 + (lane >> 3);
@@ -157,6 +158,7 @@ static __device__ __forceinline__ bf16x8 fragB256(const unsigned char* s, int c0
 // linear id -> (problem, tile origin).  XCD-aware bijective remap (block b runs on XCD b % 8; persistent ids keep
 // id % 8): each XCD's private L2 sees a contiguous run of tiles, n fastest, so neighbours share the A panel.
 // The problem is picked with static indices only (a runtime-indexed kernarg array would go to scratch).
+template <int TM = 256>
 static __device__ __forceinline__ void pick_tile(const GroupArgs& ga, int id, int total, GemmProblem& g, int& m0, int& n0) {
   const int xcd = id & 7;
   const int q8 = total >> 3, r8 = total & 7;
@@ -177,12 +179,12 @@ static __device__ __forceinline__ void pick_tile(const GroupArgs& ga, int id, in
   // then form an 8 x 4 patch that shares 8 A panels and 4 B panels through that XCD's L2, instead of a 1 x 32 strip that
   // shares one A panel and streams 32 different B panels from MALL/HBM (measured: the strip order is fabric-bound).
   const int tile = wg - g.tile_begin;
-  const int tiles_n = g.N / T2, tiles_m = g.M / T2;
+  const int tiles_n = g.N / T2, tiles_m = g.M / TM;
   const int group = 8 * tiles_n;
   const int first_m = (tile / group) * 8;
   const int gm = min(tiles_m - first_m, 8);
   const int r = tile % group;
-  m0 = (first_m + r % gm) * T2;
+  m0 = (first_m + r % gm) * TM;
   n0 = (r / gm) * T2;
 }
 
@@ -193,14 +195,14 @@ static __device__ __forceinline__ void pick_tile(const GroupArgs& ga, int id, in
 // exposes a full memory latency.  Here the flags fold at compile time, the operand loads of row fragment mi+1 are
 // issued before fragment mi is processed, and sched_barriers keep the compiler from interleaving all eight fragments
 // (which spills).
-template <int EPI_CT>
-static __device__ __forceinline__ void epilogue256(const GemmProblem& g, f4v (&acc)[8][4], int m0, int n0, int wm, int wn,
+template <int EPI_CT, int MI = 8>
+static __device__ __forceinline__ void epilogue256(const GemmProblem& g, f4v (&acc)[MI][4], int m0, int n0, int wm, int wn,
                                                    int lane, unsigned char* scr) {
   const int epi = EPI_CT >= 0 ? EPI_CT : g.epi;
   const float alpha = g.alpha;
   const int gq = lane >> 4;
   const int ncol = n0 + wn * 64 + gq * 8;  // + q * 32: the 8 contiguous columns this lane owns in column-half q
-  const int mrow = m0 + wm * 128 + (lane & 15);
+  const int mrow = m0 + wm * (MI * 16) + (lane & 15);
   float csum[2][8];
   float bq[2][8];  // this lane's 16 bias values, loaded once per tile
 #pragma unroll
@@ -239,7 +241,7 @@ static __device__ __forceinline__ void epilogue256(const GemmProblem& g, f4v (&a
                              scr + wr_row * 128 + (((1 * 4 + gq) ^ (wr_row & 7)) << 4)};
   const int rd_row = lane >> 3, rd_chunk = lane & 7;
   const unsigned char* scr_r = scr + rd_row * 128 + ((rd_chunk ^ (rd_row & 7)) << 4);
-  const size_t rd_off = (size_t)(m0 + wm * 128 + rd_row) * 1;  // row index; scaled by the leading dimension at the store
+  const size_t rd_off = (size_t)(m0 + wm * (MI * 16) + rd_row) * 1;  // row index; scaled by the leading dimension at the store
   // operand tile (residual addend or saved pre-activation) of the row fragment about to be processed, one fragment ahead
   const bool has_in = (epi & (EPI_ADD | EPI_DGELU)) != 0;
   const bf16_t* inp = (epi & EPI_ADD) ? g.addend : g.aux;
@@ -250,11 +252,11 @@ static __device__ __forceinline__ void epilogue256(const GemmProblem& g, f4v (&a
     for (int q = 0; q < 2; ++q) nxt_in[q] = *reinterpret_cast<const uint4*>(inp + (size_t)mrow * ldin + ncol + q * 32);
   }
 #pragma unroll
-  for (int mi = 0; mi < 8; ++mi) {
+  for (int mi = 0; mi < MI; ++mi) {
     const int m = mrow + mi * 16;
     const uint32_t rk = drop ? drop_rowkey(g.drop_seed, (uint32_t)m) : 0u;
     uint4 cur_in[2] = {nxt_in[0], nxt_in[1]};
-    if (has_in && mi + 1 < 8) {
+    if (has_in && mi + 1 < MI) {
 #pragma unroll
       for (int q = 0; q < 2; ++q)
         nxt_in[q] = *reinterpret_cast<const uint4*>(inp + (size_t)(m + 16) * ldin + ncol + q * 32);
@@ -365,7 +367,7 @@ static __device__ __forceinline__ void epilogue256(const GemmProblem& g, f4v (&a
     // every CU hits made the FFN-down dgrad (GELU' + bias gradient) the slowest GEMM of the step, 752 TFLOP/s against 1040-1250
     // for the other dgrad shapes.
     const bool to_ws = (epi & EPI_COLSUM_WS) != 0;
-    float* wrow = g.colsum + (to_ws ? (size_t)((m0 >> 8) * 2 + wm) * g.N : 0);
+    float* wrow = g.colsum + (to_ws ? (size_t)((m0 / (MI * 32)) * 2 + wm) * g.N : 0);
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       float red[8];
@@ -420,8 +422,12 @@ static __device__ __forceinline__ int draw_tile(int* sched, int xcd, int total) 
   return total;
 }
 
-template <bool A_KS, bool B_KS, bool DYN = false>
+// TM = 128: half-height tiles (128 x 256, each wave 64 x 64) for forward / dgrad problems whose 256 x 256 tiling would leave half
+// of the CUs without a tile (small micro-batches: M = 2048 tokens x N = 4096 is 128 big tiles on 256 CUs).  Same B tile, LDS
+// images, K loop and epilogues; the A tile is 16 KiB, a K step 4 MFMA groups instead of 8.
+template <bool A_KS, bool B_KS, bool DYN = false, int TM = 256>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GroupArgs ga) {
+  constexpr int MI = TM / 32;   // 16-row accumulator fragments per wave
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -448,8 +454,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GroupArgs ga) {
   {
     GemmProblem g0;
     int m00, n00;
-    pick_tile(ga, id, total, g0, m00, n00);
-    stage256<A_KS, false>(g0.A, g0.lda, m00, 0, smem, wid, lane);
+    pick_tile<TM>(ga, id, total, g0, m00, n00);
+    stage256<A_KS, false, TM>(g0.A, g0.lda, m00, 0, smem, wid, lane);
     stage256<B_KS, true>(g0.B, g0.ldb, n00, 0, smem + TILE2_BYTES, wid, lane);
   }
 
@@ -464,7 +470,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GroupArgs ga) {
   const bf16_t* __restrict__ Bp;
   {
     GemmProblem gm;
-    pick_tile(ga, id, total, gm, m0, n0);
+    pick_tile<TM>(ga, id, total, gm, m0, n0);
     nt = gm.K / BK2;
     Ap = gm.A;
     Bp = gm.B;
@@ -479,9 +485,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GroupArgs ga) {
   // compiler-visible VMEM result in flight across the K loop makes hipcc drain vmcnt(0) around the hand-counted waits.)
   if (DYN && tid == 0) *s_next = draw_tile(ga.sched, blockIdx.x & 7, total);
 
-  f4v acc[8][4];
+  f4v acc[MI][4];
 #pragma unroll
-  for (int mi = 0; mi < 8; ++mi)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
 
@@ -490,7 +496,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GroupArgs ga) {
     // stores, younger than that DMA, may still be in flight), then the barrier publishes all of them and fences
     // the previous iteration's reads of the stage about to be refilled.  Raw s_barrier: __syncthreads() would add a
     // vmcnt(0) release for the epilogue's global stores.
-    if (t == 0 && pend == 16) {
+    if (t == 0 && pend == 8) {
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else if (t == 0 && pend == 16) {
       asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     } else if (t == 0 && pend == 32) {
       asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
@@ -508,13 +516,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GroupArgs ga) {
     unsigned char* cur = smem + (it & 1) * STAGE2_BYTES;
     unsigned char* nxt = smem + ((it + 1) & 1) * STAGE2_BYTES;
     if (t + 1 < nt) {
-      stage256<A_KS, false>(Ap, lda, m0, (t + 1) * BK2, nxt, wid, lane);
+      stage256<A_KS, false, TM>(Ap, lda, m0, (t + 1) * BK2, nxt, wid, lane);
       stage256<B_KS, true>(Bp, ldb, n0, (t + 1) * BK2, nxt + TILE2_BYTES, wid, lane);
     } else if (has_next) {
       GemmProblem gn;
       int m0n, n0n;
-      pick_tile(ga, id_next, total, gn, m0n, n0n);
-      stage256<A_KS, false>(gn.A, gn.lda, m0n, 0, nxt, wid, lane);
+      pick_tile<TM>(ga, id_next, total, gn, m0n, n0n);
+      stage256<A_KS, false, TM>(gn.A, gn.lda, m0n, 0, nxt, wid, lane);
       stage256<B_KS, true>(gn.B, gn.ldb, n0n, 0, nxt + TILE2_BYTES, wid, lane);
     }
     ++it;
@@ -525,8 +533,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GroupArgs ga) {
 #define G2_LOADB(dst, ks)                                                                                     \
   _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) dst[ni] = fragB256<B_KS>(cur + TILE2_BYTES, wn * 64, ni, ks, lane)
 #define G2_LOADA(dst, ks, pr)                                         \
-  dst[0] = frag256<A_KS>(cur, wm * 128 + (2 * (pr)) * 16, ks, lane);  \
-  dst[1] = frag256<A_KS>(cur, wm * 128 + (2 * (pr) + 1) * 16, ks, lane)
+  dst[0] = frag256<A_KS>(cur, wm * (TM / 2) + (2 * (pr)) * 16, ks, lane);  \
+  dst[1] = frag256<A_KS>(cur, wm * (TM / 2) + (2 * (pr) + 1) * 16, ks, lane)
 #define G2_MM(a, b, pr)                                                                                              \
   _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) acc[2 * (pr) + j][ni] = \
       __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[ni], a[j], acc[2 * (pr) + j][ni], 0, 0, 0)
@@ -534,22 +542,30 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GroupArgs ga) {
     G2_LOADB(b0, 0);
     G2_LOADA(a0, 0, 0);
     G2_SB();
-    G2_LOADA(a1, 0, 1); G2_SB(); G2_MM(a0, b0, 0); G2_SB();
-    G2_LOADA(a0, 0, 2); G2_SB(); G2_MM(a1, b0, 1); G2_SB();
-    G2_LOADA(a1, 0, 3); G2_SB(); G2_MM(a0, b0, 2); G2_SB();
-    G2_LOADB(b1, 1);
-    G2_LOADA(a0, 1, 0); G2_SB(); G2_MM(a1, b0, 3); G2_SB();
-    G2_LOADA(a1, 1, 1); G2_SB(); G2_MM(a0, b1, 0); G2_SB();
-    G2_LOADA(a0, 1, 2); G2_SB(); G2_MM(a1, b1, 1); G2_SB();
-    G2_LOADA(a1, 1, 3); G2_SB(); G2_MM(a0, b1, 2); G2_SB();
-    G2_MM(a1, b1, 3);
+    if constexpr (TM == 256) {
+      G2_LOADA(a1, 0, 1); G2_SB(); G2_MM(a0, b0, 0); G2_SB();
+      G2_LOADA(a0, 0, 2); G2_SB(); G2_MM(a1, b0, 1); G2_SB();
+      G2_LOADA(a1, 0, 3); G2_SB(); G2_MM(a0, b0, 2); G2_SB();
+      G2_LOADB(b1, 1);
+      G2_LOADA(a0, 1, 0); G2_SB(); G2_MM(a1, b0, 3); G2_SB();
+      G2_LOADA(a1, 1, 1); G2_SB(); G2_MM(a0, b1, 0); G2_SB();
+      G2_LOADA(a0, 1, 2); G2_SB(); G2_MM(a1, b1, 1); G2_SB();
+      G2_LOADA(a1, 1, 3); G2_SB(); G2_MM(a0, b1, 2); G2_SB();
+      G2_MM(a1, b1, 3);
+    } else {
+      G2_LOADA(a1, 0, 1); G2_SB(); G2_MM(a0, b0, 0); G2_SB();
+      G2_LOADB(b1, 1);
+      G2_LOADA(a0, 1, 0); G2_SB(); G2_MM(a1, b0, 1); G2_SB();
+      G2_LOADA(a1, 1, 1); G2_SB(); G2_MM(a0, b1, 0); G2_SB();
+      G2_MM(a1, b1, 1);
+    }
   }
 
   G2_T(1)
   GemmProblem g;
   {
     int mm, nn;
-    pick_tile(ga, id, total, g, mm, nn);
+    pick_tile<TM>(ga, id, total, g, mm, nn);
   }
   const int epi = g.epi;
   unsigned char* scr = smem + 2 * STAGE2_BYTES + wid * 4096;
@@ -558,41 +574,42 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GroupArgs ga) {
   // slower in situ than the generic epilogue
   if (!B_KS) {
     switch (epi) {
-      case 0: epilogue256<0>(g, acc, m0, n0, wm, wn, lane, scr); break;
-      case EPI_BIAS: epilogue256<EPI_BIAS>(g, acc, m0, n0, wm, wn, lane, scr); break;
-      case EPI_BIAS | EPI_GELU: epilogue256<(EPI_BIAS | EPI_GELU)>(g, acc, m0, n0, wm, wn, lane, scr); break;
-      case EPI_BIAS | EPI_ADD: epilogue256<(EPI_BIAS | EPI_ADD)>(g, acc, m0, n0, wm, wn, lane, scr); break;
-      case EPI_BIAS | EPI_ADD | EPI_DROP: epilogue256<(EPI_BIAS | EPI_ADD | EPI_DROP)>(g, acc, m0, n0, wm, wn, lane, scr); break;
-      default: epilogue256<-1>(g, acc, m0, n0, wm, wn, lane, scr); break;
+      case 0: epilogue256<0, MI>(g, acc, m0, n0, wm, wn, lane, scr); break;
+      case EPI_BIAS: epilogue256<EPI_BIAS, MI>(g, acc, m0, n0, wm, wn, lane, scr); break;
+      case EPI_BIAS | EPI_GELU: epilogue256<(EPI_BIAS | EPI_GELU), MI>(g, acc, m0, n0, wm, wn, lane, scr); break;
+      case EPI_BIAS | EPI_ADD: epilogue256<(EPI_BIAS | EPI_ADD), MI>(g, acc, m0, n0, wm, wn, lane, scr); break;
+      case EPI_BIAS | EPI_ADD | EPI_DROP: epilogue256<(EPI_BIAS | EPI_ADD | EPI_DROP), MI>(g, acc, m0, n0, wm, wn, lane, scr); break;
+      default: epilogue256<-1, MI>(g, acc, m0, n0, wm, wn, lane, scr); break;
     }
   } else if (A_KS && epi == EPI_RMW32) {
-    epilogue256<EPI_RMW32>(g, acc, m0, n0, wm, wn, lane, scr);
+    epilogue256<EPI_RMW32, MI>(g, acc, m0, n0, wm, wn, lane, scr);
   } else if (!A_KS && epi == EPI_ADD) {
-    epilogue256<EPI_ADD>(g, acc, m0, n0, wm, wn, lane, scr);
+    epilogue256<EPI_ADD, MI>(g, acc, m0, n0, wm, wn, lane, scr);
   } else if (!A_KS && epi == 0) {
-    epilogue256<0>(g, acc, m0, n0, wm, wn, lane, scr);
+    epilogue256<0, MI>(g, acc, m0, n0, wm, wn, lane, scr);
   } else {
-    epilogue256<-1>(g, acc, m0, n0, wm, wn, lane, scr);
+    epilogue256<-1, MI>(g, acc, m0, n0, wm, wn, lane, scr);
   }
   G2_T(2)
   ++tile_no;
   if (!has_next) break;
-  pend = (epi & EPI_ATOMIC32) ? 0 : ((epi & (EPI_GELU | EPI_RMW32 | EPI_STORE32)) ? 32 : 16);
+  // stores this wave issued after the in-flight DMA: 2 per 16-row fragment (4 with a second output / fp32 outputs)
+  pend = (epi & EPI_ATOMIC32) ? 0 : ((epi & (EPI_GELU | EPI_RMW32 | EPI_STORE32)) ? 4 * MI : 2 * MI);
   id = id_next;
   }  // persistent tile loop
 }
 
-template <bool A_KS, bool B_KS, bool DYN>
+template <bool A_KS, bool B_KS, bool DYN, int TM = 256>
 static int launch256(const GroupArgs& ga, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<A_KS, B_KS, DYN>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<A_KS, B_KS, DYN, TM>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES);
     if (e != hipSuccess) return -(int)e;
     attr_set = true;
   }
   const int grid = ga.total_tiles < ga.ncu ? ga.total_tiles : ga.ncu;
-  hipLaunchKernelGGL((gemm256_kernel<A_KS, B_KS, DYN>), dim3(grid), dim3(512), G2_LDS_BYTES, stream, ga);
+  hipLaunchKernelGGL((gemm256_kernel<A_KS, B_KS, DYN, TM>), dim3(grid), dim3(512), G2_LDS_BYTES, stream, ga);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }
@@ -633,11 +650,23 @@ extern "C" int kbner_debug_read_trace(unsigned long long* out) {
 }
 #endif
 
+static int pick_tile_rows(int layout, int nprob, const kbner_gemm_problem* probs, bool dyn);
+
 extern "C" {
+
+// rows of an output tile kbner_gemm_bf16_grouped uses for a SINGLE problem of this layout and shape (256, or 128 when the
+// 256 x 256 tiling would occupy at most half of the CUs): callers of KBNER_EPI_COLSUM_WS size and fold 2 * M / rows lines
+int kbner_gemm_tile_rows(int layout, int M, int N) {
+  kbner_gemm_problem p = {};
+  p.M = M;
+  p.N = N;
+  return pick_tile_rows(layout, 1, &p, false);
+}
 
 // Grouped GEMM: nprob (1..16) problems of the SAME layout in one launch.
 // Constraints per problem: M % 256 == 0, N % 256 == 0, K % 64 == 0, lda/ldb % 8 == 0.
 static int gemm_grouped_impl(int layout, int nprob, const kbner_gemm_problem* probs, int* sched, void* stream);
+static int pick_tile_rows(int layout, int nprob, const kbner_gemm_problem* probs, bool dyn);
 
 int kbner_gemm_bf16_grouped(int layout, int nprob, const kbner_gemm_problem* probs, void* stream) {
   return gemm_grouped_impl(layout, nprob, probs, nullptr, stream);
@@ -652,10 +681,21 @@ int kbner_gemm_bf16_grouped_dyn(int layout, int nprob, const kbner_gemm_problem*
 
 }  // extern "C"
 
+// tile height of a launch: 128-row tiles when the problem is a single forward / dgrad GEMM whose 256 x 256 tiling would give at
+// most half of the CUs a tile (and the static walk is used); 256 otherwise
+static int pick_tile_rows(int layout, int nprob, const kbner_gemm_problem* probs, bool dyn) {
+  if (layout == 2 || nprob != 1 || dyn) return T2;
+  const kbner_gemm_problem& s = probs[0];
+  if (s.M % T2 != 0 || s.N % T2 != 0) return T2;
+  const long tiles = (long)(s.M / T2) * (s.N / T2);
+  return 2 * tiles <= device_cu_count() ? 128 : T2;
+}
+
 static int gemm_grouped_impl(int layout, int nprob, const kbner_gemm_problem* probs, int* sched, void* stream) {
   KBNER_CHECK_ARG(layout >= 0 && layout <= 2 && nprob >= 1 && nprob <= G2_MAXP && probs != nullptr);
   GroupArgs ga;
   ga.nprob = nprob;
+  const int TM = pick_tile_rows(layout, nprob, probs, sched != nullptr);
   int tiles = 0;
   for (int i = 0; i < nprob; ++i) {
     const kbner_gemm_problem& s = probs[i];
@@ -680,7 +720,7 @@ static int gemm_grouped_impl(int layout, int nprob, const kbner_gemm_problem* pr
     d.ldaux = s.ldaux; d.ldout2 = s.ldout2; d.epi = s.epi; d.alpha = s.alpha; d.tile_begin = tiles; d.pad_ = 0;
     d.drop_seed = s.drop_seed; d.drop_thresh = (s.epi & EPI_DROP) ? s.drop_thresh : 0u;
     ga.tile_begin[i] = tiles;
-    tiles += (s.M / T2) * (s.N / T2);
+    tiles += (s.M / TM) * (s.N / T2);
   }
   for (int i = nprob; i < G2_MAXP; ++i) {
     ga.p[i] = ga.p[0];
@@ -699,6 +739,7 @@ static int gemm_grouped_impl(int layout, int nprob, const kbner_gemm_problem* pr
       default: return launch256<true, true, true>(ga, st);
     }
   }
+  if (TM == 128) return layout == 0 ? launch256<false, false, false, 128>(ga, st) : launch256<false, true, false, 128>(ga, st);
   switch (layout) {
     case 0: return launch256<false, false, false>(ga, st);
     case 1: return launch256<false, true, false>(ga, st);

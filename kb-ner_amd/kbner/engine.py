@@ -431,10 +431,12 @@ class Tagger:
                 # column sums (= d ffn1.bias) leave the epilogue as plain stores into a [2 * Mp/256, F] workspace, folded by a
                 # small reduce kernel: per-tile atomics onto the same 4096 addresses were what made this the slowest GEMM
                 if ac.colsum_ws is None:
-                    ac.colsum_ws = torch.empty((2 * (Mp // 256), F_), dtype=F32, device=self.device)
+                    ac.colsum_ws = torch.empty((2 * (Mp // 128), F_), dtype=F32, device=self.device)
+                # (with dynamic tile draw the kernel always uses 256-row tiles)
+                trows = 256 if ops.SCHED_RING is not None else ops.gemm_tile_rows(GEMM_NN, Mp, F_)
                 ops.gemm(GEMM_NN, dhm, a.bf(p + "ffn2.weight"), Mp, F_, H, C=dpre, aux=ac.dact[l],
                          epi=EPI_DGELU | EPI_COLSUM | EPI_COLSUM_WS, colsum=ac.colsum_ws, occupancy=True)
-                ops.colsum_rows_f32(ac.colsum_ws, 2 * (Mp // 256), a.grad(p + "ffn1.bias"))
+                ops.colsum_rows_f32(ac.colsum_ws, 2 * (Mp // trows), a.grad(p + "ffn1.bias"))
             else:
                 ops.gemm(GEMM_NN, dhm, a.bf(p + "ffn2.weight"), Mp, F_, H, C=dpre, aux=ac.dact[l], epi=EPI_DGELU, occupancy=True)
                 ops.colsum(dpre, a.grad(p + "ffn1.bias"))

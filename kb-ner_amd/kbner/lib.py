@@ -45,6 +45,7 @@ SIGNATURES = {
                                 P, c_int, c_int, c_int, c_float, U32, U32, P]),
     "kbner_gemm_bf16_grouped": (c_int, [c_int, c_int, P, P]),
     "kbner_colsum_rows_f32": (c_int, [P, c_int, c_int, P, P]),
+    "kbner_gemm_tile_rows": (c_int, [c_int, c_int, c_int]),
     "kbner_gemm_bf16_grouped_dyn": (c_int, [c_int, c_int, P, P, P]),
     "kbner_splitk_finish": (c_int, [P, c_int, P, P, c_int, P, c_int, c_int, c_int, U32, U32, P]),
     "kbner_attn_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, U32, U32, P]),

@@ -169,6 +169,11 @@ def head_bwd(de, x, w, dw, db):
     return dx
 
 
+def gemm_tile_rows(layout, M, N):
+    """output-tile height (256 or 128) the grouped kernel picks for one (layout, M, N) problem with the static tile walk"""
+    return int(L.load().kbner_gemm_tile_rows(layout, M, N))
+
+
 def colsum_rows_f32(ws, rows, out):
     """out f32[N] += sum over the first `rows` rows of ws f32[>= rows, N] (the EPI_COLSUM_WS workspace)"""
     _chk(ws, F32, "ws"); _chk(out, F32, "out")

@@ -62,7 +62,7 @@ def test_gemm_colsum_epilogue(st, M):
     # the same fp32 partials as the atomic path added in another order
     res = []
     for _ in range(2):
-        ws = torch.full((2 * (M // 256), N), float("nan"), device="cuda")
+        ws = torch.full((2 * (M // ops.gemm_tile_rows(GEMM_NN, M, N)), N), float("nan"), device="cuda")   # 128-row tiles here
         cs2 = torch.full((N,), 3.0, device="cuda")
         C2 = torch.zeros_like(C)
         ops.gemm(GEMM_NN, A, W, M, N, K, C=C2, aux=aux, epi=EPI_DGELU | EPI_COLSUM | EPI_COLSUM_WS, colsum=ws)
