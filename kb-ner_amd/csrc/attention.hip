@@ -173,10 +173,15 @@ static __device__ __forceinline__ bf16x8 tr_at(const unsigned char* base, int of
 // DROP: attention-probability dropout (BertSelfAttention.dropout).  Element (query q, key k) of head (b,h) is kept iff
 // drop_keep(rowkey(bh*S + q), colkey(bh*S + k)) (common.h); the normaliser `sum` / the stored lse are those of the
 // UNdropped softmax, the kept probabilities are scaled by 1/(1-p) through `inv`.
-template <int NKB, bool DROP>
+// PERSIST (whole heads per workgroup, many heads per CU): grid.x workgroups walk the (batch, head) items w, w + grid.x, ... and
+// the NEXT head's panels are DMA'd while the current head is still being computed -- K as soon as every wave has finished the
+// last pass's Q.K^T (one barrier), V when the last P.V is done -- so the ~2.3 us a head's 128 KiB of panels take from L2 are no
+// longer exposed once per head with a single workgroup per CU.
+template <int NKB, bool DROP, bool PERSIST = false>
 __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ maskbias,
                                                           bf16_t* __restrict__ ctx, float* __restrict__ lse, int H, int A,
-                                                          float scale, int rpw, uint32_t drop_seed, uint32_t drop_thresh) {
+                                                          float scale, int rpw, uint32_t drop_seed, uint32_t drop_thresh,
+                                                          int nitems) {
   constexpr int S = NKB * 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sK = smem;
@@ -185,30 +190,34 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const bf16_t* __restri
   uint32_t* sCk = reinterpret_cast<uint32_t*>(sMask + AT_MAXS);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int qt = PERSIST ? 0 : blockIdx.x;
   const int ld = 3 * H;
-  const bf16_t* base = qkv + (size_t)b * S * ld + h * AT_D;
   const float scale2 = scale * 1.4426950408889634f;
-  const uint32_t bhS = (uint32_t)((b * A + h) * S);
   const float dscale = DROP ? drop_scale(drop_thresh) : 1.0f;
   // sMask holds maskbias / scale: it is added to the RAW score sums q.k (the softmax runs on scale2 * (q.k + mask / scale)), and
   // only in 16-key fragments at or behind the first masked key (`nfree16` leading fragments are mask-free: for the prefix masks
   // of padded batches that is every fragment but the tail, for full-length sentences all of them)
-  __shared__ int s_first_masked;
-  if (tid == 0) s_first_masked = S;
-  __syncthreads();
-  {
+  __shared__ int s_first_masked[2];   // two slots: the next item's is filled while the current one's is still read
+  // mask / dropout column keys of item (b_, h_) -> sMask, sCk, s_first_masked[slot_] (which thread 0 has reset to S beforehand)
+  auto stage_mask = [&](int b_, int h_, int slot_) {
     int fm = S;
+    const uint32_t bhS_ = (uint32_t)((b_ * A + h_) * S);
     for (int i = tid; i < S; i += 512) {
-      const float m = maskbias[(size_t)b * S + i];
+      const float m = maskbias[(size_t)b_ * S + i];
       sMask[i] = m * (1.0f / scale);
       if (m != 0.0f && i < fm) fm = i;
-      if (DROP) sCk[i] = drop_colkey(drop_seed, bhS + (uint32_t)i);
+      if (DROP) sCk[i] = drop_colkey(drop_seed, bhS_ + (uint32_t)i);
     }
-    if (fm < S) atomicMin(&s_first_masked, fm);
-  }
-  stage_panel(base + H, ld, S, sK, wid, lane);
-  stage_panel(base + 2 * H, ld, S, sV, wid, lane);
+    if (fm < S) atomicMin(&s_first_masked[slot_], fm);
+  };
+  int item = PERSIST ? (int)blockIdx.x : 0;
+  int h = PERSIST ? item % A : (int)blockIdx.y, b = PERSIST ? item / A : (int)blockIdx.z;
+  int slot = 0;
+  if (tid == 0) s_first_masked[0] = s_first_masked[1] = S;
+  __syncthreads();
+  stage_mask(b, h, 0);
+  stage_panel(qkv + (size_t)b * S * ld + h * AT_D + H, ld, S, sK, wid, lane);
+  stage_panel(qkv + (size_t)b * S * ld + h * AT_D + 2 * H, ld, S, sV, wid, lane);
   const int g = lane >> 4, li = lane & 15;
   // per-lane LDS bases (see kc_frag / tr_frag): K rows f*16 + li -> + f*2048 ; V rows kc*32 + g*4 + (li>>2) -> + kc*4096
   const unsigned char* kb0 = sK + li * 128 + (((0 * 4 + g) ^ kc_swz(li)) << 4);
@@ -218,11 +227,17 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const bf16_t* __restri
 #pragma unroll
   for (int db = 0; db < 4; ++db)
     vb[db] = sV + vrow * 128 + (((db * 2 + ((li & 3) >> 1)) ^ kc_swz(vrow)) << 4) + ((li & 1) << 3);
+  for (;;) {   // items of this workgroup (one iteration unless PERSIST)
+  const bf16_t* base = qkv + (size_t)b * S * ld + h * AT_D;
+  const uint32_t bhS = (uint32_t)((b * A + h) * S);
+  const int next = item + (int)gridDim.x;
+  const bool has_next = PERSIST && next < nitems;
   // K has landed when at most the V pieces (S/64 per wave, issued after K) are still in flight
   wait_vm(S / 64);
   __syncthreads();
-  const int nfree16 = s_first_masked >> 4;   // fragments f < nfree16 hold no masked key
-  bool v_ready = false;
+  const int nfree16 = s_first_masked[slot] >> 4;   // fragments f < nfree16 hold no masked key
+  if (has_next && tid == 0) s_first_masked[slot ^ 1] = S;   // (published by the barrier before the next item's mask is staged)
+  bool v_ready = false, k_next = false;
 #pragma unroll 1
   for (int pass = 0; pass < rpw / 128; ++pass) {
     const int q0 = qt * rpw + wid * (rpw / 8) + pass * 16;
@@ -279,8 +294,16 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const bf16_t* __restri
       }
       if (DROP) sum = group4_sum(sum);
     }
+    if (has_next && pass == rpw / 128 - 1) {
+      // every wave is past the last Q.K^T / softmax of this head: sK, sMask and sCk are dead -> the next head's mask and K panel
+      __syncthreads();
+      const int hn = next % A, bn = next / A;
+      stage_mask(bn, hn, slot ^ 1);
+      stage_panel(qkv + (size_t)bn * S * ld + hn * AT_D + H, ld, S, sK, wid, lane);
+      k_next = true;
+    }
     if (!v_ready) {  // first pass only (uniform): V is needed from here on
-      wait_vm(0);
+      wait_vm(k_next ? S / 64 : 0);
       __syncthreads();
       v_ready = true;
     }
@@ -323,6 +346,14 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const bf16_t* __restri
       if (g == 0) lse[((size_t)b * A + h) * S + q0 + li] = (mx + __log2f(sum)) * 0.6931471805599453f;
     }
   }
+  if (!has_next) break;
+  __syncthreads();   // every wave is done with sV: the next head's V panel
+  item = next;
+  h = item % A;
+  b = item / A;
+  slot ^= 1;
+  stage_panel(qkv + (size_t)b * S * ld + h * AT_D + 2 * H, ld, S, sV, wid, lane);
+  }  // items
 }
 
 // Column sums of a [16 rows x 64 cols] output fragment set accumulated over a workgroup's passes: the bias gradient of the
@@ -1008,18 +1039,38 @@ static inline int pick_rpw(int B, int S, int A) {
   return rpw;
 }
 
+static int at_cu_count() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+
 template <int NKB, bool DROP>
 static int launch_attn_fwd2(const bf16_t* qkv, const float* maskbias, bf16_t* ctx, float* lse, int B, int H, int A, int rpw,
                             uint32_t seed, uint32_t thresh, hipStream_t stream) {
   static bool once = false;
   if (!once) {
-    int r = set_lds(reinterpret_cast<const void*>(attn_fwd_kernel<NKB, DROP>), AT_LDS_BYTES);
+    int r = set_lds(reinterpret_cast<const void*>(attn_fwd_kernel<NKB, DROP, false>), AT_LDS_BYTES);
+    if (r) return r;
+    r = set_lds(reinterpret_cast<const void*>(attn_fwd_kernel<NKB, DROP, true>), AT_LDS_BYTES);
     if (r) return r;
     once = true;
   }
   const int S = NKB * 16;
-  hipLaunchKernelGGL((attn_fwd_kernel<NKB, DROP>), dim3((S + rpw - 1) / rpw, A, B), dim3(512), AT_LDS_BYTES, stream, qkv, maskbias,
-                     ctx, lse, H, A, 0.125f, rpw, seed, thresh);
+  const int ncu = at_cu_count();
+  if (rpw == S && B * A >= 2 * ncu) {   // whole heads, at least two per CU: walk them persistently, prefetching the next (-4 % at
+                                        // full length, -8 % with ragged masks, tools/attn_bench.py at B = 128)
+    hipLaunchKernelGGL((attn_fwd_kernel<NKB, DROP, true>), dim3(ncu), dim3(512), AT_LDS_BYTES, stream, qkv, maskbias, ctx, lse, H, A,
+                       0.125f, rpw, seed, thresh, B * A);
+  } else {
+    hipLaunchKernelGGL((attn_fwd_kernel<NKB, DROP, false>), dim3((S + rpw - 1) / rpw, A, B), dim3(512), AT_LDS_BYTES, stream, qkv,
+                       maskbias, ctx, lse, H, A, 0.125f, rpw, seed, thresh, 1);
+  }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }
