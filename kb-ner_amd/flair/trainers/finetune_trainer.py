@@ -407,7 +407,7 @@ class ModelFinetuner:
         log_line(log)
         self.model.eval()
         for name in ("best-model.pt", "final-model.pt"):
-            if (base_path / name).exists():
+            if (base_path / name).exists() and getattr(self.model, "engine", None) is not None:
                 state = torch.load(str(base_path / name), map_location="cpu", weights_only=False)
                 self.model.engine.load_hf_state_dict(state["encoder_state_dict"])
                 for k in ("linear.weight", "linear.bias", "transitions"):

@@ -639,3 +639,37 @@ def ColumnDataLoaderFor(trainer, cp):
                           sentence_level_batch=trainer.sentence_level_batch, sort_data=True)
     dl.assign_tags(trainer.model.tag_type, trainer.model.tag_dictionary)
     return dl
+
+
+def test_train_py_command_line(tmp_path):
+    """this repo's train.py as a user runs it (subprocesses, the reference's flags): fine-tune, --test, --parse of a folder of
+    CoNLL files in file order with --predict_posterior, --test_speed"""
+    import subprocess
+    import sys
+    import tiny_assets
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = tiny_assets.e2e_config(str(tmp_path), word_dropout=0.1, max_epochs=2, n_train=12, n_dev=4, n_test=5)
+    with open(tmp_path / "cfg.yaml", "w") as f:
+        yaml.safe_dump(cfg, f)
+
+    def run(*extra):
+        r = subprocess.run([sys.executable, os.path.join(root, "train.py"), "--config", str(tmp_path / "cfg.yaml")] + list(extra),
+                           cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert r.returncode == 0, r.stderr.decode(errors="replace")[-3000:]
+        return r.stdout.decode(errors="replace") + r.stderr.decode(errors="replace")
+
+    run()
+    base = tmp_path / "out" / "tiny_run"
+    assert (base / "best-model.pt").exists() and (base / "final-model.pt").exists() and (base / "loss.tsv").exists()
+    out = run("--test")
+    assert "Testing using best model" in out and (base / "ColumnCorpus-TINY-test.tsv").exists()
+    # --parse: a folder with a train.txt in the 4-column KB-NER format, kept in file order, marginal decoding
+    tiny_assets.write_conll_corpus(str(tmp_path / "new"), n_train=7, n_dev=1, n_test=1, seed=11)
+    out = run("--parse", "--target_dir", str(tmp_path / "new"), "--num_columns", "4", "--comment_symbol", "# id", "--keep_order",
+              "--predict_posterior", "--output_dir", str(tmp_path / "parsed"))
+    pred = (tmp_path / "parsed" / "new.conllu").read_text().split("\n")
+    src_tokens = [l.split(" ")[0] for l in (tmp_path / "new" / "train.txt").read_text().split("\n") if l and not l.startswith("# id")]
+    assert [l.split(" ")[0] for l in pred if l] == src_tokens          # every token, in file order
+    assert all(len(l.split(" ")) == 4 for l in pred if l)
+    out = run("--test_speed")
+    assert any(l.strip().replace(".", "", 1).isdigit() for l in out.split("\n"))      # the reference prints the bare rate

@@ -8,8 +8,9 @@
     torchrun --nproc-per-node 8 train.py --config ...                # data-parallel over RCCL (new capability)
 
 The reference's own train.py also runs unchanged against this package (put kb-ner_amd/ on PYTHONPATH): it only needs the
-flair.* import surface listed in SURVEY.md §8b.  Modes outside the hot path (--zeroshot/--all/--other/--predict/--mst/...)
-are rejected explicitly."""
+flair.* import surface listed in SURVEY.md §8b.  --predict_posterior (marginal decoding), --v2doc (document-window context)
+and, for `trainer: ReinforcementTrainer` YAMLs (the ACE stack), --test / --parse with the controller's `best_action` from
+training_state.pt are supported; modes outside the hot path (--zeroshot/--all/--other/--predict/--mst/...) are rejected."""
 import argparse
 import logging
 import os
@@ -48,7 +49,7 @@ def main():
                  "parse_train_and_dev", "eval_train", "debug", "remove_x"):
         ap.add_argument("--" + flag, action="store_true")
     args = ap.parse_args()
-    for flag in ("zeroshot", "all", "other", "nocrf", "predict", "mst", "predict_posterior", "recur_parse", "v2doc"):
+    for flag in ("zeroshot", "all", "other", "nocrf", "predict", "mst", "recur_parse"):
         if getattr(args, flag):
             sys.exit("--%s is outside the XLM-R + CRF hot path of this build" % flag)
     if args.quiet:
@@ -62,13 +63,38 @@ def main():
     log.info("Model Size: %d", sum(p.numel() for p in student.parameters()))
     corpus = cp.corpus
     trainer_name = cp.config.get("trainer", "ModelFinetuner")
-    if trainer_name != "ModelFinetuner":
+    if trainer_name not in ("ModelFinetuner", "ReinforcementTrainer"):
         sys.exit("trainer %s is outside the hot path" % trainer_name)
+    inference = args.test or args.parse or args.parse_test or args.test_speed
+    if trainer_name == "ReinforcementTrainer" and not inference:
+        sys.exit("ReinforcementTrainer (ACE) YAMLs are supported for --test / --parse only: training the controller is out of scope")
     tcfg = dict(cp.config.get(trainer_name, {}))
     tcfg.setdefault("distill_mode", False)
     trainer = getattr(flair.trainers, trainer_name)(student, None, corpus, config=cp.config, **tcfg, is_test=args.test or args.parse)
     train_config = dict(cp.config["train"])
     base_path = cp.get_target_path
+    if args.remove_x:                      # train.py:211-213
+        student.remove_x = True
+    if args.predict_posterior:             # marginal (forward-backward) decoding instead of Viterbi
+        student.predict_posterior = True
+    embs = student.embeddings.embeddings if hasattr(student.embeddings, "embeddings") else [student.embeddings]
+    if args.v2doc:                         # train.py:223-224: document-window context around every sentence
+        for e in embs:
+            if hasattr(e, "v2_doc"):
+                e.v2_doc = True
+    if trainer_name == "ReinforcementTrainer":
+        # train.py:214-218: the embedding subset the controller settled on; the stack's own weights come from stack-model.pt
+        # ({"rnn": LSTM state dict, "linear.weight", "linear.bias", "transitions"}; INTEGRATION.md shows the two-line export to
+        # run next to the reference's checkpoint -- its .pt pickles the reference's classes and cannot be read here)
+        import torch
+        state = torch.load(str(Path(base_path) / "training_state.pt"), map_location="cpu", weights_only=False)
+        student.selection = [int(x) for x in state["best_action"]]
+        log.info("Setting embedding mask to the best action: %s (%s)", student.selection, sorted(e.name for e in embs))
+        stack_file = Path(base_path) / "stack-model.pt"
+        if stack_file.exists():
+            student.load_stack_state(torch.load(str(stack_file), map_location="cpu", weights_only=False))
+        else:
+            log.warning("%s not found: the BiLSTM / CRF head keeps its initial weights", stack_file)
     eval_bs = args.batch_size if args.batch_size > 0 else max(32, int(train_config.get("mini_batch_size", 32)))
 
     if args.save_embedding:
@@ -83,7 +109,8 @@ def main():
         trainer.final_test(base_path, eval_mini_batch_size=eval_bs, quiet_mode=args.quiet, sort_data=not args.keep_order)
         return
     if args.parse or args.parse_test:
-        _load_trained(student, base_path)
+        if trainer_name == "ModelFinetuner":
+            _load_trained(student, base_path)
         tag_col = student.tag_type
         if args.parse_test:
             sets = list(zip(corpus.targets, corpus.test_list))
