@@ -217,6 +217,23 @@ def test_config5_yaml_route(assets, tmp_path):
     assert len(lines) == sum(len(s) for s in cp.corpus.test_list[0])
     assert all(len(l.split(" ")) == 4 and l.split(" ")[1] != "S-X" for l in lines)
     assert np.isfinite(loss) and 0.0 <= res.main_score <= 1.0
+    # the same through the command line (train.py --test): best_action from training_state.pt, head from stack-model.pt
+    import subprocess
+    import sys
+    base = cp.get_target_path
+    os.makedirs(base, exist_ok=True)
+    torch.save({"episode": 3, "best_action": sel}, str(base / "training_state.pt"))
+    torch.save(student._stack_state, str(base / "stack-model.pt"))
+    root = os.path.dirname(HERE)
+    r = subprocess.run([sys.executable, os.path.join(root, "train.py"), "--config", str(tmp_path / "cfg.yaml"), "--test", "--keep_order"],
+                       cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode(errors="replace")[-3000:]
+    cli = [l.split(" ") for l in open(base / "ColumnCorpus-TINY-test.tsv").read().split("\n") if l]
+    mine = [l.split(" ") for l in lines]
+    assert len(cli) == len(mine) and [c[:3] for c in cli] == [m[:3] for m in mine]    # same tokens, gold, predicted tags
+    r = subprocess.run([sys.executable, os.path.join(root, "train.py"), "--config", str(tmp_path / "cfg.yaml")],
+                       cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode != 0 and b"out of scope" in r.stderr + r.stdout               # training an ACE YAML is refused, loudly
     student.selection = [1] * len(names)
     with pytest.raises(NotImplementedError, match="not available offline|no device producer"):
         student.evaluate(loader, embeddings_storage_mode="none", prediction_mode=True)   # a selected placeholder refuses
