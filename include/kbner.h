@@ -112,7 +112,7 @@ int kbner_embed_ln_bwd(const kbner_bf16* dy, const kbner_bf16* h0, const float* 
 /* ---------------- dropout (torch.nn.Dropout inside transformers' BertEmbeddings / BertSelfAttention / BertSelfOutput /
  * BertOutput, active while ModelFinetuner trains: finetune_trainer.py:938 model.train()) ----------------
  * Counter-based and replayable: element (i,j) of a site is kept iff
- *   ((mix(seed + i) ^ mix((seed*0x9E3779B1 + 0x7F4A7C15) ^ j)) * 0x9E3779B1) >= drop_thresh,  drop_thresh = p * 2^32,
+ *   mul24(mix(seed + i) ^ mix((seed*0x9E3779B1 + 0x7F4A7C15) ^ j), 0x9E3779) >= drop_thresh,  drop_thresh = p * 2^32 (mul24: the low 24 bits of both factors, low 32 bits of the product),
  * kept values are scaled by 1/(1-p).  No mask is stored: backward passes the same (seed, thresh).  drop_thresh = 0 disables.
  * kbner_dropout_mask materialises the multiplier (tests): out f32[Z,M,N], element (z,i,j) -> keys (z*M+i, z*N+j). */
 int kbner_dropout_mask(float* out, int Z, int M, int N, uint32_t seed, uint32_t thresh, void* stream);

@@ -50,7 +50,7 @@ static __device__ __forceinline__ float wave_max(float v) {
 
 // Counter-based dropout shared by every kernel that applies or replays a mask (GEMM epilogue, LayerNorm
 // backward, embeddings, attention forward / dQ / dKdV): element (i, j) of a site is kept iff
-//   ((rowkey(seed, i) ^ colkey(seed, j)) * 0x9E3779B1) >= thresh        thresh = p * 2^32
+//   mul24(rowkey(seed, i) ^ colkey(seed, j), 0x9E3779) >= thresh        thresh = p * 2^32   (24-bit x 24-bit -> low 32 bits)
 // The separable form costs one xor + one multiply + one compare per element whichever axis a lane walks (the
 // attention kernels see the same probability tile in both orientations), needs no stored mask, and is replayed
 // bit-identically in backward from (seed, thresh) alone.
@@ -67,7 +67,11 @@ static __device__ __forceinline__ uint32_t drop_colkey(uint32_t seed, uint32_t j
   return drop_mix((seed * 0x9E3779B1u + 0x7F4A7C15u) ^ j);
 }
 static __device__ __forceinline__ bool drop_keep(uint32_t rk, uint32_t ck, uint32_t thresh) {
-  return ((rk ^ ck) * 0x9E3779B1u) >= thresh;
+  // 24-bit multiply (v_mul_u32_u24, full rate) of the low 24 bits of the key xor: the 32-bit v_mul_lo_u32 it replaces is a
+  // quarter-rate instruction and was ~40 % of what dropout adds to the attention kernels (one test per probability).  The
+  // product of a uniform 24-bit value with an odd 24-bit constant is equidistributed mod 2^32, so P(keep) = 1 - thresh / 2^32
+  // to within 2^-24; the multiply is what breaks the xor's linearity (a bare threshold on rk ^ ck drops whole rectangles).
+  return __umul24(rk ^ ck, 0x9E3779u) >= thresh;
 }
 static __host__ __device__ __forceinline__ float drop_scale(uint32_t thresh) {
   return 4294967296.0f / (4294967296.0f - (float)thresh);
