@@ -78,6 +78,32 @@ static __device__ __forceinline__ void glds16(const void* sbase, unsigned voff, 
                : "v"(voff), "s"(sbase), "s"(dst)
                : "memory");
 }
+// A wave's 2 or 4 consecutive 1-KiB pieces under ONE M0 write: the instruction's immediate offset advances BOTH the LDS and the
+// global address by j KiB, so the j-th per-lane offset is passed as voff_j - j * 1024 (never negative: a piece step is >= 1 KiB
+// of source bytes for every image, ld >= 64).  Saves three of the four (s_mov m0 / s_nop / restore) sequences per operand tile.
+static __device__ __forceinline__ void glds16x4(const void* sbase, unsigned v0, unsigned v1, unsigned v2, unsigned v3, void* l) {
+  const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void*)l);
+  // (m0 is declared clobbered instead of being saved and restored: nothing else in these kernels keeps a value in it)
+  asm volatile(
+      "s_mov_b32 m0, %5\n\ts_nop 0\n\t"
+      "global_load_lds_dwordx4 %0, %4\n\t"
+      "global_load_lds_dwordx4 %1, %4 offset:1024\n\t"
+      "global_load_lds_dwordx4 %2, %4 offset:2048\n\t"
+      "global_load_lds_dwordx4 %3, %4 offset:3072"
+      :
+      : "v"(v0), "v"(v1 - 1024u), "v"(v2 - 2048u), "v"(v3 - 3072u), "s"(sbase), "s"(dst)
+      : "memory", "m0");
+}
+static __device__ __forceinline__ void glds16x2(const void* sbase, unsigned v0, unsigned v1, void* l) {
+  const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void*)l);
+  asm volatile(
+      "s_mov_b32 m0, %3\n\ts_nop 0\n\t"
+      "global_load_lds_dwordx4 %0, %2\n\t"
+      "global_load_lds_dwordx4 %1, %2 offset:1024"
+      :
+      : "v"(v0), "v"(v1 - 1024u), "s"(sbase), "s"(dst)
+      : "memory", "m0");
+}
 static __device__ __forceinline__ int kc_swz(int row) { return (row >> 1) & 7; }
 static __device__ __forceinline__ int ks_swz(int krow) { return (krow & 3) | ((krow >> 1) & 4); }
 // B operand, KC image: a fragment's 16 lanes read rows {8a + 4h + c : a,c in 0..3} of a 32-row block (the column
@@ -95,21 +121,23 @@ static __device__ __forceinline__ void stage256(const bf16_t* __restrict__ P, in
   static_assert(ROWS == 256 || (ROWS == 128 && !KS), "half-height tiles exist for the row-major (KC) A image only");
   // uniform tile origin in SGPRs
   const bf16_t* sbase = KS ? P + (size_t)k0 * ld + row0 : P + (size_t)row0 * ld + k0;
+  unsigned voff[ROWS / 64];
 #pragma unroll
   for (int j = 0; j < ROWS / 64; ++j) {
     const int q = wid * (ROWS / 64) + j;  // ROWS / 8 wave-instructions x 1 KiB (32 KiB for a 256-row tile)
-    unsigned voff;
     if (!KS) {
       const int row = q * 8 + (lane >> 3);
       const int pos = lane & 7;
-      voff = (unsigned)(row * ld + ((pos ^ (ISB ? kcb_swz(row) : kc_swz(row))) << 3)) * 2u;
+      voff[j] = (unsigned)(row * ld + ((pos ^ (ISB ? kcb_swz(row) : kc_swz(row))) << 3)) * 2u;
     } else {
       const int kr = q * 2 + (lane >> 5);
       const int pos = lane & 31;
-      voff = (unsigned)(kr * ld + ((pos ^ (ks_swz(kr) << 1)) << 3)) * 2u;
+      voff[j] = (unsigned)(kr * ld + ((pos ^ (ks_swz(kr) << 1)) << 3)) * 2u;
     }
-    glds16(sbase, voff, s + q * 1024);
   }
+  unsigned char* dst = s + wid * (ROWS / 64) * 1024;   // this wave's pieces are consecutive in the image
+  if constexpr (ROWS == 256) glds16x4(sbase, voff[0], voff[1], voff[2], voff[3], dst);
+  else glds16x2(sbase, voff[0], voff[1], dst);
 }
 
 template <bool KS>
