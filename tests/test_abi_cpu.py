@@ -22,6 +22,17 @@ def test_build_and_symbols():
     assert handle.kbner_abi_version() == 2
 
 
+def test_integration_doc_maps_every_symbol():
+    """INTEGRATION.md section C names every entry point of the header (what it replaces in the reference, who calls it here)."""
+    import __graft_entry__ as ge
+    hdr = open(os.path.join(ge.ROOT, "include", "kbner.h")).read()
+    declared = set(re.findall(r"\b(kbner_[a-z0-9_]+)\s*\(", hdr))
+    doc = open(os.path.join(ge.ROOT, "INTEGRATION.md")).read()
+    table = doc[doc.index("## C. Symbol map"):]
+    missing = sorted(n for n in declared if "`%s`" % n not in table)
+    assert not missing, missing
+
+
 def test_product_path_never_imports_oracle():
     """oracle/ is test infrastructure: nothing under kb-ner_amd/ imports it (the checker behind smoke() lives in tests/)."""
     import __graft_entry__ as ge
