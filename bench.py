@@ -20,6 +20,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "kb-ner_amd"))
 
 MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16
+SUSTAINED_MFMA_RANDOM_BF16_TFLOPS = 1993.0   # measured, profiles/round2_mfma_power.txt (v_mfma_f32_16x16x32_bf16, 2.03-2.16 GHz)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -283,6 +284,10 @@ def main():
                     "frac": round(ach / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "algorithmic_flops_per_launch": round(tot_fl / max(len(recs), 1)),
                     "launches_per_step": len(recs), "gemm_ms_per_step": round(tot_ms, 3),
+                    # informational: what a register-only MFMA loop sustains on random bf16 operands under the 1400 W package
+                    # cap (tools/micro/mfma_power.hip, profiles/round2_mfma_power.txt); `peak` / `frac` stay the data-sheet ones
+                    "sustained_mfma_peak_random_bf16": SUSTAINED_MFMA_RANDOM_BF16_TFLOPS,
+                    "frac_of_sustained": round(ach / SUSTAINED_MFMA_RANDOM_BF16_TFLOPS, 4),
                     "by_layout": {("NT_fwd", "NN_dgrad", "TN_wgrad")[k]: {"tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 2),
                                                                               "ms": round(v[1], 3), "launches": v[2]}
                                   for k, v in sorted(by.items())}}
