@@ -10,7 +10,9 @@
  *   - return 0 on success, -22 (EINVAL) on a bad argument, -(hipError_t) on a launch failure; never throw/exit
  *   - every pointer is a DEVICE pointer owned by the caller (torch) and kept alive until the stream drains
  *   - `stream` is a hipStream_t (NULL = default stream); work is enqueued asynchronously on it
- *   - no global mutable state, no device allocation: callers pass workspaces
+ *   - no device allocation: callers pass workspaces.  The only mutable process state is a set of once-per-device flags (a
+ *     kernel's dynamic-LDS limit has been raised on device d; the CU count of device d), kept in atomics: entry points may be
+ *     called from several host threads and on several devices
  *   - bf16 tensors are raw uint16_t storage, row-major; fp32 statistics / optimizer state / CRF
  */
 #ifndef KBNER_H
@@ -65,7 +67,8 @@ int kbner_crf_posterior_kl(const float* emit_s, const float* emit_t, const float
 /* n-best Viterbi (SequenceTagger._viterbi_decode_nbest, sequence_tagger_model.py:1660-1818; called on KD teachers at
  * finetune_trainer.py:1600, distillation_trainer.py:819): decode i32 [B, n, nbest] tag indices and path_score f32 [B, nbest]
  * (softmax over the nbest end scores).  The NCRF++ decoder's conventions are kept as they are: trans indexed [from, to],
- * padded positions decode to 0 except the last column.  ws: kbner_crf_viterbi_nbest_ws_bytes(B, n, T, nbest) bytes. */
+ * padded positions decode to 0 except the last column.  ws: kbner_crf_viterbi_nbest_ws_bytes(B, n, T, nbest) bytes.
+ * 1 <= nbest <= min(16, T): the first step offers T candidates, the reference's topk raises beyond that (-> -22 here). */
 size_t kbner_crf_viterbi_nbest_ws_bytes(int B, int n, int T, int nbest);
 int kbner_crf_viterbi_nbest(const float* emit, const float* trans, const int* lens, int B, int n, int T, int start, int stop,
                             int nbest, void* ws, int* decode, float* path_score, void* stream);

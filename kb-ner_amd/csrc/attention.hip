@@ -885,11 +885,6 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv2_kernel(const bf16_t* __rest
   }
 }
 
-static int set_lds(const void* f, int bytes) {
-  hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-  return e == hipSuccess ? 0 : -(int)e;
-}
-
 #define AT_LDS_BYTES (2 * AT_MAXS * 128 + 3 * AT_MAXS * 4)
 
 // rows per workgroup: the whole head (one DMA of each panel per head) when the grid still covers the
@@ -900,28 +895,16 @@ static inline int pick_rpw(int B, int S, int A) {
   return rpw;
 }
 
-static int at_cu_count() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
-    if (n <= 0) n = 256;
-  }
-  return n;
-}
+static int at_cu_count() { return kbner_cu_count(); }
 
 template <int NKB, bool DROP>
 static int launch_attn_fwd2(const bf16_t* qkv, const float* maskbias, bf16_t* ctx, float* lse, int B, int H, int A, int rpw,
                             uint32_t seed, uint32_t thresh, hipStream_t stream) {
-  static bool once = false;
-  if (!once) {
-    int r = set_lds(reinterpret_cast<const void*>(attn_fwd_kernel<NKB, DROP, false>), AT_LDS_BYTES);
-    if (r) return r;
-    r = set_lds(reinterpret_cast<const void*>(attn_fwd_kernel<NKB, DROP, true>), AT_LDS_BYTES);
-    if (r) return r;
-    once = true;
-  }
+  static std::atomic<unsigned long long> done0{0}, done1{0};   // one bit per device (common.h)
+  int r = kbner_set_max_lds_once(done0, reinterpret_cast<const void*>(attn_fwd_kernel<NKB, DROP, false>), AT_LDS_BYTES);
+  if (r) return r;
+  r = kbner_set_max_lds_once(done1, reinterpret_cast<const void*>(attn_fwd_kernel<NKB, DROP, true>), AT_LDS_BYTES);
+  if (r) return r;
   const int S = NKB * 16;
   const int ncu = at_cu_count();
   if (rpw == S && B * A >= 2 * ncu) {   // whole heads, at least two per CU: walk them persistently, prefetching the next (-4 % at
@@ -945,27 +928,20 @@ static int launch_attn_fwd(const bf16_t* qkv, const float* maskbias, bf16_t* ctx
 template <bool DROP>
 static int launch_attn_bwd(const bf16_t* qkv, const bf16_t* ctx, const bf16_t* dctx, const float* maskbias, const float* lse, float* Dws,
                            bf16_t* dqkv, int B, int S, int H, int A, uint32_t seed, uint32_t thresh, float* dbias, hipStream_t s) {
-  static bool once = false;
-  if (!once) {
-    int r = set_lds(reinterpret_cast<const void*>(attn_bwd_dq_kernel<DROP>), AT_LDS_BYTES);
-    if (r) return r;
-    r = set_lds(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<DROP>), AT_LDS_BYTES);
-    if (r) return r;
-    once = true;
-  }
+  static std::atomic<unsigned long long> done0{0}, done1{0}, done2{0}, done3{0};   // one bit per device (common.h)
+  int r = kbner_set_max_lds_once(done0, reinterpret_cast<const void*>(attn_bwd_dq_kernel<DROP>), AT_LDS_BYTES);
+  if (r) return r;
+  r = kbner_set_max_lds_once(done1, reinterpret_cast<const void*>(attn_bwd_dkv_kernel<DROP>), AT_LDS_BYTES);
+  if (r) return r;
   int rpw = pick_rpw(B, S, A);
   if (rpw < 16 * AT_NWB) rpw = 16 * AT_NWB;  // every wave owns at least one 16-row pass
   const dim3 grid((S + rpw - 1) / rpw, A, B);
   // 32-row-stationary kernels whenever a workgroup's row tile gives each of its 8 waves whole 32-row passes
   if (rpw % 256 == 0 && S % 32 == 0) {
-    static bool once2 = false;
-    if (!once2) {
-      int r = set_lds(reinterpret_cast<const void*>(attn_bwd_dq2_kernel<DROP>), AT_LDS_BYTES);
-      if (r) return r;
-      r = set_lds(reinterpret_cast<const void*>(attn_bwd_dkv2_kernel<DROP>), AT_LDS_BYTES);
-      if (r) return r;
-      once2 = true;
-    }
+    r = kbner_set_max_lds_once(done2, reinterpret_cast<const void*>(attn_bwd_dq2_kernel<DROP>), AT_LDS_BYTES);
+    if (r) return r;
+    r = kbner_set_max_lds_once(done3, reinterpret_cast<const void*>(attn_bwd_dkv2_kernel<DROP>), AT_LDS_BYTES);
+    if (r) return r;
     hipLaunchKernelGGL(attn_bwd_dq2_kernel<DROP>, grid, dim3(512), AT_LDS_BYTES, s, qkv, dctx, ctx, maskbias, lse, Dws, dqkv, S, H, A,
                        0.125f, rpw, seed, thresh, dbias);
     hipLaunchKernelGGL(attn_bwd_dkv2_kernel<DROP>, grid, dim3(512), AT_LDS_BYTES, s, qkv, dctx, maskbias, lse, Dws, dqkv, S, H, A,

@@ -452,7 +452,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd3_kernel(const bf16_t* __restr
     a3_stamp<PROF>(pr, 11);
     // Everything this item reads in its first two steps (its Q fragments, K blocks 0..2, V blocks 0..1, the mask row) is older
     // than the youngest `top_wait` instructions when the previous item rolled its blocks in over >= 6 steps (end of the loop)
-    a3_wait_vm_n(top_wait);
+    if (!(dbg & 2)) a3_wait_vm_n(top_wait);
     a3_frags_landed(qf);
     a3_barrier();
     a3_stamp<PROF>(pr, 0);
@@ -463,7 +463,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd3_kernel(const bf16_t* __restr
       if (tid < S) sCk[tid] = drop_colkey(drop_seed, bhS + (uint32_t)tid);
       a3_barrier();
     }
-    const bf16_t* nK = qkv + (size_t)nbh * S * ld + nh * AT_D + H;
+    // (dbg bit 16: timing experiment, always re-fetch the first head's panels -- L2-resident sources)
+    const bf16_t* nK = (dbg & 16) ? qkv + H : qkv + (size_t)nbh * S * ld + nh * AT_D + H;
     const bf16_t* nV = nK + H;
     A3Fwd st;
     uint32_t rk[2] = {0u, 0u};
@@ -514,13 +515,13 @@ __global__ __launch_bounds__(512, 2) void attn_fwd3_kernel(const bf16_t* __restr
 #define A3_ROLL(KB)                                                                                          \
   {                                                                                                          \
     const bool roll = has_next && !(dbg & 1) && (((KB) + 1) % rolln == 0);                                   \
-    if ((KB) == 0) a3_wait_vm_n(0);                                                                          \
-    if ((KB) == 0 || roll) a3_barrier();                                                                     \
+    if ((KB) == 0 && !(dbg & 2)) a3_wait_vm_n(0);                                                            \
+    if (((KB) == 0 || roll) && !(dbg & 4)) a3_barrier();                                                     \
     if (roll) {                                                                                              \
       if ((KB) + 1 == rolln) a3_dma_mask(maskbias + (size_t)nbh * S, S, sMaskB + (slot ^ 1) * 2048, wid, lane); \
       for (int blk = (KB) + 1 - rolln; blk <= (KB); ++blk) a3_dma_block(nK, ld, blk, sK, (ringn + blk) & 7, wid, lane); \
       for (int blk = (KB)-rolln; blk < (KB); ++blk)                                                          \
-        if (blk >= 0) a3_dma_block(nV, ld, blk, sV, (ringn + blk) & 7, wid, lane);                           \
+        if (blk >= 0 && !(dbg & 8)) a3_dma_block(nV, ld, blk, sV, (ringn + blk) & 7, wid, lane);             \
     }                                                                                                        \
   }                                                                                                          \
   a3_stamp<PROF>(pr, 2);
@@ -555,7 +556,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd3_kernel(const bf16_t* __restr
       const int vfirst = nrolled > 0 ? nrolled - 1 : 0;
       if (nrolled == 0) a3_dma_mask(maskbias + (size_t)nbh * S, S, sMaskB + (slot ^ 1) * 2048, wid, lane);
       for (int blk = kfirst; blk < nb; ++blk) a3_dma_block(nK, ld, blk, sK, (ringn + blk) & 7, wid, lane);
-      for (int blk = vfirst; blk < nb; ++blk) a3_dma_block(nV, ld, blk, sV, (ringn + blk) & 7, wid, lane);
+      if (!(dbg & 8))
+        for (int blk = vfirst; blk < nb; ++blk) a3_dma_block(nV, ld, blk, sV, (ringn + blk) & 7, wid, lane);
       nfinal = nrolled >= 2 ? (nb - kfirst) + (nb - vfirst) : -1;
     }
     a3_stamp<PROF>(pr, 5);
@@ -593,31 +595,20 @@ __global__ __launch_bounds__(512, 2) void attn_fwd3_kernel(const bf16_t* __restr
   }
 }
 
-static int a3_set_lds(const void* f, int bytes) {
-  hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-  return e == hipSuccess ? 0 : -(int)e;
-}
-
-static int a3_cu_count() {
-  int dev = 0;
-  hipDeviceProp_t prop;
-  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-    return prop.multiProcessorCount;
-  return 256;
-}
-
 template <bool DROP>
 static int launch_fwd3(const bf16_t* qkv, const float* maskbias, bf16_t* ctx, float* lse, int B, int S, int H, int A, uint32_t seed,
                        uint32_t thresh, hipStream_t stream) {
-  static int ncu = 0, dbg = 0, prof = 0, sgb = 0, rolln = 1;
+  static int dbg = -1, prof = 0, sgb = 0, rolln = 1;   // debug switches of this experimental kernel (environment, read once)
   static unsigned long long* profbuf = nullptr;
-  if (ncu == 0) {
-    int r = a3_set_lds(reinterpret_cast<const void*>(attn_fwd3_kernel<DROP, false, 0>), A3_LDS_BYTES);
-    if (r) return r;
-    r = a3_set_lds(reinterpret_cast<const void*>(attn_fwd3_kernel<DROP, false, 1>), A3_LDS_BYTES);
-    if (r) return r;
-    r = a3_set_lds(reinterpret_cast<const void*>(attn_fwd3_kernel<DROP, true, 0>), A3_LDS_BYTES);
-    if (r) return r;
+  static std::atomic<unsigned long long> done0{0}, done1{0}, done2{0};
+  int r = kbner_set_max_lds_once(done0, reinterpret_cast<const void*>(attn_fwd3_kernel<DROP, false, 0>), A3_LDS_BYTES);
+  if (r) return r;
+  r = kbner_set_max_lds_once(done1, reinterpret_cast<const void*>(attn_fwd3_kernel<DROP, false, 1>), A3_LDS_BYTES);
+  if (r) return r;
+  r = kbner_set_max_lds_once(done2, reinterpret_cast<const void*>(attn_fwd3_kernel<DROP, true, 0>), A3_LDS_BYTES);
+  if (r) return r;
+  const int ncu = kbner_cu_count();
+  if (dbg < 0) {
     const char* e = getenv("KBNER_ATTN_DBG");
     dbg = e ? atoi(e) : 0;
     e = getenv("KBNER_ATTN_PROF");
@@ -628,7 +619,6 @@ static int launch_fwd3(const bf16_t* qkv, const float* maskbias, bf16_t* ctx, fl
     rolln = e ? atoi(e) : 1;
     if (rolln < 1) rolln = 1;
     if (prof && hipMalloc(&profbuf, 4 * 8 * 12 * sizeof(unsigned long long)) != hipSuccess) prof = 0;
-    ncu = a3_cu_count();
   }
   const int nitems = B * A * ((S + A3_ROWS - 1) / A3_ROWS);
   const int grid = nitems < ncu ? nitems : ncu;

@@ -20,6 +20,36 @@
 
 typedef uint16_t bf16_t;  // raw bfloat16 storage
 
+// One-off per-DEVICE host-side initialisation (a kernel's dynamic-LDS limit, a device's CU count): a bit per device ordinal in an
+// atomic mask, so a second device gets its own call and two host threads racing here both make the same idempotent call.  This
+// is the only mutable process state of the library (include/kbner.h, conventions).
+#include <atomic>
+static inline int kbner_device_ordinal() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+  return dev & 63;
+}
+static inline int kbner_set_max_lds_once(std::atomic<unsigned long long>& done, const void* kernel, int bytes) {
+  const unsigned long long bit = 1ull << kbner_device_ordinal();
+  if (done.load(std::memory_order_acquire) & bit) return 0;
+  hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return -(int)e;
+  done.fetch_or(bit, std::memory_order_release);
+  return 0;
+}
+// CUs of the current device (cached per device ordinal; 256 if the query fails)
+static inline int kbner_cu_count() {
+  static std::atomic<int> cache[64];
+  const int dev = kbner_device_ordinal();
+  int n = cache[dev].load(std::memory_order_relaxed);
+  if (n == 0) {
+    hipDeviceProp_t prop;
+    n = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    cache[dev].store(n, std::memory_order_relaxed);
+  }
+  return n;
+}
+
 typedef short s4v __attribute__((ext_vector_type(4)));
 typedef short s8v __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));

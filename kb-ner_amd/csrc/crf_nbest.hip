@@ -127,6 +127,9 @@ size_t kbner_crf_viterbi_nbest_ws_bytes(int B, int n, int T, int nbest) { return
 int kbner_crf_viterbi_nbest(const float* emit, const float* trans, const int* lens, int B, int n, int T, int start, int stop,
                             int nbest, void* ws, int* decode, float* path_score, void* stream) {
   KBNER_CHECK_ARG(B >= 0 && n >= 1 && T > 0 && T <= NBEST_MAXT && nbest >= 1 && nbest <= 16 && T * nbest <= 32767);
+  // the first step offers only T candidates (one per source tag): the reference's torch.topk(nbest) over them raises for
+  // nbest > T (sequence_tagger_model.py:2071-2237), and the merged lists would carry -inf / duplicate paths here
+  KBNER_CHECK_ARG(nbest <= T);
   KBNER_CHECK_ARG(start >= 0 && start < T && stop >= 0 && stop < T && ws != nullptr && decode != nullptr && path_score != nullptr);
   if (B == 0) return 0;
   hipStream_t st = (hipStream_t)stream;

@@ -235,13 +235,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
 
 template <bool A_KS, bool B_KS>
 static int launch_gemm(const GemmArgs& g, hipStream_t stream) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<A_KS, B_KS>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
-    if (e != hipSuccess) return -(int)e;
-    attr_set = true;
-  }
+  static std::atomic<unsigned long long> attr_done{0};   // per template instantiation, one bit per device
+  const int r = kbner_set_max_lds_once(attr_done, reinterpret_cast<const void*>(gemm_kernel<A_KS, B_KS>), 2 * STAGE_BYTES);
+  if (r) return r;
   const int grid = (g.M / BM) * (g.N / BN) * g.splitk;
   hipLaunchKernelGGL((gemm_kernel<A_KS, B_KS>), dim3(grid), dim3(256), 2 * STAGE_BYTES, stream, g);
   hipError_t e = hipGetLastError();

@@ -540,6 +540,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GroupArgs ga) {
       if (nt == 1) __builtin_amdgcn_s_barrier();   // (K = 64: the draw was written after this tile's only barrier was passed)
       id_next = __builtin_amdgcn_readfirstlane(*s_next);
       has_next = id_next < total;
+      // K = 64: no later barrier of this tile orders the read before wave 0's epilogue, whose scratch holds the word
+      if (nt == 1) __builtin_amdgcn_s_barrier();
     }
     unsigned char* cur = smem + (it & 1) * STAGE2_BYTES;
     unsigned char* nxt = smem + ((it + 1) & 1) * STAGE2_BYTES;
@@ -629,29 +631,16 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GroupArgs ga) {
 
 template <bool A_KS, bool B_KS, bool DYN, int TM = 256>
 static int launch256(const GroupArgs& ga, hipStream_t stream) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<A_KS, B_KS, DYN, TM>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS_BYTES);
-    if (e != hipSuccess) return -(int)e;
-    attr_set = true;
-  }
+  static std::atomic<unsigned long long> attr_done{0};   // per template instantiation, one bit per device
+  const int r = kbner_set_max_lds_once(attr_done, reinterpret_cast<const void*>(gemm256_kernel<A_KS, B_KS, DYN, TM>), G2_LDS_BYTES);
+  if (r) return r;
   const int grid = ga.total_tiles < ga.ncu ? ga.total_tiles : ga.ncu;
   hipLaunchKernelGGL((gemm256_kernel<A_KS, B_KS, DYN, TM>), dim3(grid), dim3(512), G2_LDS_BYTES, stream, ga);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }
 
-static int device_cu_count() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
-    if (n <= 0) n = 256;
-  }
-  return n;
-}
+static int device_cu_count() { return kbner_cu_count(); }
 
 // public mirror of GemmProblem (include/kbner.h: kbner_gemm_problem)
 struct kbner_gemm_problem {

@@ -122,7 +122,10 @@ class ModelFinetuner:
         wts, idx, kw, base = [], [], [], 0
         for bt in group:
             sel = self.model.multi_view_plan(bt) if multi_view_rate is not None else []
-            f = (1.0 - multi_view_rate) if sel else 1.0
+            # the reference scales the NLL whenever check_multi_view returns the tag tensor (finetune_trainer.py:909-914) -- some
+            # sentence has an orig_sent AND an S-X tag occurs anywhere in the batch -- even if no single sentence has both
+            mv_batch = multi_view_rate is not None and self.model.check_multi_view(bt) is not False
+            f = (1.0 - multi_view_rate) if mv_batch else 1.0
             wts += [f / (G * len(bt))] * len(bt)
             if sel:
                 idx += [base + k for k in sel]

@@ -432,10 +432,10 @@ class Tagger:
                 # small reduce kernel: per-tile atomics onto the same 4096 addresses were what made this the slowest GEMM
                 if ac.colsum_ws is None:
                     ac.colsum_ws = torch.empty((2 * (Mp // 128), F_), dtype=F32, device=self.device)
-                # (with dynamic tile draw the kernel always uses 256-row tiles)
-                trows = 256 if ops.SCHED_RING is not None else ops.gemm_tile_rows(GEMM_NN, Mp, F_)
-                ops.gemm(GEMM_NN, dhm, a.bf(p + "ffn2.weight"), Mp, F_, H, C=dpre, aux=ac.dact[l],
-                         epi=EPI_DGELU | EPI_COLSUM | EPI_COLSUM_WS, colsum=ac.colsum_ws, occupancy=True)
+                # ops.gemm reports the tile height of the kernel that ran (256 under dynamic tile draw, the static kernel's pick --
+                # also when the scheduler ring is used up -- otherwise): it decides how many workspace lines hold partial sums
+                trows = ops.gemm(GEMM_NN, dhm, a.bf(p + "ffn2.weight"), Mp, F_, H, C=dpre, aux=ac.dact[l],
+                                 epi=EPI_DGELU | EPI_COLSUM | EPI_COLSUM_WS, colsum=ac.colsum_ws, occupancy=True)
                 ops.colsum_rows_f32(ac.colsum_ws, 2 * (Mp // trows), a.grad(p + "ffn1.bias"))
             else:
                 ops.gemm(GEMM_NN, dhm, a.bf(p + "ffn2.weight"), Mp, F_, H, C=dpre, aux=ac.dact[l], epi=EPI_DGELU, occupancy=True)
@@ -631,10 +631,12 @@ class FusedAdamW:
         a.v.copy_(sd["v"].to(a.device))
         self.t = int(sd["t"])
         if a.emb_flags is not None:
-            # a row is live iff it has ever received a gradient, i.e. iff its second moment is not identically zero
+            # a row is live iff it has ever received a gradient, i.e. iff one of its moments is not identically zero (v alone
+            # can underflow to 0 for tiny gradients while m is still non-zero: the dense update would then apply m / eps)
             lo = a.offsets["emb.word"]
             V, H = a.shapes["emb.word"]
-            a.emb_flags.copy_((a.v[lo:lo + V * H].view(V, H) != 0).any(1).to(torch.uint8))
+            live = (a.v[lo:lo + V * H].view(V, H) != 0).any(1) | (a.m[lo:lo + V * H].view(V, H) != 0).any(1)
+            a.emb_flags.copy_(live.to(torch.uint8))
 
     def lr_lambda(self):
         if self.t_total is None:

@@ -267,7 +267,8 @@ def make_problem(A, B, M, N, K, C=None, C32=None, bias=None, addend=None, aux=No
 
 
 def gemm_grouped(layout, problems):
-    """problems: list (<= 16) of L.GemmProblem (make_problem) of one layout; 256x256x64 8-wave kernel."""
+    """problems: list (<= 16) of L.GemmProblem (make_problem) of one layout; 256x256x64 8-wave kernel.
+    -> True when the launch used the dynamic tile draw (always 256-row tiles), False for the static kernel."""
     n = len(problems)
     arr = (L.GemmProblem * n)(*problems)
     hook = GEMM_HOOK
@@ -280,21 +281,27 @@ def gemm_grouped(layout, problems):
         slot = c_void_p(ring.data_ptr() + 32 * _sched_pos)
         _sched_pos += 1
         L.call("kbner_gemm_bf16_grouped_dyn", layout, n, ctypes.cast(arr, ctypes.c_void_p), slot, stream_ptr())
+        dyn = True
     else:
         L.call("kbner_gemm_bf16_grouped", layout, n, ctypes.cast(arr, ctypes.c_void_p), stream_ptr())
+        dyn = False
     if hook is not None:
         ev1.record()
         hook.append((ev0, ev1, sum(2.0 * p.M * p.N * p.K for p in problems), layout,
                      (len(problems), problems[0].M, problems[0].N, problems[0].K, problems[0].epi)))
+    return dyn
 
 
 def gemm(layout, A, B, M, N, K, C=None, C32=None, bias=None, addend=None, aux=None, out2=None, epi=0, splitk=1, alpha=1.0,
          lda=None, ldb=None, colsum=None, drop=NO_DROP, occupancy=False):
     """C[M,N] (bf16) or C32[M,N] += (fp32).  A/B are 2-D bf16 tensors in their memory layouts.
-    Shapes divisible by 256 go to the 256^2 8-wave kernel, others to the 128^2 kernel."""
+    Shapes divisible by 256 go to the 256^2 8-wave kernel, others to the 128^2 kernel.
+    -> the tile height (rows) of the kernel that ran: 256 / 128 for the big kernel (EPI_COLSUM_WS consumers fold 2 * M / rows
+    workspace lines), 128 for the small one."""
     _chk(A, BF16, "A"); _chk(B, BF16, "B")
     if uses_256(M, N, occupancy) and splitk == 1 and lda is None and ldb is None:
-        return gemm_grouped(layout, [make_problem(A, B, M, N, K, C, C32, bias, addend, aux, out2, epi, alpha, colsum, drop)])
+        dyn = gemm_grouped(layout, [make_problem(A, B, M, N, K, C, C32, bias, addend, aux, out2, epi, alpha, colsum, drop)])
+        return 256 if dyn else gemm_tile_rows(layout, M, N)
     if drop[1]:
         epi |= L.EPI_DROP
     if colsum is not None:
@@ -315,6 +322,7 @@ def gemm(layout, A, B, M, N, K, C=None, C32=None, bias=None, addend=None, aux=No
     if hook is not None:
         ev1.record()
         hook.append((ev0, ev1, 2.0 * M * N * K, layout, (1, M, N, K, epi)))
+    return 128
 
 
 def gemm_splitk(layout, A, B, M, N, K, splits, ws, C, bias=None, addend=None, drop=NO_DROP):

@@ -299,7 +299,12 @@ def test_multi_view_pairing_and_weights_host_logic():
         multi_view_training = True
 
         def multi_view_plan(self, batch):   # paired sentences that have context
-            return [i for i, s in enumerate(batch) if hasattr(s, "orig_sent")]
+            return [i for i, s in enumerate(batch) if hasattr(s, "orig_sent") and not getattr(s, "no_x", False)]
+
+        def check_multi_view(self, batch):  # reference rule: some sentence is paired AND some S-X tag occurs in the batch
+            if not any(hasattr(s, "orig_sent") for s in batch):
+                return False
+            return True if any(not getattr(s, "no_x", False) for s in batch) else False
 
     t = ModelFinetuner.__new__(ModelFinetuner)
     t.model, t.corpus = Model(), Corpus()
@@ -318,6 +323,11 @@ def test_multi_view_pairing_and_weights_host_logic():
     assert mv is None and np.allclose(wts, [0.5, 0.5])
     wts, mv = t._group_weights(group, None)                        # multi-view off: the plain fused weights
     assert mv is None and np.allclose(wts, [1 / 6] * 6)
+    # a paired sentence WITHOUT context tags next to an unpaired one WITH them: check_multi_view is a tensor in the reference
+    # (finetune_trainer.py:909-914), so the NLL is scaled by (1 - rate) although no sentence enters the KL term
+    d[0].no_x = True
+    wts, mv = t._group_weights([[d[0], a[2]]], 0.25)
+    assert mv is None and np.allclose(wts, [0.75 / 2] * 2)
 
 
 def test_batch_spans_equals_get_spans_on_random_tag_sequences():
