@@ -252,9 +252,9 @@ def test_full_step_vs_oracle(st):
 
 
 def test_base_config_step_vs_oracle(st):
-    """BASELINE configs[0] shape: xlm-roberta-base dims (L12 / H768 / A12 / F3072) at S = 512, one micro-batch of 2 sentences,
-    fwd + bwd against the oracle's fp32 autograd (small vocabulary: the embedding table is not what this pins)"""
-    r = st.check_step(H=768, A=12, F_=3072, L=12, S=512, V=2048, std=0.02)
+    """BASELINE configs[0] at its full size: xlm-roberta-base dims (L12 / H768 / A12 / F3072, V = 250 002) at S = 512, one
+    micro-batch of 2 sentences, fwd + bwd against the oracle's fp32 autograd on the host CPU"""
+    r = st.check_step(H=768, A=12, F_=3072, L=12, S=512, V=250002, std=0.02)
     print("base-config check_step:", {k: v for k, v in r.items() if k != "grad_table_top"}, r["grad_table_top"][:3])
     assert r["loss_rel"] < 2e-3, r
     assert r["emissions_rel"] < 2e-2, r

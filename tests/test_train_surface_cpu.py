@@ -213,3 +213,37 @@ def test_every_shipped_yaml_block_is_accepted():
         assert not [k for k in refused_train if b["train"].get(k)], name
         assert list(b["embeddings"]) == ["TransformerWordEmbeddings-0"] and not mkw.get("use_rnn"), name
     assert n_finetune == 15 and n_multiview == 3
+
+
+def test_reference_entry_script_form(tmp_path):
+    """the reference's own train.py is run through `python -m kbner.run_script <script>`.  A stand-in script is
+    generated from the fixture (every import statement the reference's train.py makes, in order) and placed next to a DECOY
+    `flair/` package -- the layout of the reference checkout, where the script's directory would come first on sys.path.
+    `python <script>` picks the decoy (why the plain form cannot work); the run_script form imports this repo's mirror."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(HERE)
+    pkg = os.path.join(repo, "kb-ner_amd")
+    lines = []
+    for imp in SURFACE["imports"]:
+        if imp["name"] is None:
+            lines.append("import %s%s" % (imp["module"], (" as " + imp["asname"]) if imp.get("asname") else ""))
+        elif (("datasets_module", imp["name"]) in OUT_OF_SCOPE) or imp["name"] == "*":
+            continue
+        else:
+            lines.append("from %s import %s" % (imp["module"], imp["name"]))
+    lines += ["import sys, flair", "print('FLAIR_FROM', flair.__file__)", "print('ARGV', sys.argv[1:])"]
+    script = tmp_path / "train.py"
+    script.write_text("\n".join(lines) + "\n")
+    decoy = tmp_path / "flair"
+    decoy.mkdir()
+    (decoy / "__init__.py").write_text("print('DECOY_FLAIR_IMPORTED')\nraise ImportError('decoy: the reference package shadows PYTHONPATH')\n")
+    env = dict(os.environ, PYTHONPATH=pkg)
+    plain = subprocess.run([sys.executable, str(script), "--config", "x.yaml"], env=env, cwd=str(tmp_path), capture_output=True, text=True)
+    assert plain.returncode != 0 and "DECOY_FLAIR_IMPORTED" in plain.stdout, (plain.stdout, plain.stderr)
+    good = subprocess.run([sys.executable, "-m", "kbner.run_script", str(script), "--config", "x.yaml"], env=env, cwd=str(tmp_path),
+                          capture_output=True, text=True)
+    assert good.returncode == 0, (good.stdout, good.stderr)
+    assert "DECOY_FLAIR_IMPORTED" not in good.stdout
+    assert ("FLAIR_FROM " + os.path.join(pkg, "flair")) in good.stdout, good.stdout
+    assert "ARGV ['--config', 'x.yaml']" in good.stdout
