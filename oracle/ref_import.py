@@ -129,6 +129,11 @@ class TokenizerAdapter:
     begin_offset=1).  encode_plus restates the 3.0.0 semantics for a list of ids: `<s> ids[:max_length-2] </s>`; with
     return_overflowing_tokens the overflow is the tail that did not fit, preceded by `stride` ids of overlap."""
 
+    # "3.0.0": the pinned release's `longest_first` loop (see encode_plus); "intended": what that loop was meant to do and what
+    # every later release does for a single sequence -- the overflow is the tail starting `stride` ids before the cut.
+    # oracle/gen_golden_windows.py captures the reference's sliding-window path under BOTH.
+    OVERFLOW = "3.0.0"
+
     def __init__(self, tok):
         self.__dict__["_tok"] = tok
         for a in ("eos", "sep", "bos", "cls", "pad", "unk"):
@@ -162,11 +167,15 @@ class TokenizerAdapter:
             # the published 3.0.0 algorithm, which cannot be installed here).  The build's product path implements the intended
             # semantics (next window restarts `stride` ids before the cut); KB-NER data never exceeds one window in training
             # (kb/context_process.py:974), so goldens captured through this adapter never reach this branch.
-            overflow = []
-            for _ in range(len(ids) - room):
-                w = min(len(ids), stride + 1) if not overflow else 1
-                overflow.extend(ids[-w:])
-                ids = ids[:-1]
+            if TokenizerAdapter.OVERFLOW == "intended":
+                overflow = ids[max(room - stride, 0):]
+                ids = ids[:room]
+            else:
+                overflow = []
+                for _ in range(len(ids) - room):
+                    w = min(len(ids), stride + 1) if not overflow else 1
+                    overflow.extend(ids[-w:])
+                    ids = ids[:-1]
             if return_overflowing_tokens:
                 out["overflowing_tokens"] = overflow
         out["input_ids"] = [bos] + ids + [eos]

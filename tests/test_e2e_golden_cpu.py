@@ -224,3 +224,44 @@ def test_v2_doc_windows_match_reference(tmp_path):
             if first[b, k] >= 0:
                 mine[b, k] = hidden[first_row[b, k], first[b, k]]
     np.testing.assert_array_equal(mine, feats)
+
+
+def test_sliding_windows_match_reference_run(tmp_path):
+    """f-3: sentences longer than one encoder window.  tests/golden/windows.npz was captured by RUNNING the reference's
+    TransformerWordEmbeddings (oracle/gen_golden_windows.py: the encode_plus overflow loop, flair/embeddings.py:3203-3227, and the
+    seam stitching of window states, :3292-3299) with max_subtokens_sequence_length = 64, stride = 32 on one batch of sentences of
+    1, 5, 9 and 19 windows.  The product's host side must build the same encoder rows and mask, and the (row, position) it gathers
+    every word token from must be the element the reference's stitching reaches: checked here by indexing the REFERENCE's own
+    hidden states with the product's index and comparing with the reference's features, bit for bit.
+    The one deliberate deviation: transformers 3.0.0's `longest_first` loop returns the overflow scrambled (`ids_quirk`); the
+    product implements the intended order -- the fixture holds both, and the quirk rows differ from the first overflow row on."""
+    import tiny_assets
+    from flair.data import Sentence
+    from flair.embeddings import TransformerWordEmbeddings
+    g = np.load(os.path.join(GOLD, "windows.npz"))
+    mdir = tiny_assets.build_model_dir(str(tmp_path / "enc"), seed=0)
+    emb = TransformerWordEmbeddings(model=mdir, layers="-1", pooling_operation="first")
+    emb.max_subtokens_sequence_length, emb.stride, emb.allow_long_sentences = int(g["max_len"]), int(g["stride"]), True
+    sents = [Sentence(str(t)) for t in g["texts"]]
+    ids, am, first, lengths, first_row = emb.prepare_batch(sents)
+    np.testing.assert_array_equal(ids, g["ids_intended"])
+    np.testing.assert_array_equal(am, g["mask_intended"])
+    assert list(lengths) == list(g["lengths"])
+    rows = list(g["rows_per_sentence"])
+    assert rows == [1, 5, 9, 19]
+    r0 = np.concatenate([[0], np.cumsum(rows)])
+    hidden, feats = g["hidden_intended"], g["features_intended"]
+    mine = np.zeros_like(feats)
+    for b in range(len(sents)):
+        for k in range(int(lengths[b])):
+            if first[b, k] >= 0:
+                assert r0[b] <= first_row[b, k] < r0[b + 1]
+                mine[b, k] = hidden[first_row[b, k], first[b, k]]
+    np.testing.assert_array_equal(mine, feats)
+    # the recorded deviation: same number of rows, identical up to (and including) the first window of every sentence, then
+    # the literal 3.0.0 loop feeds the encoder scrambled ids
+    q = g["ids_quirk"]
+    assert q.shape == ids.shape
+    for b in range(len(sents)):
+        np.testing.assert_array_equal(q[r0[b]], ids[r0[b]])
+    assert (q[r0[1] + 1] != ids[r0[1] + 1]).any()

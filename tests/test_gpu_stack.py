@@ -162,6 +162,41 @@ def test_bert_embeddings_device_features_vs_reference_golden(tmp_path):
     assert not mine[1, lengths[1]:].any() and not mine[2, lengths[2]:].any()      # padding rows stay zero
 
 
+def test_sliding_window_features_vs_reference_run(tmp_path):
+    """f-3 on the device: a frozen TransformerWordEmbeddings with 64-position windows (stride 32) over sentences of 1, 5, 9 and 19
+    windows -- the encoder runs on every window row and gather_rows_ld pulls each word token's first sub-token from its
+    (row, position) == the features the REFERENCE assigned after stitching its window states (tests/golden/windows.npz,
+    oracle/gen_golden_windows.py), within the bf16 tolerance of the encoder"""
+    import tiny_assets
+    from flair.data import Dictionary, Sentence
+    from flair.embeddings import StackedEmbeddings, TransformerWordEmbeddings
+    from flair.models import FastSequenceTagger
+    g = np.load(os.path.join(GOLD, "windows.npz"))
+    mdir = tiny_assets.build_model_dir(str(tmp_path / "enc"), seed=0)
+    emb = TransformerWordEmbeddings(model=mdir, layers="-1", pooling_operation="first", fine_tune=False)
+    emb.max_subtokens_sequence_length, emb.stride, emb.allow_long_sentences = int(g["max_len"]), int(g["stride"]), True
+    td = Dictionary(add_unk=False)
+    for it in ("<unk>", "O", "S-PER", "<START>", "<STOP>"):
+        td.add_item(it)
+    tagger = FastSequenceTagger(hidden_size=32, embeddings=StackedEmbeddings([emb]), tag_dictionary=td, tag_type="ner", use_crf=True,
+                                use_rnn=True, dropout=0.0)
+    sents = [Sentence(str(t)) for t in g["texts"]]
+    X, lengths, B, n = tagger._stack_input(sents)
+    D = emb.embedding_length
+    mine = X[:B * n, :D].float().cpu().numpy().reshape(B, n, D)
+    ref = g["features_intended"]
+    assert list(lengths) == list(g["lengths"])
+    num = sum(float(((mine[b, :L] - ref[b, :L]) ** 2).sum()) for b, L in enumerate(lengths))
+    den = sum(float((ref[b, :L] ** 2).sum()) for b, L in enumerate(lengths))
+    rel = (num / den) ** 0.5
+    print("sliding-window features rel L2", rel)
+    assert rel < 2e-2, rel
+    # per sentence too: a wrong seam would spoil one sentence's tail, not the batch average
+    for b, L in enumerate(lengths):
+        rb = (float(((mine[b, :L] - ref[b, :L]) ** 2).sum()) / float((ref[b, :L] ** 2).sum())) ** 0.5
+        assert rb < 3e-2, (b, rb)
+
+
 def test_config5_yaml_route(assets, tmp_path):
     """the ACE-shaped YAML through ConfigParser -> ReinforcementTrainer (assign_doc_for_ext_context chunks every sentence at
     <EOS>) -> train.py's --parse steps: selection mask set on the student, evaluate() writes one line per REAL token"""
