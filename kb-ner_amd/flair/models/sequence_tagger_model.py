@@ -515,9 +515,14 @@ class SequenceTagger(flair.nn.Model):
 
     # ------------------------------------------------------------------ evaluation
     def evaluate(self, data_loader, out_path: Path = None, embeddings_storage_mode: str = "cpu", prediction_mode=False,
-                 speed_test=False):
+                 speed_test=False, shard=None):
         """sequence_tagger_model.py:2593-2729.  Under speed_test only forward + decode run (no loss, so self.mask keeps ALL
         tokens and Viterbi decodes the context too; no prediction lines, no metric) -- as in the reference.
+
+        shard = (rank, world_size): data-parallel evaluation -- this rank takes batches rank, rank + world, ...; the metric's
+        tp / fp / fn / tn counters, the loss sum and the batch count are summed over ranks (kbner.dp) before the Result is
+        built, so EVERY rank returns the Result one rank scoring all batches would return (the loss as the mean over all
+        batches).  Not combined with out_path (the prediction file is written by one rank over the whole set).
 
         Host / device pipeline: batch k+1's encoder + loss + Viterbi are ENQUEUED (with the device->host copy of its tags into
         pinned memory) before batch k's labels, prediction lines, spans and metric are built on the host, so the two overlap;
@@ -527,6 +532,10 @@ class SequenceTagger(flair.nn.Model):
         from flair.data import span_tables
         eval_loss, batch_no = 0.0, 0
         metric = Metric("Evaluation")
+        if shard is not None and (out_path is not None or shard[1] <= 1):
+            if out_path is not None and shard[1] > 1:
+                raise ValueError("evaluate(shard=...) cannot write a prediction file: evaluate the whole set on one rank")
+            shard = None
         outfile = open(out_path, "w", encoding="utf-8") if out_path is not None else None
         env = {"items": self.tag_dictionary.get_items(), "metric": metric, "outfile": outfile, "speed_test": speed_test}
         env["tables"] = span_tables(env["items"])
@@ -535,7 +544,9 @@ class SequenceTagger(flair.nn.Model):
         t0 = time.time()
         try:
             pending = None
-            for batch in data_loader:
+            for index, batch in enumerate(data_loader):
+                if shard is not None and index % shard[1] != shard[0]:
+                    continue
                 batch_no += 1
                 st = self._eval_enqueue(batch, prediction_mode, speed_test)
                 if pending is not None:
@@ -552,6 +563,15 @@ class SequenceTagger(flair.nn.Model):
             rate = getattr(data_loader, "num_examples", 0) / max(1e-9, time.time() - t0)
             print(rate)
             log.info("decode speed: %.2f sents/sec", rate)
+        if shard is not None:
+            from kbner import dp
+            parts = dp.all_gather_object((metric.counts(), eval_loss, batch_no))
+            metric = Metric("Evaluation")
+            eval_loss, batch_no = 0.0, 0
+            for counts, loss_sum, nb in parts:   # rank order: the same sums on every rank
+                metric.merge_counts(counts)
+                eval_loss += loss_sum
+                batch_no += nb
         eval_loss /= max(1, batch_no)
         detailed = ("\nMICRO_AVG: acc {} - f1-score {}\nMACRO_AVG: acc {} - f1-score {}".format(
             metric.micro_avg_accuracy(), metric.micro_avg_f_score(), metric.macro_avg_accuracy(), metric.macro_avg_f_score()))

@@ -332,24 +332,27 @@ class ModelFinetuner:
                 log_line(log)
                 log.info("EPOCH %d done: loss %.4f - lr %.2e - %.1f sentences/sec (all ranks)", epoch + 1, train_loss,
                          learning_rate * opt.lr_lambda(), W * seen / max(time.time() - t_ep, 1e-9))
-                # ---- evaluation + model selection on rank 0 (replicas are identical)
+                # ---- evaluation: the dev / test batches are shared out over the ranks (replicas are identical) and the span
+                # counters summed, so every rank holds the same Result; model selection, files and the
+                # checkpoint stay on rank 0
+                shard = (dp.rank(), W) if W > 1 else None
+                score = macro = None
+                if dev_loaders:
+                    f1s, dls = [], []
+                    for name, dl in zip(getattr(self.corpus, "targets", ["dev"]), dev_loaders):
+                        res, dl_loss = self.model.evaluate(dl, embeddings_storage_mode=embeddings_storage_mode, shard=shard)
+                        log.info("%s DEV : loss %.4f - f1 %.4f - macro %.4f", name, dl_loss, res.main_score, res.macro_score)
+                        # dataset-level macro average over the dev sets, in PERCENT (:1108-1126)
+                        f1s.append((res.macro_score if select_model_by_macro else res.main_score) * 100)
+                        dls.append(dl_loss)
+                    score = sum(f1s) / len(f1s)
+                    log.info("Dataset-Level Macro Average: %.2f\tDataset-Level Macro avg loss: %.2f", score, sum(dls) / len(dls))
+                    dev_score_history.append(score)
+                    dev_loss_history.append(sum(dls) / len(dls))
+                for name, tl in zip(getattr(self.corpus, "targets", ["test"]), test_loaders):
+                    res, tl_loss = self.model.evaluate(tl, embeddings_storage_mode=embeddings_storage_mode, shard=shard)
+                    log.info("%s TEST: loss %.4f - f1 %.4f", name, tl_loss, res.main_score)
                 if is_main:
-                    score = macro = None
-                    if dev_loaders:
-                        f1s, dls = [], []
-                        for name, dl in zip(getattr(self.corpus, "targets", ["dev"]), dev_loaders):
-                            res, dl_loss = self.model.evaluate(dl, embeddings_storage_mode=embeddings_storage_mode)
-                            log.info("%s DEV : loss %.4f - f1 %.4f - macro %.4f", name, dl_loss, res.main_score, res.macro_score)
-                            # dataset-level macro average over the dev sets, in PERCENT (:1108-1126)
-                            f1s.append((res.macro_score if select_model_by_macro else res.main_score) * 100)
-                            dls.append(dl_loss)
-                        score = sum(f1s) / len(f1s)
-                        log.info("Dataset-Level Macro Average: %.2f\tDataset-Level Macro avg loss: %.2f", score, sum(dls) / len(dls))
-                        dev_score_history.append(score)
-                        dev_loss_history.append(sum(dls) / len(dls))
-                    for name, tl in zip(getattr(self.corpus, "targets", ["test"]), test_loaders):
-                        res, tl_loss = self.model.evaluate(tl, embeddings_storage_mode=embeddings_storage_mode)
-                        log.info("%s TEST: loss %.4f - f1 %.4f", name, tl_loss, res.main_score)
                     with open(loss_txt, "a") as f:
                         f.write("%d\t%s\t%.3e\t%.6f\t%s\t%s\t_\n" % (epoch + 1, time.strftime("%H:%M:%S"), learning_rate * opt.lr_lambda(),
                                                                    train_loss, dev_loss_history[-1] if dev_loss_history else "_",

@@ -86,6 +86,21 @@ class Metric(object):
         acc = [self.accuracy(c) for c in self.get_classes()]
         return round(sum(acc) / len(acc), 4) if acc else 0.0
 
+    # ---- data-parallel evaluation: every rank scores its share of the batches, the per-class counters are
+    # summed over ranks, and precision / recall / F1 are computed from the totals -- exactly what one rank scoring every batch
+    # gets, because every score of this class is a function of the four counter tables only
+    def counts(self):
+        """{class: [tp, fp, tn, fn]} (plain ints: picklable for all_gather_object)"""
+        return {c: [self._tps[c], self._fps[c], self._tns[c], self._fns[c]] for c in self.get_classes()}
+
+    def merge_counts(self, counts):
+        for c, (tp, fp, tn, fn) in counts.items():
+            self._tps[c] += tp
+            self._fps[c] += fp
+            self._tns[c] += tn
+            self._fns[c] += fn
+        return self
+
     def get_classes(self) -> List:
         keys = set(itertools.chain(self._tps, self._fps, self._tns, self._fns))
         return sorted(k for k in keys if k is not None)

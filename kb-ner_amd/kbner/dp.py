@@ -86,6 +86,15 @@ def broadcast_object(obj, src=0):
     return box[0]
 
 
+def all_gather_object(obj):
+    """every rank's (small, picklable) object, in rank order"""
+    if world_size() == 1:
+        return [obj]
+    out = [None] * world_size()
+    dist.all_gather_object(out, obj)
+    return out
+
+
 def barrier():
     if world_size() > 1:
         dist.barrier()

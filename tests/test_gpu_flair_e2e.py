@@ -218,6 +218,11 @@ def test_bench_two_ranks_rccl():
                    ["--gpus", "2", "--steps", "2", "--warmup", "1", "--micro-batch", "16", "--accum", "1", "--no-roofline"])
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["value"] > 0
     assert d["dp_exchange"]["buckets"] == 6 and d["allreduce_ms_exposed"] is not None
+    # the first box with two GPUs gives a verdict on the OVERLAPPED path: it must not have fallen back to the blocking
+    # all-reduce (bench.py reports a failure of the overlapped exchange as dp_exchange.fallback), and what is left exposed
+    # behind the end of backward -- the sparse embedding rows + the ~3 MB remainder, DESIGN.md section 6 -- stays under 5 ms
+    assert "fallback" not in d["dp_exchange"], d["dp_exchange"]
+    assert d["allreduce_ms_exposed"] < 5.0, d["allreduce_ms_exposed"]
     b = _run_bench({"HSA_ENABLE_IPC_MODE_LEGACY": "0"},
                    ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                     "--master-port", "29534"],
