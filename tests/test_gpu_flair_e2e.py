@@ -237,9 +237,10 @@ def test_full_size_step_vs_oracle():
     forward + backward on the HIP path vs the oracle's fp32 autograd on the host CPU (~1 min)."""
     import selftest as st
     r = st.check_step(H=1024, A=16, F_=4096, L=24, S=512, V=250002, std=0.02)
-    # thresholds = 3x the observed error (DESIGN.md §4: loss 7e-5, emissions 1.2e-2, worst gradient cosine 0.991 / rel 0.13)
-    assert r["loss_rel"] < 2.1e-4, r
-    assert r["emissions_rel"] < 3.6e-2, r
+    # thresholds = 3x the observed error (round 3, identical on two boxes and on the round-2 tree: loss 4.0e-4, emissions 1.22e-2;
+    # worst gradient cosine 0.9826 / rel 0.188 on encoder.layer.23.attention.self.query.weight)
+    assert r["loss_rel"] < 1.2e-3, r
+    assert r["emissions_rel"] < 3.7e-2, r
     assert r["grad_min_cos"] > 0.98 and r["grad_worst_rel"] < 0.2, r
     assert r["grad_linear.weight"] < 5e-2 and r["grad_transitions"] < 5e-2, r
     assert r["viterbi_equal"], r
