@@ -64,6 +64,35 @@ size_t kbner_crf_posterior_kl_ws_floats(int B, int n, int T);
 int kbner_crf_posterior_kl(const float* emit_s, const float* emit_t, const float* trans, const int* lens, const float* wgt,
                            float tau, int B, int n, int T, int start, int stop, float* loss, float* demit, float* dtrans,
                            float* ws, void* stream);
+/* ---- teacher-student knowledge distillation of the CRF (`distill_mode: true`) ----
+ * Teacher side, run once per training sentence before the first epoch (ModelFinetuner.assign_pretrained_teacher_targets,
+ * flair/trainers/finetune_trainer.py:1515-1910); `suppress` = bit mask of the tags whose emissions are lowered by 1e12 first
+ * (START, STOP, <unk>: :1627-1629,1705-1707):
+ *   kbner_crf_fb_score        score f32[B,n,T] = forward_var + backward_var of the teacher's CRF below lens[b], 0 past it
+ *                             (:1631-1634) -- the `distill_posterior` target;
+ *   kbner_crf_pair_posterior  the `distill_exact` targets (:1709-1722,1885): pair f32[B,n-1,T*T] = softmax over (to, from) of
+ *                             (alpha_{i-1}[from] + beta_i[to] + e_i[to] + trans[to,from]) / tau (rows past lens[b]-1 zero),
+ *                             start_score, end_score f32[B,T]; ws: kbner_crf_pair_ws_floats(B, n, T) floats.
+ * Student side, every training step (FastSequenceTagger.simple_forward_distillation_loss,
+ * flair/models/sequence_tagger_model.py:2110-2372), forward and backward in one launch, d(sum_b wgt[b] loss[b]) / d emit
+ * WRITTEN to demit f32[B,n,T], the transition gradient ADDED to dtrans f32[T,T]:
+ *   kbner_crf_posterior_kl_scores  :2120-2136 -- kbner_crf_posterior_kl with the teacher given as its fb scores score_t
+ *                                  (its own transitions went into them), same workspace;
+ *   kbner_crf_exact_kd             :2139-2244 + _calculate_xstruct_distillation_loss :2400-2425 -- loss[b] = max(0, -(E_teacher[
+ *                                  score / tau] - logZ_tau) * tau^2); ws: kbner_crf_pair_ws_floats(B, n, T) floats.
+ * (The `distill_crf` branch, :2249-2309, is kbner_crf_nll_fwd / _bwd over the n-best paths of kbner_crf_viterbi_nbest.)  T <= 32. */
+int kbner_crf_fb_score(const float* emit, const float* trans, const int* lens, unsigned suppress, int B, int n, int T, int start,
+                       int stop, float* score, void* stream);
+int kbner_crf_posterior_kl_scores(const float* emit_s, const float* score_t, const float* trans, const int* lens, const float* wgt,
+                                  float tau, int B, int n, int T, int start, int stop, float* loss, float* demit, float* dtrans,
+                                  float* ws, void* stream);
+size_t kbner_crf_pair_ws_floats(int B, int n, int T);
+int kbner_crf_pair_posterior(const float* emit, const float* trans, const int* lens, unsigned suppress, float tau, int B, int n,
+                             int T, int start, int stop, float* pair, float* start_score, float* end_score, float* ws,
+                             void* stream);
+int kbner_crf_exact_kd(const float* emit, const float* trans, const int* lens, const float* pair, const float* start_score,
+                       const float* end_score, const float* wgt, float tau, int B, int n, int T, int start, int stop, float* loss,
+                       float* demit, float* dtrans, float* ws, void* stream);
 /* n-best Viterbi (SequenceTagger._viterbi_decode_nbest, sequence_tagger_model.py:1660-1818; called on KD teachers at
  * finetune_trainer.py:1600, distillation_trainer.py:819): decode i32 [B, n, nbest] tag indices and path_score f32 [B, nbest]
  * (softmax over the nbest end scores).  The NCRF++ decoder's conventions are kept as they are: trans indexed [from, to],
@@ -85,6 +114,9 @@ int kbner_gather_rows_f32(const float* src, const int* idx, float* out, int R, i
 /* fp32 row scatter dst[idx[r],:] = rows[r,:] (unique indices, W % 4 == 0): the data-parallel exchange of the touched
  * word-embedding gradient rows -- new capability, the reference has no distributed path (finetune_trainer.py:466,699-700) */
 int kbner_scatter_rows_f32(const float* rows, const int* idx, float* dst, int R, int W, void* stream);
+/* fp32 row scatter-ADD, any W: dst[idx[r],:] += rows[r,:] (idx[r] < 0 skipped, indices unique) -- backward of the remove_x
+ * compaction (sequence_tagger_model.py:2474-2488) when the KD terms need the gradient on the all-token emissions */
+int kbner_scatter_add_rows_f32(const float* rows, const int* idx, float* dst, int R, int W, void* stream);
 /* its backward (unique indices; caller zero-fills dsrc) */
 int kbner_scatter_rows(const kbner_bf16* dout, const int* idx, kbner_bf16* dsrc, int R, int H, void* stream);
 /* self.linear, sequence_tagger_model.py:1027: out f32[R,T] = x bf16[R,H] . w f32[T,H]^T + bias */

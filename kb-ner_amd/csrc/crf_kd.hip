@@ -37,6 +37,10 @@ static __device__ __forceinline__ float kd_lse(const float (&x)[KD_TT]) {
   return m + logf(s);
 }
 
+// TSCORE: emit_t holds the teacher's forward-backward SCORES (alpha + beta of ITS OWN CRF, computed once before training by
+// kbner_crf_fb_score) instead of emissions to be scanned with the student's transitions -- the teacher-student `distill_posterior`
+// branch of simple_forward_distillation_loss (sequence_tagger_model.py:2120-2136) as opposed to the multi-view one (:2080-2093).
+template <bool TSCORE>
 __global__ __launch_bounds__(64) void crf_posterior_kl_kernel(const float* __restrict__ emit_s, const float* __restrict__ emit_t,
                                                               const float* __restrict__ trans, const int* __restrict__ lens,
                                                               const float* __restrict__ wgt, float tau, int n, int T, int start,
@@ -72,19 +76,19 @@ __global__ __launch_bounds__(64) void crf_posterior_kl_kernel(const float* __res
     float as = (t == start) ? 0.0f : KD_NEG, at = as;
     for (int i = 0; i < L; ++i) {
       const float e1 = live ? es[(size_t)i * T + t] : 0.0f;
-      const float e2 = live ? et[(size_t)i * T + t] : 0.0f;
       float x[KD_TT];
 #pragma unroll
       for (int f = 0; f < KD_TT; ++f) x[f] = (e1 + row[f]) + kd_bcast(as, f);
       const float n1 = kd_lse(x);
-#pragma unroll
-      for (int f = 0; f < KD_TT; ++f) x[f] = (e2 + row[f]) + kd_bcast(at, f);
-      const float n2 = kd_lse(x);
       as = live ? n1 : KD_NEG;
-      at = live ? n2 : KD_NEG;
-      if (live) {
-        As[(size_t)i * T + t] = as;
-        At[(size_t)i * T + t] = at;
+      if (live) As[(size_t)i * T + t] = as;
+      if (!TSCORE) {
+        const float e2 = live ? et[(size_t)i * T + t] : 0.0f;
+#pragma unroll
+        for (int f = 0; f < KD_TT; ++f) x[f] = (e2 + row[f]) + kd_bcast(at, f);
+        const float n2 = kd_lse(x);
+        at = live ? n2 : KD_NEG;
+        if (live) At[(size_t)i * T + t] = at;
       }
     }
   }
@@ -95,7 +99,7 @@ __global__ __launch_bounds__(64) void crf_posterior_kl_kernel(const float* __res
     float bs = live ? trans[stop * T + t] : KD_NEG, bt = bs;
     for (int i = L - 1; i >= 0; --i) {
       const float gs = live ? (As[(size_t)i * T + t] + bs) * inv_tau : -INFINITY;
-      const float gt = live ? (At[(size_t)i * T + t] + bt) * inv_tau : -INFINITY;
+      const float gt = live ? (TSCORE ? et[(size_t)i * T + t] : At[(size_t)i * T + t] + bt) * inv_tau : -INFINITY;
       const float ms = wave_max(gs), mt = wave_max(gt);
       const float xs = live ? __expf(gs - ms) : 0.0f, xt = live ? __expf(gt - mt) : 0.0f;
       const float zs = wave_sum(xs), zt = wave_sum(xt);
@@ -108,16 +112,18 @@ __global__ __launch_bounds__(64) void crf_posterior_kl_kernel(const float* __res
       }
       if (i > 0) {
         const float e1 = live ? es[(size_t)i * T + t] : 0.0f;
-        const float e2 = live ? et[(size_t)i * T + t] : 0.0f;
         float x[KD_TT];
 #pragma unroll
         for (int u = 0; u < KD_TT; ++u) x[u] = (kd_bcast(e1, u) + col[u]) + kd_bcast(bs, u);
         const float n1 = kd_lse(x);
-#pragma unroll
-        for (int u = 0; u < KD_TT; ++u) x[u] = (kd_bcast(e2, u) + col[u]) + kd_bcast(bt, u);
-        const float n2 = kd_lse(x);
         bs = live ? n1 : KD_NEG;
-        bt = live ? n2 : KD_NEG;
+        if (!TSCORE) {
+          const float e2 = live ? et[(size_t)i * T + t] : 0.0f;
+#pragma unroll
+          for (int u = 0; u < KD_TT; ++u) x[u] = (kd_bcast(e2, u) + col[u]) + kd_bcast(bt, u);
+          const float n2 = kd_lse(x);
+          bt = live ? n2 : KD_NEG;
+        }
       }
     }
   }
@@ -186,6 +192,255 @@ __global__ __launch_bounds__(64) void crf_posterior_kl_kernel(const float* __res
   }
 }
 
+// Forward-backward scores of a (teacher) CRF: score[b,i,t] = alpha_i[t] + beta_i[t] for i < lens[b], 0 past it -- what
+// ModelFinetuner.assign_pretrained_teacher_targets stores per sentence as the `distill_posterior` target
+// (finetune_trainer.py:1627-1634: `(forward_var + backward_var) * mask` with the teacher's own transitions, after the logits of
+// START / STOP / <unk> were lowered by 1e12 -- here the tags of the `suppress` bit mask).  alpha is written into `score` by the
+// forward scan and beta added in place by the backward scan: no workspace.
+__global__ __launch_bounds__(64) void crf_fb_score_kernel(const float* __restrict__ emit, const float* __restrict__ trans,
+                                                          const int* __restrict__ lens, unsigned suppress, int n, int T, int start,
+                                                          int stop, float* __restrict__ score) {
+  const int b = blockIdx.x;
+  const int t = threadIdx.x;
+  const int L = lens[b];
+  const bool live = t < T;
+  const float off = (live && ((suppress >> t) & 1u)) ? 1e12f : 0.0f;
+  float row[KD_TT], col[KD_TT];
+#pragma unroll
+  for (int f = 0; f < KD_TT; ++f) {
+    row[f] = (live && f < T) ? trans[t * T + f] : -INFINITY;
+    col[f] = (live && f < T) ? trans[f * T + t] : -INFINITY;
+  }
+  const float* e = emit + (size_t)b * n * T;
+  float* sc = score + (size_t)b * n * T;
+  for (int i = max(L, 0) * T + t; i < n * T; i += 64) sc[i] = 0.0f;
+  if (L <= 0) return;
+  float a = (t == start) ? 0.0f : KD_NEG;
+  for (int i = 0; i < L; ++i) {
+    const float e1 = live ? e[(size_t)i * T + t] - off : 0.0f;
+    float x[KD_TT];
+#pragma unroll
+    for (int f = 0; f < KD_TT; ++f) x[f] = (e1 + row[f]) + kd_bcast(a, f);
+    const float n1 = kd_lse(x);
+    a = live ? n1 : KD_NEG;
+    if (live) sc[(size_t)i * T + t] = a;
+  }
+  float bt = live ? trans[stop * T + t] : KD_NEG;
+  for (int i = L - 1; i >= 0; --i) {
+    if (live) sc[(size_t)i * T + t] += bt;
+    if (i > 0) {
+      const float e1 = live ? e[(size_t)i * T + t] - off : 0.0f;
+      float x[KD_TT];
+#pragma unroll
+      for (int u = 0; u < KD_TT; ++u) x[u] = (kd_bcast(e1, u) + col[u]) + kd_bcast(bt, u);
+      const float n1 = kd_lse(x);
+      bt = live ? n1 : KD_NEG;
+    }
+  }
+}
+
+// Teacher side of `distill_exact` (finetune_trainer.py:1705-1722,1885): for every adjacent token pair (i-1, i), i < lens[b], the
+// softmax over the T*T (to, from) tag pairs of (alpha_{i-1}[from] + beta_i[to] + e_i[to] + trans[to, from]) / tau -- the
+// teacher's tempered pairwise posterior -- plus start_score[t] = (e_0[t] + trans[t, START] + beta_0[t]) / tau and
+// end_score[t] = (trans[STOP, t] + alpha_{L-1}[t]) / tau.  Emissions of the `suppress` tags lowered by 1e12 as in
+// crf_fb_score_kernel.  pair rows at or past lens[b] - 1 are written as zeros (the reference stores softmax(0) = 1 / T^2 there
+// and multiplies them by a zero mask in the loss, sequence_tagger_model.py:2170,2414).  ws: n * T floats per sentence (alpha).
+__global__ __launch_bounds__(64) void crf_pair_posterior_kernel(const float* __restrict__ emit, const float* __restrict__ trans,
+                                                                const int* __restrict__ lens, unsigned suppress, float tau, int n,
+                                                                int T, int start, int stop, float* __restrict__ pair,
+                                                                float* __restrict__ start_score, float* __restrict__ end_score,
+                                                                float* __restrict__ ws) {
+  const int b = blockIdx.x;
+  const int t = threadIdx.x;
+  const int L = lens[b];
+  const bool live = t < T;
+  const float off = (live && ((suppress >> t) & 1u)) ? 1e12f : 0.0f;
+  const float inv_tau = 1.0f / tau;
+  float row[KD_TT], col[KD_TT];
+#pragma unroll
+  for (int f = 0; f < KD_TT; ++f) {
+    row[f] = (live && f < T) ? trans[t * T + f] : -INFINITY;
+    col[f] = (live && f < T) ? trans[f * T + t] : -INFINITY;
+  }
+  const float* e = emit + (size_t)b * n * T;
+  float* A = ws + (size_t)b * n * T;
+  float* P = pair + (size_t)b * (n > 0 ? n - 1 : 0) * T * T;
+  for (size_t i = (size_t)max(L - 1, 0) * T * T + t; i < (size_t)(n > 0 ? n - 1 : 0) * T * T; i += 64) P[i] = 0.0f;
+  if (L <= 0) {
+    if (live) start_score[(size_t)b * T + t] = end_score[(size_t)b * T + t] = 0.0f;
+    return;
+  }
+  float a = (t == start) ? 0.0f : KD_NEG;
+  for (int i = 0; i < L; ++i) {
+    const float e1 = live ? e[(size_t)i * T + t] - off : 0.0f;
+    float x[KD_TT];
+#pragma unroll
+    for (int f = 0; f < KD_TT; ++f) x[f] = (e1 + row[f]) + kd_bcast(a, f);
+    const float n1 = kd_lse(x);
+    a = live ? n1 : KD_NEG;
+    if (live) A[(size_t)i * T + t] = a;
+  }
+  if (live) end_score[(size_t)b * T + t] = (trans[stop * T + t] + a) * inv_tau;
+  float bt = live ? trans[stop * T + t] : KD_NEG;
+  for (int i = L - 1; i >= 1; --i) {
+    const float e1 = live ? e[(size_t)i * T + t] - off : 0.0f;
+    const float ap = live ? A[(size_t)(i - 1) * T + t] : KD_NEG;   // alpha_{i-1}[lane]
+    float x[KD_TT];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int f = 0; f < KD_TT; ++f) {
+      x[f] = live ? (((kd_bcast(ap, f) + bt) + (e1 + row[f])) * inv_tau) : -INFINITY;
+      mx = fmaxf(mx, x[f]);
+    }
+    mx = wave_max(mx);
+    float sm = 0.0f;
+#pragma unroll
+    for (int f = 0; f < KD_TT; ++f) {
+      x[f] = __expf(x[f] - mx);
+      sm += x[f];
+    }
+    sm = wave_sum(sm);
+    const float inv = 1.0f / sm;
+    if (live) {
+      float* dst = P + (size_t)(i - 1) * T * T + (size_t)t * T;
+#pragma unroll
+      for (int f = 0; f < KD_TT; ++f)
+        if (f < T) dst[f] = x[f] * inv;
+    }
+    float y[KD_TT];
+#pragma unroll
+    for (int u = 0; u < KD_TT; ++u) y[u] = (kd_bcast(e1, u) + col[u]) + kd_bcast(bt, u);
+    const float n1 = kd_lse(y);
+    bt = live ? n1 : KD_NEG;
+  }
+  if (live) start_score[(size_t)b * T + t] = (((e[t] - off) + trans[t * T + start]) + bt) * inv_tau;
+}
+
+// Student side of `distill_exact` (simple_forward_distillation_loss, sequence_tagger_model.py:2139-2244, and
+// _calculate_xstruct_distillation_loss, :2400-2425), forward AND backward:
+//     loss[b] = max(0, -(E_b - logZ_tau) * tau^2)
+//     E_b = sum_{i>=1} sum_{t,f} pair_i[t,f] (e_i[t] + trans[t,f]) / tau + sum_t softmax(start_score)[t] (e_0[t] + trans[t,START]) / tau
+//           + sum_t softmax(end_score)[t] trans[STOP,t] / tau,          logZ_tau = the partition of the CRF (e / tau, trans / tau)
+// The reference differentiates it through autograd; here d loss / d e_i[t] = tau (mu_i[t] - sum_f pair_i[t,f]) with mu the token
+// marginals of the tempered CRF, d loss / d trans[t,f] = tau sum_i (nu_i[t,f] - pair_i[t,f]) with nu its pairwise marginals, and
+// the START column / STOP row likewise; a sentence whose loss was clamped to 0 contributes no gradient (the reference overwrites
+// it with a constant).  demit WRITTEN, dtrans ADDED, each scaled by wgt[b].  ws: n * T floats per sentence.
+__global__ __launch_bounds__(64) void crf_exact_kd_kernel(const float* __restrict__ emit, const float* __restrict__ trans,
+                                                          const int* __restrict__ lens, const float* __restrict__ pair,
+                                                          const float* __restrict__ start_score, const float* __restrict__ end_score,
+                                                          const float* __restrict__ wgt, float tau, int n, int T, int start,
+                                                          int stop, float* __restrict__ loss, float* __restrict__ demit,
+                                                          float* __restrict__ dtrans, float* __restrict__ ws) {
+  const int b = blockIdx.x;
+  const int t = threadIdx.x;
+  const int L = lens[b];
+  const bool live = t < T;
+  const float inv_tau = 1.0f / tau;
+  float row[KD_TT], col[KD_TT];   // trans[t,:] / tau, trans[:,t] / tau
+#pragma unroll
+  for (int f = 0; f < KD_TT; ++f) {
+    row[f] = (live && f < T) ? trans[t * T + f] * inv_tau : -INFINITY;
+    col[f] = (live && f < T) ? trans[f * T + t] * inv_tau : -INFINITY;
+  }
+  const float* e = emit + (size_t)b * n * T;
+  const float* P = pair + (size_t)b * (n > 0 ? n - 1 : 0) * T * T;
+  float* de = demit + (size_t)b * n * T;
+  float* A = ws + (size_t)b * n * T;
+  for (int i = t; i < n * T; i += 64) de[i] = 0.0f;
+  if (L <= 0) {
+    if (t == 0) loss[b] = 0.0f;
+    return;
+  }
+  // softmax of the teacher's start / end scores
+  float ps, pe;
+  {
+    const float s1 = live ? start_score[(size_t)b * T + t] : -INFINITY, s2 = live ? end_score[(size_t)b * T + t] : -INFINITY;
+    const float m1 = wave_max(s1), m2 = wave_max(s2);
+    const float x1 = live ? __expf(s1 - m1) : 0.0f, x2 = live ? __expf(s2 - m2) : 0.0f;
+    ps = x1 / wave_sum(x1);
+    pe = x2 / wave_sum(x2);
+  }
+  const float tstart = live ? trans[t * T + start] * inv_tau : 0.0f;   // trans[t, START] / tau
+  const float tstop = live ? trans[stop * T + t] * inv_tau : 0.0f;     // trans[STOP, t] / tau
+  // ---- forward scan: tempered alpha + the teacher's expected score
+  float expect = 0.0f;
+  float a = (t == start) ? 0.0f : KD_NEG;
+  for (int i = 0; i < L; ++i) {
+    const float e1 = live ? e[(size_t)i * T + t] * inv_tau : 0.0f;
+    float x[KD_TT];
+#pragma unroll
+    for (int f = 0; f < KD_TT; ++f) x[f] = (e1 + row[f]) + kd_bcast(a, f);
+    const float n1 = kd_lse(x);
+    a = live ? n1 : KD_NEG;
+    if (live) {
+      A[(size_t)i * T + t] = a;
+      if (i == 0) {
+        expect += ps * (e1 + tstart);
+      } else {
+        const float* src = P + (size_t)(i - 1) * T * T + (size_t)t * T;
+#pragma unroll
+        for (int f = 0; f < KD_TT; ++f)
+          if (f < T) expect += src[f] * (e1 + row[f]);
+      }
+    }
+  }
+  if (live) expect += pe * tstop;
+  expect = wave_sum(expect);
+  float logz;
+  {
+    const float v = live ? a + tstop : -INFINITY;
+    const float m = wave_max(v);
+    logz = m + logf(wave_sum(live ? __expf(v - m) : 0.0f));
+  }
+  const float lb = -(expect - logz) * tau * tau;
+  if (t == 0) loss[b] = lb < 0.0f ? 0.0f : lb;
+  if (lb < 0.0f) return;
+  const float w = wgt[b] * tau;   // -tau^2 * (1 / tau): both E and logZ_tau depend on (e, trans) through (e, trans) / tau
+  // ---- backward scan: beta, marginals, gradients
+  float drow[KD_TT];
+#pragma unroll
+  for (int f = 0; f < KD_TT; ++f) drow[f] = 0.0f;
+  float bt = live ? tstop : KD_NEG;
+  float dstop = 0.0f, dstart = 0.0f;
+  for (int i = L - 1; i >= 0; --i) {
+    const float e1 = live ? e[(size_t)i * T + t] * inv_tau : 0.0f;
+    const float ai = live ? A[(size_t)i * T + t] : KD_NEG;
+    const float mu = live ? __expf((ai + bt) - logz) : 0.0f;
+    if (i == L - 1) dstop = w * (mu - pe);
+    float pm = 0.0f;
+    if (i == 0) {
+      pm = ps;
+      dstart = w * (mu - ps);
+    } else {
+      const float ap = live ? A[(size_t)(i - 1) * T + t] : KD_NEG;
+      const float c = (e1 + bt) - logz;
+      const float* src = P + (size_t)(i - 1) * T * T + (size_t)t * T;
+#pragma unroll
+      for (int f = 0; f < KD_TT; ++f) {
+        const float pv = (live && f < T) ? src[f] : 0.0f;
+        const float nu = live ? __expf((kd_bcast(ap, f) + row[f]) + c) : 0.0f;
+        drow[f] += w * (nu - pv);
+        pm += pv;
+      }
+    }
+    if (live) de[(size_t)i * T + t] = w * (mu - pm);
+    if (i > 0) {
+      float y[KD_TT];
+#pragma unroll
+      for (int u = 0; u < KD_TT; ++u) y[u] = (kd_bcast(e1, u) + col[u]) + kd_bcast(bt, u);
+      const float n1 = kd_lse(y);
+      bt = live ? n1 : KD_NEG;
+    }
+  }
+  if (live) {
+#pragma unroll
+    for (int f = 0; f < KD_TT; ++f)
+      if (f < T && drow[f] != 0.0f) atomicAdd(dtrans + t * T + f, drow[f]);
+    if (dstart != 0.0f) atomicAdd(dtrans + t * T + start, dstart);
+    if (dstop != 0.0f) atomicAdd(dtrans + stop * T + t, dstop);
+  }
+}
+
 extern "C" {
 
 // floats of workspace kbner_crf_posterior_kl needs
@@ -203,8 +458,72 @@ int kbner_crf_posterior_kl(const float* emit_s, const float* emit_t, const float
   if (B == 0) return 0;
   KBNER_CHECK_ARG(emit_s != nullptr && emit_t != nullptr && trans != nullptr && lens != nullptr && wgt != nullptr &&
                   loss != nullptr && demit != nullptr && dtrans != nullptr && ws != nullptr);
-  hipLaunchKernelGGL(crf_posterior_kl_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, emit_s, emit_t, trans, lens, wgt, tau, n,
-                     T, start, stop, loss, demit, dtrans, ws);
+  hipLaunchKernelGGL(crf_posterior_kl_kernel<false>, dim3(B), dim3(64), 0, (hipStream_t)stream, emit_s, emit_t, trans, lens, wgt,
+                     tau, n, T, start, stop, loss, demit, dtrans, ws);
+  KBNER_LAUNCH_RET();
+}
+
+// Teacher-student posterior distillation (simple_forward_distillation_loss, `distill_posterior` branch,
+// sequence_tagger_model.py:2120-2136): as kbner_crf_posterior_kl, but the teacher side is given as its forward-backward SCORES
+// score_t f32[B,n,T] (kbner_crf_fb_score of the teacher's emissions under the teacher's transitions), not as emissions.
+// Same workspace size, same outputs (demit WRITTEN, dtrans ADDED).
+int kbner_crf_posterior_kl_scores(const float* emit_s, const float* score_t, const float* trans, const int* lens, const float* wgt,
+                                  float tau, int B, int n, int T, int start, int stop, float* loss, float* demit, float* dtrans,
+                                  float* ws, void* stream) {
+  KBNER_CHECK_ARG(B >= 0 && n >= 0 && T > 0 && T <= KD_TT && tau > 0.0f);
+  KBNER_CHECK_ARG(start >= 0 && start < T && stop >= 0 && stop < T);
+  if (B == 0) return 0;
+  KBNER_CHECK_ARG(emit_s != nullptr && score_t != nullptr && trans != nullptr && lens != nullptr && wgt != nullptr &&
+                  loss != nullptr && demit != nullptr && dtrans != nullptr && ws != nullptr);
+  hipLaunchKernelGGL(crf_posterior_kl_kernel<true>, dim3(B), dim3(64), 0, (hipStream_t)stream, emit_s, score_t, trans, lens, wgt,
+                     tau, n, T, start, stop, loss, demit, dtrans, ws);
+  KBNER_LAUNCH_RET();
+}
+
+// score f32[B,n,T] = alpha + beta (log domain) of the CRF (emit, trans) at the tokens below lens[b], 0 past them; the emissions
+// of the tags set in `suppress` (bit t = tag t) are lowered by 1e12 first (finetune_trainer.py:1627-1634).  T <= 32.
+int kbner_crf_fb_score(const float* emit, const float* trans, const int* lens, unsigned suppress, int B, int n, int T, int start,
+                       int stop, float* score, void* stream) {
+  KBNER_CHECK_ARG(B >= 0 && n >= 0 && T > 0 && T <= KD_TT);
+  KBNER_CHECK_ARG(start >= 0 && start < T && stop >= 0 && stop < T);
+  if (B == 0 || n == 0) return 0;
+  KBNER_CHECK_ARG(emit != nullptr && trans != nullptr && lens != nullptr && score != nullptr);
+  hipLaunchKernelGGL(crf_fb_score_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, emit, trans, lens, suppress, n, T, start, stop,
+                     score);
+  KBNER_LAUNCH_RET();
+}
+
+// floats of workspace kbner_crf_pair_posterior / kbner_crf_exact_kd need
+size_t kbner_crf_pair_ws_floats(int B, int n, int T) { return (size_t)B * n * T; }
+
+// Teacher targets of `distill_exact` (finetune_trainer.py:1705-1722,1885): pair f32[B, n-1, T*T] (index to * T + from),
+// start_score / end_score f32[B,T] of the CRF (emit - 1e12 on the `suppress` tags, trans) at temperature tau.  T <= 32.
+int kbner_crf_pair_posterior(const float* emit, const float* trans, const int* lens, unsigned suppress, float tau, int B, int n,
+                             int T, int start, int stop, float* pair, float* start_score, float* end_score, float* ws,
+                             void* stream) {
+  KBNER_CHECK_ARG(B >= 0 && n >= 1 && T > 0 && T <= KD_TT && tau > 0.0f);
+  KBNER_CHECK_ARG(start >= 0 && start < T && stop >= 0 && stop < T);
+  if (B == 0) return 0;
+  KBNER_CHECK_ARG(emit != nullptr && trans != nullptr && lens != nullptr && (pair != nullptr || n == 1) &&
+                  start_score != nullptr && end_score != nullptr && ws != nullptr);
+  hipLaunchKernelGGL(crf_pair_posterior_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, emit, trans, lens, suppress, tau, n, T,
+                     start, stop, pair, start_score, end_score, ws);
+  KBNER_LAUNCH_RET();
+}
+
+// Student loss of `distill_exact` against those targets (sequence_tagger_model.py:2139-2244,2400-2425): loss f32[B] (clamped
+// at 0), demit f32[B,n,T] WRITTEN with d(sum_b wgt[b] loss[b]) / d emit, the transition gradient ADDED to dtrans.  T <= 32.
+int kbner_crf_exact_kd(const float* emit, const float* trans, const int* lens, const float* pair, const float* start_score,
+                       const float* end_score, const float* wgt, float tau, int B, int n, int T, int start, int stop, float* loss,
+                       float* demit, float* dtrans, float* ws, void* stream) {
+  KBNER_CHECK_ARG(B >= 0 && n >= 1 && T > 0 && T <= KD_TT && tau > 0.0f);
+  KBNER_CHECK_ARG(start >= 0 && start < T && stop >= 0 && stop < T);
+  if (B == 0) return 0;
+  KBNER_CHECK_ARG(emit != nullptr && trans != nullptr && lens != nullptr && (pair != nullptr || n == 1) &&
+                  start_score != nullptr && end_score != nullptr && wgt != nullptr && loss != nullptr && demit != nullptr &&
+                  dtrans != nullptr && ws != nullptr);
+  hipLaunchKernelGGL(crf_exact_kd_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, emit, trans, lens, pair, start_score,
+                     end_score, wgt, tau, n, T, start, stop, loss, demit, dtrans, ws);
   KBNER_LAUNCH_RET();
 }
 

@@ -373,6 +373,29 @@ extern "C" int kbner_scatter_rows_f32(const float* rows, const int* idx, float* 
   KBNER_LAUNCH_RET();
 }
 
+// fp32 row scatter-ADD, any width: dst[idx[r],:] += rows[r,:] for idx[r] >= 0 (indices unique: plain read-modify-write).
+// The knowledge-distillation step (kbner/engine.py:Tagger.kd_loss) folds the gradient of the gold-label NLL, computed on the
+// rows left after the remove_x compaction, back into the gradient of the all-token emissions the KD terms are defined on
+// (the backward of the masked_select compaction, sequence_tagger_model.py:2474-2488, under autograd in the reference).
+__global__ __launch_bounds__(256) void scatter_add_rows_f32_kernel(const float* __restrict__ rows, const int* __restrict__ idx,
+                                                                   float* __restrict__ dst, int R, int W) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)R * W) return;
+  const int r = (int)(i / W), c = (int)(i % W);
+  const int d = idx[r];
+  if (d >= 0) dst[(size_t)d * W + c] += rows[i];
+}
+
+extern "C" int kbner_scatter_add_rows_f32(const float* rows, const int* idx, float* dst, int R, int W, void* stream) {
+  KBNER_CHECK_ARG(R >= 0 && W > 0);
+  if (R == 0) return 0;
+  KBNER_CHECK_ARG(rows != nullptr && idx != nullptr && dst != nullptr);
+  const size_t n = (size_t)R * W;
+  hipLaunchKernelGGL(scatter_add_rows_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rows, idx,
+                     dst, R, W);
+  KBNER_LAUNCH_RET();
+}
+
 // Materialise a dropout site's multiplier (tests / debugging only: the product kernels regenerate it in registers):
 // out[z,i,j] = drop_keep(rowkey(seed, z*M+i), colkey(seed, z*N+j)) ? 1/(1-p) : 0.  Hidden-state sites: Z=1, [M tokens, H];
 // attention-probability sites: Z = B*A heads, M = N = S.

@@ -587,6 +587,102 @@ class Tagger:
             self._backprop_emissions(demit, pooled, crow_idx, B, nc, R, S, grad_ready)
         return loss
 
+    # ---------------------------------------------------------------- teacher-student knowledge distillation
+    def kd_loss(self, batch, kd, interpolation, tau, loss_scale=1.0, backward=True, weights=None, grad_ready=None):
+        """One micro-batch of `distill_mode` training (FastSequenceTagger.simple_forward_distillation_loss,
+        sequence_tagger_model.py:2110-2372, for a CRF student):
+            interpolation * (posterior + crf + exact) + (1 - interpolation) * NLL
+        The KD terms are defined on the emissions of ALL word tokens (`features = self.forward(data_points)`, mask = the length
+        mask), the NLL on the tokens left after the remove_x compaction (`_calculate_loss`) -- one encoder pass serves both.
+        kd: the batch's teacher targets as device tensors, any of
+            "scores"   list (one per teacher) of f32[B,n,T] teacher forward-backward scores          (distill_posterior)
+            "targets"  i32[B,n,K] teacher n-best tag sequences, K = best_k * teachers                 (distill_crf)
+            "weights"  f32[B,K] their path weights + "att_nums" (sentence, teacher) pairs             (crf_attention)
+            "exact"    (pair f32[B,n-1,T*T], start_score f32[B,T], end_score f32[B,T])                (distill_exact)
+        weights: optional per-sentence weights replacing the 1/B of the batch means.  Returns the loss (0-d device tensor);
+        self.last_kd_parts = (kd terms, NLL), both unweighted by the interpolation."""
+        return self._launch(self._kd_loss, batch, kd, interpolation, tau, loss_scale, backward, weights, grad_ready)
+
+    def _kd_loss(self, batch, kd, interpolation, tau, loss_scale, backward, weights, grad_ready):
+        B, S = batch["B"], batch["S"]
+        R = batch.get("R", B)
+        hidden = self.encoder_forward(batch["ids"], batch["pos_ids"], batch["maskbias"], R, S)
+        n = batch["row_idx"].numel() // B
+        row_idx = batch["row_idx"]
+        if self.training and self.word_dropout > 0.0:
+            # WordDropout (flair/nn.py:176-183): token position k zeroed for EVERY sentence of the batch (see _emit)
+            self._last_word_dropped = self._drop_rng.random(n) < self.word_dropout
+            dropped = torch.from_numpy(self._last_word_dropped).to(self.device).repeat(B)
+            row_idx = torch.where(dropped, torch.full_like(row_idx, -1), row_idx)
+        em, pooled = self.emissions(hidden, row_idx, B, n)
+        self.last_emissions = em
+        loss, demit = self.kd_crf_terms(em, batch, kd, interpolation, tau, loss_scale, backward, weights)
+        if backward:
+            self._backprop_emissions(demit, pooled, row_idx, B, n, R, S, grad_ready)
+        return loss
+
+    def kd_crf_terms(self, em, batch, kd, interpolation, tau, loss_scale=1.0, backward=True, weights=None, dtrans=None):
+        """everything of kd_loss downstream of the all-token emissions em f32[B,n,T]: -> (loss 0-d tensor, d loss / d em or None).
+        The transition gradient is accumulated into arena.g (or into `dtrans` when given: tests)."""
+        a = self.arena
+        B, n, T = em.shape
+        trans = a.param("transitions")
+        w = self._sentence_weights(weights, B)
+        if dtrans is None:
+            dtrans = a.grad("transitions") if backward else torch.zeros((T, T), dtype=F32, device=self.device)
+        lens = batch["lengths"]
+        ip = float(interpolation)
+        kd_val = torch.zeros((), dtype=F32, device=self.device)
+        demit = None
+
+        def acc(d):
+            nonlocal demit
+            demit = d if demit is None else demit.add_(d)
+
+        scores = kd.get("scores") or []
+        for st in scores:                                                # :2120-2136, mean over the teachers
+            wk = w * (ip / len(scores))
+            per, d = ops.crf_posterior_kl_scores(em, st, trans, lens, wk * loss_scale, tau, self.start, self.stop, dtrans)
+            kd_val = kd_val + (per * w).sum() / len(scores)
+            acc(d)
+        if kd.get("exact") is not None:                                  # :2139-2244
+            pair, s_sc, e_sc = kd["exact"]
+            per, d = ops.crf_exact_kd(em, trans, lens, pair, s_sc, e_sc, w * (ip * loss_scale), tau, self.start, self.stop, dtrans)
+            kd_val = kd_val + (per * w).sum()
+            acc(d)
+        if kd.get("targets") is not None:                                # :2249-2309: every teacher path as a gold sequence
+            tg = kd["targets"]
+            K = tg.shape[2]
+            em_k = em.repeat_interleave(K, 0)                            # row b * K + k, as the reference's repeat / permute
+            tags_k = tg.permute(0, 2, 1).reshape(B * K, n).contiguous()
+            lens_k = lens.repeat_interleave(K)
+            logz, gold, alpha = ops.crf_nll_fwd(em_k, trans, tags_k, lens_k, self.start, self.stop)
+            if kd.get("weights") is not None:                            # crf_attention: sum(nll * att) / att_nums
+                wk = (kd["weights"] * (w[:, None] * (B / float(kd["att_nums"])))).reshape(B * K).contiguous()
+            else:                                                        # mean over the B * K paths
+                wk = (w[:, None] / K).expand(B, K).reshape(B * K).contiguous()
+            part = torch.empty((1,), dtype=F32, device=self.device)
+            ops.wdiff_sum(logz, gold, wk, part)
+            kd_val = kd_val + part[0]
+            d = ops.crf_nll_bwd(em_k, trans, tags_k, lens_k, alpha, logz, wk * (ip * loss_scale), self.start, self.stop, dtrans)
+            acc(d.view(B, K, n, T).sum(1))
+        # gold-label NLL on the compacted rows (:2371, _calculate_loss)
+        nc = batch["ctags"].shape[1]
+        comp = ops.gather_rows_f32(em.view(B * n, T), batch["cfeat_idx"]).view(B, nc, T)
+        logz, gold, alpha = ops.crf_nll_fwd(comp, trans, batch["ctags"], batch["clens"], self.start, self.stop)
+        nll = torch.empty((1,), dtype=F32, device=self.device)
+        ops.wdiff_sum(logz, gold, w, nll)
+        self.last_kd_parts = (kd_val, nll[0])
+        loss = ip * kd_val + (1.0 - ip) * nll[0]
+        if not backward:
+            return loss, None
+        dc = ops.crf_nll_bwd(comp, trans, batch["ctags"], batch["clens"], alpha, logz, w * ((1.0 - ip) * loss_scale), self.start,
+                             self.stop, dtrans)
+        if demit is None:
+            demit = torch.zeros_like(em)
+        ops.scatter_add_rows_f32(dc.view(B * nc, T), batch["cfeat_idx"], demit.view(B * n, T))
+        return loss, demit
+
     def forward_features(self, batch):
         """FastSequenceTagger.forward (sequence_tagger_model.py:844): emissions for ALL word tokens."""
         B, S = batch["B"], batch["S"]

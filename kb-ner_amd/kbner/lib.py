@@ -24,11 +24,17 @@ SIGNATURES = {
     "kbner_crf_posterior": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P]),
     "kbner_crf_posterior_kl_ws_floats": (c_size_t, [c_int, c_int, c_int]),
     "kbner_crf_posterior_kl": (c_int, [P, P, P, P, P, c_float, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P]),
+    "kbner_crf_fb_score": (c_int, [P, P, P, U32, c_int, c_int, c_int, c_int, c_int, P, P]),
+    "kbner_crf_posterior_kl_scores": (c_int, [P, P, P, P, P, c_float, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P]),
+    "kbner_crf_pair_ws_floats": (c_size_t, [c_int, c_int, c_int]),
+    "kbner_crf_pair_posterior": (c_int, [P, P, P, U32, c_float, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P]),
+    "kbner_crf_exact_kd": (c_int, [P, P, P, P, P, P, P, c_float, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P]),
     "kbner_crf_viterbi_nbest_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "kbner_crf_viterbi_nbest": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P]),
     "kbner_gather_rows": (c_int, [P, P, P, c_int, c_int, P]),
     "kbner_gather_rows_ld": (c_int, [P, c_int, P, P, c_int, c_int, c_int, P]),
     "kbner_gather_rows_f32": (c_int, [P, P, P, c_int, c_int, P]),
+    "kbner_scatter_add_rows_f32": (c_int, [P, P, P, c_int, c_int, P]),
     "kbner_scatter_rows": (c_int, [P, P, P, c_int, c_int, P]),
     "kbner_scatter_rows_f32": (c_int, [P, P, P, c_int, c_int, P]),
     "kbner_head_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, P]),

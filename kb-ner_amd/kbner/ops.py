@@ -110,6 +110,70 @@ def crf_posterior_kl(emit_s, emit_t, trans, lens, weights, tau, start, stop, dtr
     return loss, demit
 
 
+def crf_fb_score(emit, trans, lens, start, stop, suppress=()):
+    """teacher forward-backward scores f32[B,n,T] (alpha + beta below lens, 0 past it); the emissions of the tags in `suppress`
+    are lowered by 1e12 first -- the `distill_posterior` target (finetune_trainer.py:1627-1634)"""
+    _chk(emit, F32, "emit"); _chk(trans, F32, "trans"); _chk(lens, I32, "lens")
+    B, n, T = emit.shape
+    score = torch.empty_like(emit)
+    bits = 0
+    for t in suppress:
+        bits |= 1 << int(t)
+    L.call("kbner_crf_fb_score", ptr(emit), ptr(trans), ptr(lens), bits, B, n, T, start, stop, ptr(score), stream_ptr())
+    return score
+
+
+def crf_posterior_kl_scores(emit_s, score_t, trans, lens, weights, tau, start, stop, dtrans):
+    """teacher-student posterior distillation (simple_forward_distillation_loss, `distill_posterior`): as crf_posterior_kl with the
+    teacher given as its forward-backward scores (crf_fb_score under the teacher's own transitions)"""
+    _chk(emit_s, F32, "emit_s"); _chk(score_t, F32, "score_t"); _chk(trans, F32, "trans"); _chk(lens, I32, "lens")
+    _chk(weights, F32, "weights"); _chk(dtrans, F32, "dtrans")
+    if emit_s.shape != score_t.shape:
+        raise L.KbnerError("student emissions and teacher scores must have the same [B, n, T] shape")
+    B, n, T = emit_s.shape
+    loss = torch.empty((B,), dtype=F32, device=emit_s.device)
+    demit = torch.empty_like(emit_s)
+    ws = torch.empty((int(L.load().kbner_crf_posterior_kl_ws_floats(B, n, T)),), dtype=F32, device=emit_s.device)
+    L.call("kbner_crf_posterior_kl_scores", ptr(emit_s), ptr(score_t), ptr(trans), ptr(lens), ptr(weights), float(tau), B, n, T,
+           start, stop, ptr(loss), ptr(demit), ptr(dtrans), ptr(ws), stream_ptr())
+    return loss, demit
+
+
+def crf_pair_posterior(emit, trans, lens, tau, start, stop, suppress=()):
+    """teacher targets of `distill_exact` (finetune_trainer.py:1705-1722): (pair f32[B,n-1,T*T], start_score f32[B,T],
+    end_score f32[B,T])"""
+    _chk(emit, F32, "emit"); _chk(trans, F32, "trans"); _chk(lens, I32, "lens")
+    B, n, T = emit.shape
+    pair = torch.empty((B, max(n - 1, 0), T * T), dtype=F32, device=emit.device)
+    s_sc = torch.empty((B, T), dtype=F32, device=emit.device)
+    e_sc = torch.empty((B, T), dtype=F32, device=emit.device)
+    ws = torch.empty((max(1, int(L.load().kbner_crf_pair_ws_floats(B, n, T))),), dtype=F32, device=emit.device)
+    bits = 0
+    for t in suppress:
+        bits |= 1 << int(t)
+    L.call("kbner_crf_pair_posterior", ptr(emit), ptr(trans), ptr(lens), bits, float(tau), B, n, T, start, stop,
+           ptr(pair) if n > 1 else None, ptr(s_sc), ptr(e_sc), ptr(ws), stream_ptr())
+    return pair, s_sc, e_sc
+
+
+def crf_exact_kd(emit, trans, lens, pair, start_score, end_score, weights, tau, start, stop, dtrans):
+    """student loss of `distill_exact` (sequence_tagger_model.py:2139-2244,2400-2425) -> (loss f32[B], demit f32[B,n,T]);
+    dtrans f32[T,T] is accumulated into"""
+    _chk(emit, F32, "emit"); _chk(trans, F32, "trans"); _chk(lens, I32, "lens"); _chk(start_score, F32, "start_score")
+    _chk(end_score, F32, "end_score"); _chk(weights, F32, "weights"); _chk(dtrans, F32, "dtrans")
+    B, n, T = emit.shape
+    if n > 1:
+        _chk(pair, F32, "pair")
+        if tuple(pair.shape) != (B, n - 1, T * T):
+            raise L.KbnerError("pair must be [B, n-1, T*T] = %s, got %s" % ((B, n - 1, T * T), tuple(pair.shape)))
+    loss = torch.empty((B,), dtype=F32, device=emit.device)
+    demit = torch.empty_like(emit)
+    ws = torch.empty((max(1, int(L.load().kbner_crf_pair_ws_floats(B, n, T))),), dtype=F32, device=emit.device)
+    L.call("kbner_crf_exact_kd", ptr(emit), ptr(trans), ptr(lens), ptr(pair) if n > 1 else None, ptr(start_score), ptr(end_score),
+           ptr(weights), float(tau), B, n, T, start, stop, ptr(loss), ptr(demit), ptr(dtrans), ptr(ws), stream_ptr())
+    return loss, demit
+
+
 # ---------------------------------------------------------------- rows / head
 def gather_rows(src, idx, out=None):
     _chk(src, BF16, "src"); _chk(idx, I32, "idx")
@@ -142,6 +206,16 @@ def scatter_rows_f32(rows, idx, dst):
     """dst f32[V, W][idx[r], :] = rows f32[R, W][r, :] (unique indices; idx < 0 skipped)"""
     _chk(rows, F32, "rows"); _chk(idx, I32, "idx"); _chk(dst, F32, "dst")
     L.call("kbner_scatter_rows_f32", ptr(rows), ptr(idx), ptr(dst), idx.numel(), rows.shape[-1], stream_ptr())
+
+
+def scatter_add_rows_f32(rows, idx, dst):
+    """dst[idx[r],:] += rows[r,:] (idx[r] < 0 skipped; indices unique), fp32, any width"""
+    _chk(rows, F32, "rows"); _chk(idx, I32, "idx"); _chk(dst, F32, "dst")
+    R, W = rows.shape
+    if idx.numel() != R or dst.shape[-1] != W:
+        raise L.KbnerError("scatter_add_rows_f32: rows [R,W], idx [R], dst [*,W]")
+    L.call("kbner_scatter_add_rows_f32", ptr(rows), ptr(idx), ptr(dst), R, W, stream_ptr())
+    return dst
 
 
 def scatter_rows(dout, idx, dsrc):

@@ -543,3 +543,179 @@ def test_sparse_embedding_optimizer_equals_dense():
     assert torch.equal(tg.arena.param("emb.word")[dead], p0[dead])            # never read, never written
     assert torch.equal(ref.p[ref.offsets["emb.word"]:][:p0.numel()].view_as(p0)[dead], p0[dead])   # the dense update agrees
     assert float((tg.arena.param("emb.word")[~dead] - p0[~dead]).abs().max()) > 0
+
+
+# ---------------------------------------------------------------- teacher-student knowledge distillation
+def _kd_suppress(g):
+    return (int(g["stop"]), int(g["start"]), int(g["unk"]))
+
+
+def test_kd_teacher_targets_vs_reference_golden(golden_dir):
+    """the teacher side of distill_mode (ModelFinetuner.assign_pretrained_teacher_targets) on the HIP path against what the
+    reference's own methods produced (tests/golden/kd_loss.npz): forward-backward scores (kbner_crf_fb_score), n-best paths and
+    weights (kbner_crf_viterbi_nbest, tie-free teacher matrices), pairwise posteriors + start / end scores
+    (kbner_crf_pair_posterior)"""
+    from kbner import ops
+    g = np.load(os.path.join(golden_dir, "kd_loss.npz"))
+    start, stop = int(g["start"]), int(g["stop"])
+    for c in range(int(g["n_cases"])):
+        lens, tau = g["c%d_lens" % c], float(g["c%d_tau" % c])
+        posterior, crf, att, exact = [bool(x) for x in g["c%d_flags" % c]]
+        n = g["c%d_es" % c].shape[1]
+        valid = np.arange(n)[None, :] < lens[:, None]
+        dl = torch.from_numpy(lens.astype(np.int32)).cuda()
+        for t in range(int(g["c%d_n_teachers" % c])):
+            logits = torch.from_numpy(g["c%d_t%d_logits" % (c, t)]).cuda()
+            tr = torch.from_numpy(g["c%d_t%d_trans" % (c, t)]).cuda()
+            if posterior:
+                sc = ops.crf_fb_score(logits, tr, dl, start, stop, _kd_suppress(g)).cpu().numpy()
+                ref = g["c%d_t%d_fb_score" % (c, t)]
+                fin = valid[:, :, None] & (ref > -1e10)
+                assert np.allclose(sc[fin], ref[fin], rtol=1e-5, atol=3e-4), c
+                assert (sc[valid[:, :, None] & (ref <= -1e10)] < -1e10).all() and np.all(sc[~valid] == 0)
+            if crf:
+                ps, dec = ops.crf_viterbi_nbest(logits, tr, dl, start, stop, int(g["c%d_best_k" % c]))
+                np.testing.assert_allclose(ps.cpu().numpy(), g["c%d_t%d_path_score" % (c, t)], rtol=2e-5, atol=1e-7)
+                if not int(g["c%d_sentinel" % c]):
+                    np.testing.assert_array_equal(dec.cpu().numpy() * valid[:, :, None], g["c%d_t%d_decode" % (c, t)])
+            if exact:
+                pair, s_sc, e_sc = ops.crf_pair_posterior(logits, tr, dl, tau, start, stop, _kd_suppress(g))
+                pv = (np.arange(max(n - 1, 0))[None, :] < (lens - 1)[:, None])
+                ref = g["c%d_t%d_pair" % (c, t)]
+                assert np.abs(pair.cpu().numpy()[pv] - ref[pv]).max(initial=0.0) < 3e-6, c
+                assert np.all(pair.cpu().numpy()[~pv] == 0)
+                for mine, want in ((s_sc.cpu().numpy(), g["c%d_t%d_start_score" % (c, t)]),
+                                   (e_sc.cpu().numpy(), g["c%d_t%d_end_score" % (c, t)])):
+                    fin = want > -1e10
+                    assert np.allclose(mine[fin], want[fin], rtol=1e-5, atol=3e-4) and (mine[~fin] < -1e10).all(), c
+
+
+def _kd_device_case(g, c):
+    """one golden case as (emissions, device batch, kd dict) for Tagger.kd_crf_terms"""
+    from kbner import batch as kb
+    es, lens, tags = g["c%d_es" % c], g["c%d_lens" % c], g["c%d_tags" % c]
+    B, n, T = es.shape
+    nt = int(g["c%d_n_teachers" % c])
+    posterior, crf, att, exact = [bool(x) for x in g["c%d_flags" % c]]
+    x_idx = int(g["x_idx"])
+    valid = np.arange(n)[None, :] < lens[:, None]
+    keep = valid & (tags != x_idx)
+    clens = keep.sum(1).astype(np.int32)
+    nc = max(1, int(clens.max()))
+    cfeat = np.full((B, nc), -1, np.int32)
+    ctags = np.zeros((B, nc), np.int32)
+    for b in range(B):
+        k = np.nonzero(keep[b])[0]
+        cfeat[b, :len(k)] = b * n + k
+        ctags[b, :len(k)] = tags[b, k]
+    db = {"lengths": torch.from_numpy(lens.astype(np.int32)).cuda(), "cfeat_idx": torch.from_numpy(cfeat.reshape(-1)).cuda(),
+          "ctags": torch.from_numpy(ctags).cuda(), "clens": torch.from_numpy(clens).cuda()}
+    kd = {}
+    if posterior:
+        kd["scores"] = [torch.from_numpy(g["c%d_t%d_fb_score" % (c, t)]).cuda() for t in range(nt)]
+    if crf:
+        kd["targets"] = torch.from_numpy(np.concatenate([g["c%d_t%d_decode" % (c, t)] for t in range(nt)], -1).astype(np.int32)).cuda()
+        if att:
+            kd["weights"] = torch.from_numpy(np.concatenate([g["c%d_t%d_path_score" % (c, t)] for t in range(nt)], -1)).cuda()
+            kd["att_nums"] = nt * B
+    if exact:
+        kd["exact"] = tuple(torch.from_numpy(g["c%d_t0_%s" % (c, nm)]).cuda().contiguous() for nm in ("pair", "start_score", "end_score"))
+    return torch.from_numpy(es).cuda(), db, kd
+
+
+def _kd_tagger(T, start, stop, trans):
+    from kbner import engine
+    cfg = engine.EncoderConfig(vocab_size=64, hidden_size=128, num_hidden_layers=1, num_attention_heads=2, intermediate_size=128,
+                               max_position_embeddings=66)
+    tg = engine.Tagger(cfg, T, start, stop, device="cuda")
+    tg.init_random(seed=3, std=0.02)
+    tg.arena.param("transitions").copy_(torch.from_numpy(trans).cuda())
+    return tg
+
+
+def test_kd_loss_vs_reference_golden(golden_dir):
+    """Tagger.kd_crf_terms -- the student loss of distill_mode from the emissions on (posterior KL against teacher scores, NLL of
+    the teacher's n-best paths with / without path weights, exact pairwise term, gold NLL on the remove_x-compacted rows,
+    interpolation) and its explicit backward -- against FastSequenceTagger.simple_forward_distillation_loss run under autograd
+    by the reference (tests/golden/kd_loss.npz): loss, d / d emissions, d / d transitions"""
+    g = np.load(os.path.join(golden_dir, "kd_loss.npz"))
+    start, stop = int(g["start"]), int(g["stop"])
+    tg = _kd_tagger(g["trans_s"].shape[0], start, stop, g["trans_s"])
+    for c in range(int(g["n_cases"])):
+        em, db, kd = _kd_device_case(g, c)
+        dtr = torch.zeros_like(tg.arena.param("transitions"))
+        loss, de = tg.kd_crf_terms(em, db, kd, float(g["c%d_interpolation" % c]), float(g["c%d_tau" % c]), dtrans=dtr)
+        torch.cuda.synchronize()
+        ref = float(g["c%d_loss" % c])
+        assert abs(float(loss) - ref) <= 5e-5 * max(1.0, abs(ref)), (c, float(loss), ref)
+        assert abs(float(tg.last_kd_parts[1]) - float(g["c%d_nll" % c])) <= 3e-5 * max(1.0, abs(float(g["c%d_nll" % c]))), c
+        ref = g["c%d_des" % c]
+        assert np.abs(de.cpu().numpy() - ref).max() <= 1e-4 * max(1e-3, np.abs(ref).max()), c
+        ref = g["c%d_dtrans" % c]
+        assert np.abs(dtr.cpu().numpy() - ref).max() <= 2e-4 * max(1e-3, np.abs(ref).max()), c
+
+
+@pytest.mark.parametrize("B,n,T,tau,K", [(32, 40, 29, 4.0, 5), (5, 1, 21, 1.0, 1), (16, 17, 32, 2.0, 3), (3, 150, 29, 3.0, 10)])
+def test_kd_loss_vs_oracle(B, n, T, tau, K):
+    """the same path against the fp64 torch-autograd restatement (oracle/kd.py) on random ragged batches with per-sentence weights
+    left at 1/B, all three KD terms on at once, teacher targets produced ON THE DEVICE (fb scores, n-best, pair posteriors) from
+    random teacher logits -- T = 32 (every lane live), one-token sentences, long sentences"""
+    from kbner import ops
+    from oracle import crf as ocrf
+    from oracle import kd as okd
+    rng = np.random.default_rng(B * 977 + n)
+    start, stop, unk, x_idx = T - 2, T - 1, 0, 5
+    trans = ocrf.init_transitions(T, start, stop, rng).astype(np.float32)
+    trans_t = rng.standard_normal((T, T)).astype(np.float32)     # tie-free for the n-best decoder
+    es = (rng.standard_normal((B, n, T)) * 2.0).astype(np.float32)
+    et = (es + rng.standard_normal((B, n, T))).astype(np.float32)
+    et[:, :, [start, stop]] -= 50.0
+    lens = rng.integers(1, n + 1, size=B)
+    lens[0] = n
+    tags = rng.integers(1, T - 2, size=(B, n))
+    tags[:, n // 2:] = np.where(rng.random((B, n - n // 2)) < 0.3, x_idx, tags[:, n // 2:])
+    tags[:, 0] = 1
+    interp = 0.4
+    dl = torch.from_numpy(lens.astype(np.int32)).cuda()
+    lg, trt = torch.from_numpy(et).cuda(), torch.from_numpy(trans_t).cuda()
+    sup = (stop, start, unk)
+    score = ops.crf_fb_score(lg, trt, dl, start, stop, sup)
+    ps, dec = ops.crf_viterbi_nbest(lg, trt, dl, start, stop, K)
+    valid = torch.arange(n, device="cuda")[None, :] < dl[:, None]
+    dec = (dec * valid[:, :, None]).to(torch.int32).contiguous()
+    pair, s_sc, e_sc = ops.crf_pair_posterior(lg, trt, dl, tau, start, stop, sup)
+    # device targets == oracle targets (double precision)
+    o_score = okd.teacher_fb_score(torch.from_numpy(et).double(), torch.from_numpy(trans_t).double(), lens, start, stop, sup).numpy()
+    fin = valid.cpu().numpy()[:, :, None] & (o_score > -1e10)
+    assert np.abs(score.cpu().numpy()[fin] - o_score[fin]).max() <= 2e-5 * max(1.0, np.abs(o_score[fin]).max())
+    o_pair, o_s, o_e = okd.teacher_pair_posterior(torch.from_numpy(et).double(), torch.from_numpy(trans_t).double(), lens, start, stop,
+                                                  sup, tau)
+    pv = (np.arange(max(n - 1, 0))[None, :] < (lens - 1)[:, None])
+    assert np.abs(pair.cpu().numpy()[pv] - o_pair.numpy()[pv]).max(initial=0.0) < 5e-6
+    kd = {"scores": [score], "targets": dec, "weights": ps, "att_nums": B, "exact": (pair, s_sc, e_sc)}
+    keep = valid.cpu().numpy() & (tags != x_idx)
+    clens = keep.sum(1).astype(np.int32)
+    nc = max(1, int(clens.max()))
+    cfeat, ctags = np.full((B, nc), -1, np.int32), np.zeros((B, nc), np.int32)
+    for b in range(B):
+        k = np.nonzero(keep[b])[0]
+        cfeat[b, :len(k)] = b * n + k
+        ctags[b, :len(k)] = tags[b, k]
+    db = {"lengths": dl, "cfeat_idx": torch.from_numpy(cfeat.reshape(-1)).cuda(), "ctags": torch.from_numpy(ctags).cuda(),
+          "clens": torch.from_numpy(clens).cuda()}
+    tg = _kd_tagger(T, start, stop, trans)
+    dtr = torch.zeros((T, T), device="cuda")
+    loss, de = tg.kd_crf_terms(torch.from_numpy(es).cuda(), db, kd, interp, tau, dtrans=dtr)
+    torch.cuda.synchronize()
+    es_t = torch.from_numpy(es).double().requires_grad_(True)
+    tr_t = torch.from_numpy(trans).double().requires_grad_(True)
+    want = okd.kd_loss(es_t, tr_t, lens, tags, start, stop, x_idx, tau, interp, scores_t=[score.cpu().double()],
+                       targets=dec.cpu().long(), weights=ps.cpu().double(), att_nums=B,
+                       exact=(pair.cpu().double(), s_sc.cpu().double(), e_sc.cpu().double()))
+    want.backward()
+    tol = 1e-4 * max(1.0, n / 20.0)
+    assert abs(float(loss) - float(want.detach())) <= tol * max(1.0, abs(float(want.detach())))
+    ref = es_t.grad.numpy()
+    assert np.abs(de.cpu().numpy() - ref).max() <= tol * max(1e-3, np.abs(ref).max())
+    ref = tr_t.grad.numpy()
+    assert np.abs(dtr.cpu().numpy() - ref).max() <= 3 * tol * max(1e-3, np.abs(ref).max())
