@@ -108,10 +108,33 @@ class ConfigParser:
         return self.create_model(self.config, pretrained=self.load_pretrained(self.config), is_student=True, crf=not nocrf)
 
     def create_teachers(self, is_professor=False):
-        return []
+        """config_parser.py:242-253: one teacher per training corpus, built from `<target>[<corpus>].train_config` (its own
+        YAML: embeddings + model + target_dir / model_name) and loaded from that run's best-model.pt; it teaches that corpus"""
+        if is_professor:
+            raise NotImplementedError("professors (train_with_professor) are outside the hot path")
+        teachers = []
+        for corpus in self.corpus_list:
+            config = Params.from_file(self.config[self.target][corpus]["train_config"])
+            teacher = self.create_model(config, pretrained=True)
+            teacher.targets = {corpus}
+            teachers.append(teacher)
+        return teachers
 
     def create_teachers_list(self, is_professor=False):
-        return []
+        """config_parser.py:255-274 (`is_teacher_list: true`): `<target>.teachers` maps a teacher's YAML to the ':'-joined corpora
+        it teaches; teachers of corpora this run does not train on are skipped"""
+        if is_professor:
+            raise NotImplementedError("professors (train_with_professor) are outside the hot path")
+        teachers = []
+        configs = self.config[self.target]["teachers"]
+        for filename in configs:
+            corpus_target = set(configs[filename].split(":"))
+            if not (set(self.corpus.targets) & corpus_target):
+                continue
+            teacher = self.create_model(Params.from_file(filename), pretrained=True)
+            teacher.targets = corpus_target
+            teachers.append(teacher)
+        return teachers
 
     def load_pretrained(self, config):
         return bool(self.config.get("load_pretrained", False))

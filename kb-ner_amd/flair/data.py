@@ -271,6 +271,9 @@ class Sentence:
         self._embeddings: Dict = {}
         self.language_code = language_code
         self.tokenized = None
+        # knowledge-distillation targets, one entry per teacher (flair/data.py:364-370 of the reference)
+        self._teacher_target, self._teacher_weights, self._teacher_posteriors = [], [], []
+        self._teacher_startscores, self._teacher_endscores = [], []
         if text is not None:
             pos = 0
             for word in text.split():
@@ -431,6 +434,50 @@ class Sentence:
 
     def to(self, device):
         pass
+
+    # -- teacher targets of `distill_mode` training (reference flair/data.py:762-806).  The reference stores torch tensors padded
+    # to the length of the teacher's batch and moves them with `storage_mode`; here they are host numpy arrays trimmed to the
+    # sentence (rows past the sentence length are zero in the reference and never read), padded per training batch by
+    # FastSequenceTagger._kd_batch.  `storage_mode` is accepted and ignored.
+    @staticmethod
+    def _host(vector):
+        import numpy as np
+        return vector.detach().cpu().numpy() if hasattr(vector, "detach") else np.asarray(vector)
+
+    def set_teacher_target(self, vector, storage_mode=None):       # int [len, best_k] n-best tag sequences
+        self._teacher_target.append(self._host(vector)[:len(self)])
+
+    def set_teacher_weights(self, vector, storage_mode=None):      # f32 [best_k] path weights
+        self._teacher_weights.append(self._host(vector))
+
+    def set_teacher_posteriors(self, vector, storage_mode=None):   # f32 [len, T] fb scores, or [len - 1, T * T] (distill_exact)
+        self._teacher_posteriors.append(self._host(vector))
+
+    def set_teacher_startscores(self, vector, storage_mode=None):  # f32 [T]
+        self._teacher_startscores.append(self._host(vector))
+
+    def set_teacher_endscores(self, vector, storage_mode=None):    # f32 [T]
+        self._teacher_endscores.append(self._host(vector))
+
+    def get_teacher_target(self):
+        import numpy as np
+        return np.concatenate(self._teacher_target, -1)
+
+    def get_teacher_weights(self):
+        import numpy as np
+        return np.concatenate(self._teacher_weights, -1)
+
+    def get_teacher_posteriors(self):
+        import numpy as np
+        return np.stack(self._teacher_posteriors, -2)
+
+    def get_teacher_startscores(self):
+        import numpy as np
+        return np.stack(self._teacher_startscores, -2)
+
+    def get_teacher_endscores(self):
+        import numpy as np
+        return np.stack(self._teacher_endscores, -2)
 
     def get_language_code(self) -> str:
         return self.language_code or "en"

@@ -26,11 +26,12 @@ log = logging.getLogger("flair")
 START_TAG: str = "<START>"
 STOP_TAG: str = "<STOP>"
 
-# constructor switches of the reference that select code outside the hot path (KD / MFVI / attention variants / ACE controller
-# training): accepted by name, rejected when switched on
-_UNSUPPORTED_TRUE = ("use_mfvi", "use_cnn", "distill_crf", "crf_attention", "biaf_attention", "use_language_attention",
-                     "token_level_attention", "distill_with_gold", "exp_score", "distill_prob",
-                     "distill_emission", "distill_exact", "posterior_constraint", "use_language_vector", "enhanced_crf",
+# constructor switches of the reference that select code outside the hot path (softmax-head / emission KD, MFVI, attention
+# variants, ACE controller training): accepted by name, rejected when switched on.  The CRF knowledge-distillation switches
+# (distill_crf, crf_attention, distill_with_gold, exp_score, distill_posterior, distill_exact) ARE implemented.
+_UNSUPPORTED_TRUE = ("use_mfvi", "use_cnn", "biaf_attention", "use_language_attention",
+                     "token_level_attention", "distill_prob",
+                     "distill_emission", "posterior_constraint", "use_language_vector", "enhanced_crf",
                      "use_language_id", "use_transition_attention", "unlabel_entropy_loss", "relearn_embeddings", "map_embeddings",
                      "no_encoder", "new_drop", "use_embedding_masks", "use_gumbel", "embedding_attention",
                      "calculate_l2_loss", "l2_loss_only", "train_initial_hidden_state")
@@ -72,8 +73,23 @@ class SequenceTagger(flair.nn.Model):
         if multi_view_training and not (distill_posterior and remove_x and not use_rnn):
             raise NotImplementedError("multi_view_training is implemented for the posterior-distillation form of the shipped "
                                       "configs: distill_posterior: true, remove_x: true, use_rnn: false")
-        if distill_posterior and not multi_view_training:
-            raise NotImplementedError("distill_posterior without multi_view_training belongs to the distillation trainers (out of scope)")
+        # teacher-student knowledge distillation (`distill_mode: true` of ModelFinetuner; simple_forward_distillation_loss below):
+        # distill_posterior (without multi_view_training), distill_crf (+ crf_attention, distill_with_gold, exp_score), distill_exact
+        kd_student = (distill_posterior and not multi_view_training) or distill_crf or distill_exact
+        if kd_student and use_rnn:
+            raise NotImplementedError("knowledge distillation is implemented for the fine-tuning student (use_rnn: false)")
+        if distill_exact and distill_posterior:
+            # both read / write the sentences' `_teacher_posteriors` (finetune_trainer.py:1880-1886, sequence_tagger_model.py
+            # :2128,2163): in the reference the combination fails on the tensor shapes
+            raise ValueError("distill_exact and distill_posterior share the teacher-posterior storage: enable one of them")
+        if distill_exact and distill_crf:
+            # the reference's batch assembly asserts equal target lengths (finetune_trainer.py:1946: the pairwise posteriors have
+            # one row less than the n-best paths), so this combination never trains there
+            raise ValueError("distill_exact cannot be combined with distill_crf (the reference's resort() asserts on it)")
+        if (crf_attention or distill_with_gold) and not distill_crf:
+            raise ValueError("crf_attention / distill_with_gold weight the n-best paths of distill_crf: enable distill_crf")
+        if distill_with_gold and not crf_attention:
+            raise ValueError("distill_with_gold reweights the crf_attention path weights (sequence_tagger_model.py:2282-2304): enable crf_attention")
         self.hidden_size = hidden_size
         self.embeddings = embeddings
         self.tag_dictionary = tag_dictionary
@@ -98,11 +114,13 @@ class SequenceTagger(flair.nn.Model):
         self.biaf_attention = False
         self.use_language_attention = False
         self.use_language_vector = False
-        self.distill_crf = self.distill_prob = self.distill_exact = False
+        self.distill_prob = self.distill_emission = False
+        self.distill_crf, self.distill_exact = bool(distill_crf), bool(distill_exact)
         self.distill_posterior = bool(distill_posterior)
         self.multi_view_training = bool(multi_view_training)
         self.calculate_l2_loss = self.l2_loss_only = False
-        self.crf_attention = False
+        self.crf_attention, self.distill_with_gold, self.exp_score = bool(crf_attention), bool(distill_with_gold), bool(exp_score)
+        self.gold_const = gold_const
         self.selection = None
         self.mask = None
         self.word_map = self.char_map = self.lemma_map = self.postag_map = None
@@ -366,7 +384,8 @@ class SequenceTagger(flair.nn.Model):
         self.mask = torch.from_numpy(hb["keep"].astype(np.float32)).to(flair.device)
         return self.engine.forward_loss(db, backward=False)
 
-    def forward_backward(self, data_points, loss_scale=1.0, sentence_weights=None, grad_ready=None, multi_view=None):
+    def forward_backward(self, data_points, loss_scale=1.0, sentence_weights=None, grad_ready=None, multi_view=None,
+                         distill_interpolation=None):
         """forward_loss + backward into the gradient arena (what `loss.backward()` does at finetune_trainer.py:957).
         sentence_weights (optional, one per sentence) replace the 1/B of the batch mean: see ModelFinetuner.train's
         accumulation-group fusion.  grad_ready(lo, hi): called as soon as arena.g[lo:hi] is final (data-parallel overlap).
@@ -382,6 +401,12 @@ class SequenceTagger(flair.nn.Model):
         hb, db = self._device_batch(data_points)
         self._last = (hb, db)
         self.mask = torch.from_numpy(hb["keep"].astype(np.float32)).to(flair.device)
+        if distill_interpolation is not None:
+            # distill_mode (finetune_trainer.py:897-904 -> simple_forward_distillation_loss): the sentences carry teacher targets
+            loss = self.engine.kd_loss(db, self._kd_batch(data_points, hb), float(distill_interpolation), float(self.temperature),
+                                       loss_scale=loss_scale, backward=True, weights=sentence_weights, grad_ready=grad_ready)
+            self.last_loss_parts = self.engine.last_kd_parts   # (KD terms, gold NLL), before the interpolation
+            return loss
         if not multi_view or len(multi_view[0]) == 0:
             loss = self.engine.forward_loss(db, loss_scale=loss_scale, backward=True, weights=sentence_weights, grad_ready=grad_ready)
             self.last_loss_parts = (loss, None)
@@ -403,6 +428,107 @@ class SequenceTagger(flair.nn.Model):
         store_embeddings(orig, "none")
         self.last_loss_parts = (loss, kd)   # (weighted NLL of the context view, weighted distillation term): 0-d device tensors
         return loss + kd
+
+    # ------------------------------------------------------------------ teacher-student knowledge distillation
+    def _kd_suppress(self):
+        """the tags whose teacher logits are lowered by 1e12 (finetune_trainer.py:1627-1629): STOP, START, '<unk>' -- index 0
+        when the dictionary has no '<unk>' item, exactly as Dictionary.get_idx_for_item answers there"""
+        td = self.tag_dictionary
+        return (td.get_idx_for_item(STOP_TAG), td.get_idx_for_item(START_TAG), td.get_idx_for_item("<unk>"))
+
+    def forward_backward_score(self, feats, lengths):
+        """TEACHER side of distill_posterior: `(forward_var + backward_var) * mask` of this model's CRF over feats f32[B,n,T] with
+        the START / STOP / <unk> columns lowered by 1e12 (finetune_trainer.py:1627-1634 calling _forward_alg(distill_mode=True),
+        :1329-1380, and _backward_alg, :1396-1470) -> f32[B,n,T] on the device"""
+        from kbner import ops
+        lens = torch.as_tensor(lengths).to(device=feats.device, dtype=torch.int32).contiguous()
+        return ops.crf_fb_score(feats.contiguous().float(), self.transitions, lens, self.start_idx, self.stop_idx, self._kd_suppress())
+
+    def pair_posterior(self, feats, lengths, temperature):
+        """TEACHER side of distill_exact (finetune_trainer.py:1705-1722,1885) -> (pair f32[B,n-1,T*T] softmax over (to, from),
+        start_score f32[B,T], end_score f32[B,T])"""
+        from kbner import ops
+        lens = torch.as_tensor(lengths).to(device=feats.device, dtype=torch.int32).contiguous()
+        return ops.crf_pair_posterior(feats.contiguous().float(), self.transitions, lens, float(temperature), self.start_idx,
+                                      self.stop_idx, self._kd_suppress())
+
+    def _kd_batch(self, sentences, hb):
+        """the batch's teacher targets (Sentence.set_teacher_*; finetune_trainer.py:1866-1886) padded to the batch's token count
+        and moved to the device -- what `resort` (:1911-2060) and the `get_teacher_*` stacks of simple_forward_distillation_loss
+        (:2128-2131,2253-2256,2283-2286) do in the reference -> the `kd` dict of kbner.engine.Tagger.kd_loss"""
+        B, T = len(sentences), self.tagset_size
+        n = hb["row_idx"].size // B
+        dev = flair.device
+        kd = {}
+
+        def teachers_of(attr):
+            k = {len(getattr(sn, attr)) for sn in sentences}
+            if len(k) != 1 or 0 in k:
+                raise ValueError("every sentence of a distill_mode batch needs the same, non-zero number of teacher entries in %s "
+                                 "(got %s): was ModelFinetuner.assign_pretrained_teacher_targets run on this data, and does "
+                                 "every training corpus have a teacher?" % (attr, sorted(k)))
+            return k.pop()
+
+        if self.distill_posterior:
+            nt = teachers_of("_teacher_posteriors")
+            sc = np.zeros((nt, B, n, T), np.float32)
+            for b, sn in enumerate(sentences):
+                for t, p in enumerate(sn._teacher_posteriors):
+                    L = min(len(sn), n)
+                    sc[t, b, :L] = p[:L]
+            kd["scores"] = [torch.from_numpy(sc[t]).to(dev) for t in range(nt)]
+        if self.distill_exact:
+            teachers_of("_teacher_posteriors")
+            pair = np.zeros((B, max(n - 1, 0), T * T), np.float32)
+            s_sc, e_sc = np.zeros((B, T), np.float32), np.zeros((B, T), np.float32)
+            for b, sn in enumerate(sentences):      # the loss reads teacher 0 only (`[:, :, 0]`, :2163-2166)
+                p = sn._teacher_posteriors[0]
+                L = min(len(p), max(n - 1, 0))
+                pair[b, :L] = p[:L]
+                s_sc[b], e_sc[b] = sn._teacher_startscores[0], sn._teacher_endscores[0]
+            kd["exact"] = (torch.from_numpy(pair).to(dev), torch.from_numpy(s_sc).to(dev), torch.from_numpy(e_sc).to(dev))
+        if self.distill_crf:
+            nt = teachers_of("_teacher_target")
+            tg = [sn.get_teacher_target() for sn in sentences]          # [len, best_k * teachers]
+            K = tg[0].shape[1]
+            targets = np.zeros((B, n, K), np.int32)
+            for b, t in enumerate(tg):
+                L = min(len(t), n)
+                targets[b, :L] = t[:L]
+            kd["targets"] = torch.from_numpy(targets).to(dev)
+            if self.crf_attention:
+                teachers_of("_teacher_weights")
+                att = np.stack([sn.get_teacher_weights() for sn in sentences], 0).astype(np.float32)      # [B, K]
+                att_nums = sum(len(sn._teacher_weights) for sn in sentences)
+                if self.distill_with_gold:
+                    # :2289-2304: paths that disagree with the gold tags on more tokens weigh less
+                    valid = np.arange(n)[None, :] < np.asarray([len(sn) for sn in sentences])[:, None]
+                    num_error = ((targets != hb["tags"][:, :, None]) & valid[:, :, None]).sum(1).astype(np.float32)   # [B, K]
+                    g = float(self.gold_const)
+                    score_w = np.exp(-num_error / g) if self.exp_score else g / (num_error + g)
+                    att = att * score_w
+                    att = att / att.sum(-1, keepdims=True) * (att_nums / float(B))
+                kd["weights"] = torch.from_numpy(np.ascontiguousarray(att, np.float32)).to(dev)
+                kd["att_nums"] = att_nums
+        return kd
+
+    def simple_forward_distillation_loss(self, data_points, teacher_data_points=None, teacher=None, sort=True, interpolation=0.5,
+                                         train_with_professor=False, professor_interpolation=0.5, language_attention_warmup=False,
+                                         calc_teachers_target_loss=False, language_weight=None, biaffine=None, language_vector=None):
+        """sequence_tagger_model.py:2110-2372 for a CRF student: interpolation * (posterior + crf + exact KD terms) +
+        (1 - interpolation) * gold NLL, as a 0-d device tensor (forward only; training goes through forward_backward(...,
+        distill_interpolation=...) since there is no autograd graph).  The sentences must carry teacher targets."""
+        if teacher is not None or train_with_professor or calc_teachers_target_loss or language_attention_warmup:
+            raise NotImplementedError("online teachers / professors / language attention are outside the hot path")
+        if isinstance(data_points, Sentence):
+            data_points = [data_points]
+        self.embeddings.embed(data_points)
+        hb, db = self._device_batch(data_points)
+        self._last = (hb, db)
+        self.mask = torch.from_numpy(hb["keep"].astype(np.float32)).to(flair.device)
+        loss = self.engine.kd_loss(db, self._kd_batch(data_points, hb), float(interpolation), float(self.temperature), backward=False)
+        self.last_loss_parts = self.engine.last_kd_parts
+        return loss
 
     def check_multi_view(self, sentences):
         """sequence_tagger_model.py:1928-1956: False unless some sentence of the batch carries an `orig_sent` and the batch's tags
@@ -724,6 +850,11 @@ class SequenceTagger(flair.nn.Model):
             "use_crf": True, "use_rnn": False, "remove_x": self.remove_x, "sentence_loss": self.sentence_level_loss,
             "word_dropout": self.use_word_dropout, "embedding_model_dir": getattr(self._emb, "name", None),
             "trained_epochs": self.trained_epochs,
+            # loss switches, so that a model re-loaded as a student (load_pretrained) keeps training the way it was configured
+            "temperature": self.temperature, "multi_view_training": self.multi_view_training,
+            "distill_posterior": self.distill_posterior, "distill_crf": self.distill_crf, "distill_exact": self.distill_exact,
+            "crf_attention": self.crf_attention, "distill_with_gold": self.distill_with_gold, "exp_score": self.exp_score,
+            "gold_const": self.gold_const,
         }
 
     @classmethod
@@ -733,7 +864,10 @@ class SequenceTagger(flair.nn.Model):
         model = cls(hidden_size=state["hidden_size"], embeddings=StackedEmbeddings([emb]), tag_dictionary=state["tag_dictionary"],
                     tag_type=state["tag_type"], use_crf=True, use_rnn=False, remove_x=state["remove_x"],
                     sentence_loss=state["sentence_loss"], word_dropout=state.get("word_dropout", 0.0), dropout=0.0,
-                    locked_dropout=0.0)
+                    locked_dropout=0.0, temperature=state.get("temperature", 1),
+                    **{k: state.get(k, False) for k in ("multi_view_training", "distill_posterior", "distill_crf", "distill_exact",
+                                                        "crf_attention", "distill_with_gold", "exp_score")},
+                    gold_const=state.get("gold_const", 1.0))
         model.engine.load_hf_state_dict(state["encoder_state_dict"])
         for k in ("linear.weight", "linear.bias", "transitions"):
             model.engine.set_param(k, state[k])

@@ -41,10 +41,23 @@ class ModelFinetuner:
                  sentence_level_batch: bool = False, clip_sentences: int = -1, remove_sentences: bool = False,
                  assign_doc_id: bool = False, train_with_doc: bool = False, pretrained_file_dict: dict = None,
                  sentence_level_pretrained_data: bool = False, assign_doc_for_ext_context: bool = False, **kwargs):
-        if distill_mode or ensemble_distill_mode or train_with_professor:
-            raise NotImplementedError("knowledge distillation is outside the hot path (all KB-NER configs set distill_mode: false)")
+        if ensemble_distill_mode or train_with_professor:
+            raise NotImplementedError("ensemble_distill_mode / train_with_professor are outside the hot path")
         _warn_unknown("ModelFinetuner", kwargs)
         self.model = model
+        # teacher-student knowledge distillation (finetune_trainer.py:223-237): the teachers only label the training set once,
+        # before the first epoch (assign_pretrained_teacher_targets), and are dropped after that
+        self.distill_mode = bool(distill_mode) and not is_test
+        if self.distill_mode:
+            if not teachers:
+                raise ValueError("distill_mode: true needs at least one teacher (ConfigParser.create_teachers / create_teachers_list)")
+            if not (getattr(model, "distill_crf", False) or getattr(model, "distill_exact", False) or
+                    (getattr(model, "distill_posterior", False) and not getattr(model, "multi_view_training", False))):
+                raise NotImplementedError("distill_mode with a CRF student needs one of the model switches distill_crf / "
+                                          "distill_posterior / distill_exact; emission-level KD "
+                                          "(assign_pretrained_teacher_predictions) belongs to softmax students, outside the hot path")
+            for teacher in teachers:
+                teacher.eval()
         self.optimizer_state = optimizer_state     # checkpoint resume (finetune_trainer.py:573,690)
         self.scheduler_state = scheduler_state
         self.corpus = corpus
@@ -133,6 +146,77 @@ class ModelFinetuner:
             base += len(bt)
         return wts, ((idx, kw) if idx else None)
 
+    # ------------------------------------------------------------------ teacher-student knowledge distillation
+    @property
+    def interpolation(self):               # finetune_trainer.py:1350-1355
+        return (self.config or {}).get("interpolation", 0.5)
+
+    @property
+    def teacher_annealing(self):           # :1356-1361
+        return bool((self.config or {}).get("teacher_annealing", False))
+
+    @property
+    def anneal_factor(self):               # :1362-1367
+        return (self.config or {}).get("anneal_factor", 2)
+
+    def assign_pretrained_teacher_targets(self, coupled_train_data, teachers, best_k=10, mini_batch_size=32):
+        """finetune_trainer.py:1515-1910: run every teacher over the training sets it teaches (`teacher.targets`) and store, per
+        sentence and teacher,
+          distill_crf        the best_k tag sequences of the n-best Viterbi decoder (+ with crf_attention the softmax of their
+                             scores)                                                                   (:1600, :1871-1874)
+          distill_posterior  forward_var + backward_var of the TEACHER's CRF over its emissions with the START / STOP / <unk>
+                             logits lowered by 1e12                                                    (:1627-1634, :1878)
+          distill_exact      the tempered pairwise posteriors + start / end scores                     (:1705-1722, :1878-1885)
+        All of it is computed on the device (teacher.forward = the HIP encoder + head; kbner_crf_viterbi_nbest /
+        kbner_crf_fb_score / kbner_crf_pair_posterior) and kept on the host, trimmed to the sentence.  Every data-parallel rank
+        labels the whole training set: the batches a rank trains on change with every epoch's shuffle.
+        Returns the flat list of training sentences."""
+        import numpy as np
+        log.info("Distilling sentences as targets...")
+        if len(self.corpus.targets) != len(coupled_train_data):
+            raise ValueError("Coupled train data is not equal to target!")
+        m = self.model
+        counter = 0
+        for teacher in teachers:
+            if m.tag_dictionary.item2idx != teacher.tag_dictionary.item2idx:
+                raise ValueError("the tag_dictionaries of the teacher and student are not same")
+            teacher.eval()
+            for index, train_data in enumerate(coupled_train_data):
+                if self.corpus.targets[index] not in getattr(teacher, "targets", set(self.corpus.targets)):
+                    continue
+                loader = ColumnDataLoader(list(train_data), mini_batch_size, False, model=teacher,
+                                          sentence_level_batch=self.sentence_level_batch)
+                loader.assign_tags(teacher.tag_type, teacher.tag_dictionary)
+                for batch in loader:
+                    counter += len(batch)
+                    logits = teacher.forward(batch).contiguous()                       # f32 [B, n, T], device
+                    n = logits.shape[1]
+                    lens = torch.tensor([len(sn) for sn in batch], dtype=torch.int32, device=logits.device)
+                    mask = torch.arange(n, device=logits.device)[None, :] < lens[:, None]
+                    if m.distill_crf:
+                        path_score, decode_idx = teacher._viterbi_decode_nbest(logits, mask, best_k)
+                        decode = (decode_idx * mask[:, :, None]).cpu().numpy().astype(np.int32)
+                        path_score = path_score.cpu().numpy()
+                    if m.distill_posterior:
+                        fb_score = teacher.forward_backward_score(logits, lens).cpu().numpy()
+                    if m.distill_exact:
+                        pair, s_sc, e_sc = (x.cpu().numpy() for x in teacher.pair_posterior(logits, lens, m.temperature))
+                    for i, sentence in enumerate(batch):
+                        L = len(sentence)
+                        if m.distill_crf:
+                            if m.crf_attention:
+                                sentence.set_teacher_weights(path_score[i])
+                            sentence.set_teacher_target(decode[i, :L])
+                        if m.distill_posterior:
+                            sentence.set_teacher_posteriors(fb_score[i, :L].copy())
+                        if m.distill_exact:
+                            sentence.set_teacher_posteriors(pair[i, :max(L - 1, 0)].copy())
+                            sentence.set_teacher_startscores(s_sc[i].copy())
+                            sentence.set_teacher_endscores(e_sc[i].copy())
+                    store_embeddings(batch, "none")
+        log.info("Distilled %d sentences", counter)
+        return [sn for data in coupled_train_data for sn in data]
+
     # ------------------------------------------------------------------ training
     def train(self, base_path: Union[Path, str], learning_rate: float = 5e-5, mini_batch_size: int = 32,
               eval_mini_batch_size: int = None, max_epochs: int = 100, anneal_factor: float = 0.5, patience: int = 10,
@@ -185,6 +269,13 @@ class ModelFinetuner:
         if train_with_dev:
             train_sets = [ConcatDataset([t, d]) for t, d in zip(self.corpus.train_list, self.corpus.dev_list)]
         train_data = [s for ds in train_sets for s in ds]
+        if self.distill_mode:
+            # finetune_trainer.py:597-636: every training sentence gets its teacher targets, then the teachers are released
+            train_data = self.assign_pretrained_teacher_targets(train_sets, self.teachers, best_k=best_k,
+                                                                mini_batch_size=mini_batch_size)
+            self.teachers = []
+            if torch.cuda.is_available():
+                torch.cuda.empty_cache()
         loader = ColumnDataLoader(train_data, mini_batch_size, shuffle, use_bert=self.use_bert, tokenizer=self.bert_tokenizer,
                                   model=self.model, sentence_level_batch=self.sentence_level_batch, sort_data=sort_data)
         loader.assign_tags(self.model.tag_type, self.model.tag_dictionary)
@@ -254,6 +345,12 @@ class ModelFinetuner:
         if multi_view:
             log.info("multi-view training: (1 - %s) * NLL(context view) + %s * T^2 KL(posterior(context view) || posterior(sentence "
                      "alone)), T = %s", multi_view_rate, multi_view_rate, self.model.temperature)
+        if self.distill_mode:
+            multi_view = False
+            log.info("distill_mode: interpolation * KD(%s) + (1 - interpolation) * NLL, interpolation %s, T = %s",
+                     "+".join(k for k in ("distill_posterior", "distill_crf", "distill_exact") if getattr(self.model, k, False)),
+                     "annealed from 1 by %s%% per epoch" % self.anneal_factor if self.teacher_annealing else self.interpolation,
+                     self.model.temperature)
         dev_score_history, dev_loss_history, train_loss_history = [], [], []
         best_score, bad_epochs = 0.0, 0   # finetune_trainer.py: best_score starts at 0 and a TIE with it still saves (:1280-1289)
         log_every = log_interval or max(1, len(loader) // W // 10)
@@ -291,13 +388,20 @@ class ModelFinetuner:
                             touched += [sn.orig_sent for sn in touched if hasattr(sn, "orig_sent")]
                         reducer.begin(self.model.touched_word_ids(touched))
                     hook = reducer.bucket_ready if (reducer is not None and flush and overlap_allreduce) else None
+                    kd_ip = None
+                    if self.distill_mode:
+                        # finetune_trainer.py:882-889: fixed interpolation, or annealed per batch from 1 towards 0
+                        kd_ip = self.interpolation
+                        if self.teacher_annealing:
+                            kd_ip = max(0.0, 1.0 - ((epoch * len(mine) + local_no) / max(len(mine), 1) * self.anneal_factor) / 100.0)
+                    kdkw = {"distill_interpolation": kd_ip} if self.distill_mode else {}
                     if fuse:
                         group.append(batch)
                         if flush:
                             sents = [sn for bt in group for sn in bt]
                             wts, mv = self._group_weights(group, multi_view_rate if multi_view else None)
                             fused = self.model.forward_backward(sents, loss_scale=1.0, sentence_weights=wts, grad_ready=hook,
-                                                                multi_view=mv)
+                                                                multi_view=mv, **kdkw)
                             # log the mean of the group's micro-batch losses, once per micro-batch, like the unfused loop
                             losses += [fused] * len(group)
                             scaled += [fused / div] * len(group)
@@ -308,7 +412,7 @@ class ModelFinetuner:
                                                                   grad_ready=hook, multi_view=mv))
                         scaled.append(losses[-1] / div)
                     else:
-                        losses.append(self.model.forward_backward(batch, loss_scale=1.0 / div, grad_ready=hook))
+                        losses.append(self.model.forward_backward(batch, loss_scale=1.0 / div, grad_ready=hook, **kdkw))
                         scaled.append(losses[-1] / div)
                     store_embeddings(batch, embeddings_storage_mode)
                     if flush:

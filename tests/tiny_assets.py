@@ -144,6 +144,29 @@ def multiview_config(d, max_epochs=3, accum=2, mini_batch_size=2, temperature=4.
     return cfg
 
 
+def kd_config(d, max_epochs=2, accum=2, mini_batch_size=3, temperature=2.0, interpolation=0.5, best_k=3, n_train=18, n_dev=6,
+              n_test=4, posterior=True, crf=True, attention=True, exact=False):
+    """teacher-student knowledge distillation on the tiny corpus, the way the reference configures it: `ModelFinetuner:
+    {distill_mode: true}`, the KD switches on the student model, `interpolation` at the top level, `is_teacher_list: true` +
+    `ner.teachers: {<teacher yaml>: <corpora it teaches>}` (flair/config_parser.py:255-274).  -> (student config, teacher config);
+    the teacher's YAML is the plain e2e config under its own model_name (its best-model.pt is written by the caller)."""
+    d = str(d)
+    kw = dict(word_dropout=0.0, max_epochs=max_epochs, shuffle=False, accum=accum, mini_batch_size=mini_batch_size, n_train=n_train,
+              n_dev=n_dev, n_test=n_test, save_finetuned_embedding=False)
+    teacher = e2e_config(d, **kw)
+    teacher["model_name"] = "tiny_teacher"
+    cfg = e2e_config(d, **kw)
+    cfg["model_name"] = "tiny_kd_run"
+    cfg["ModelFinetuner"]["distill_mode"] = True
+    cfg["model"]["FastSequenceTagger"].update(distill_posterior=posterior, distill_crf=crf, crf_attention=attention,
+                                              distill_exact=exact, temperature=temperature)
+    cfg["interpolation"] = interpolation
+    cfg["is_teacher_list"] = True
+    cfg["ner"]["teachers"] = {os.path.join(d, "teacher.yaml"): "ColumnCorpus-TINY"}
+    cfg["train"]["best_k"] = best_k
+    return cfg, teacher
+
+
 def e2e_config(d, word_dropout=0.1, max_epochs=6, shuffle=None, n_train=32, n_dev=8, n_test=8, accum=2, mini_batch_size=4,
                save_finetuned_embedding=True):
     """The KB-NER-shaped YAML (as a dict) of the tiny end-to-end run under directory `d`: builds the model dir + corpus files

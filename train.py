@@ -70,7 +70,15 @@ def main():
         sys.exit("ReinforcementTrainer (ACE) YAMLs are supported for --test / --parse only: training the controller is out of scope")
     tcfg = dict(cp.config.get(trainer_name, {}))
     tcfg.setdefault("distill_mode", False)
-    trainer = getattr(flair.trainers, trainer_name)(student, None, corpus, config=cp.config, **tcfg, is_test=args.test or args.parse)
+    if tcfg["distill_mode"] and not inference and trainer_name == "ModelFinetuner":
+        # train.py:98-127 of the reference: `is_teacher_list: true` -> <target>.teachers, else one teacher per corpus
+        teachers = cp.create_teachers_list() if cp.config.get("is_teacher_list") else cp.create_teachers()
+        trainer = flair.trainers.ModelFinetuner(student, teachers, corpus, config=cp.config, professors=[], **tcfg)
+    else:
+        if inference:
+            tcfg["distill_mode"] = False     # no teachers are built for --test / --parse (train.py:122-123)
+        trainer = getattr(flair.trainers, trainer_name)(student, None, corpus, config=cp.config, **tcfg,
+                                                        is_test=args.test or args.parse)
     train_config = dict(cp.config["train"])
     base_path = cp.get_target_path
     if args.remove_x:                      # train.py:211-213
