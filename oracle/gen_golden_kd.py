@@ -87,6 +87,9 @@ def main():
         (3, 9, 1.0, 0.5, 1, 0, False, False, False, True, False),
         (4, 13, 3.0, 0.6, 1, 0, False, False, False, True, False),
         (2, 1, 2.0, 0.5, 1, 0, False, False, False, True, False),
+        # distill_with_gold (:2289-2304): path weights scaled by gold_const / (errors + gold_const), or exp(-errors / gold_const)
+        (4, 11, 1.0, 0.5, 2, 3, False, True, True, False, ("gold", 1.0)),
+        (3, 10, 1.0, 0.4, 1, 4, True, True, True, False, ("gold_exp", 2.0)),
     ]
     cases, ci = {}, 0
     for (B, n, tau, interp, nt, k, posterior, crf, att, exact, ctx) in SPECS:
@@ -95,6 +98,9 @@ def main():
         lens[0] = n
         tags = np.zeros((B, n), np.int64)
         sentinel = ctx == "sentinel" or not crf
+        with_gold, exp_score, gold_const = False, False, 1.0
+        if isinstance(ctx, tuple):
+            with_gold, exp_score, gold_const = True, ctx[0] == "gold_exp", ctx[1]
         ctx = ctx is True
         for b in range(B):
             nreal = int(lens[b]) if not ctx else max(1, int(lens[b]) // 2)
@@ -153,6 +159,7 @@ def main():
         student.transitions.grad = None
         student.temperature = tau
         student.distill_posterior, student.distill_crf, student.crf_attention, student.distill_exact = posterior, crf, att, exact
+        student.distill_with_gold, student.exp_score, student.gold_const = with_gold, exp_score, gold_const
         fs = torch.from_numpy(es).requires_grad_(True)
 
         def forward(data_points, _fs=fs, _mask=mask):
@@ -170,7 +177,8 @@ def main():
             nll = student._calculate_loss(torch.from_numpy(es), sents, mask)
         for key, v in (("es", es), ("lens", lens.astype(np.int64)), ("tags", tags), ("tau", np.float32(tau)),
                        ("interpolation", np.float32(interp)), ("n_teachers", np.int64(nt)), ("best_k", np.int64(k)),
-                       ("flags", np.asarray([posterior, crf, att, exact], np.int64)), ("sentinel", np.int64(sentinel)), ("loss", np.float32(loss.item())),
+                       ("flags", np.asarray([posterior, crf, att, exact], np.int64)), ("sentinel", np.int64(sentinel)),
+                       ("with_gold", np.asarray([with_gold, exp_score], np.int64)), ("gold_const", np.float32(gold_const)), ("loss", np.float32(loss.item())),
                        ("nll", np.float32(nll.item())), ("des", fs.grad.numpy().copy()),
                        ("dtrans", student.transitions.grad.numpy().copy())):
             cases["c%d_%s" % (ci, key)] = v

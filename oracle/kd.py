@@ -76,6 +76,17 @@ def crf_term(es, trans, lens, targets, start, stop, weights=None, att_nums=None)
     return tot
 
 
+def gold_reweighted(att, targets, tags, lens, gold_const, exp_score, att_nums):
+    """distill_with_gold (:2289-2304): att [B,K] * gold_const / (errors + gold_const) (or exp(-errors / gold_const)), errors =
+    tokens where the path disagrees with the gold tags; renormalised per sentence to att_nums / B"""
+    B, n, K = targets.shape
+    mask = lengths_mask(lens, n, torch.float32)
+    num_error = ((targets != torch.as_tensor(tags)[:, :, None]).float() * mask[:, :, None]).sum(1)
+    sw = torch.exp(-num_error / gold_const) if exp_score else gold_const / (num_error + gold_const)
+    att = att * sw.to(att.dtype)
+    return att / att.sum(-1, keepdim=True) * (att_nums / B)
+
+
 def exact_term(es, trans, lens, pair, s_sc, e_sc, tau, start, stop):
     """:2139-2244 + _calculate_xstruct_distillation_loss (:2400-2425): -(E_teacher[score / T] - logZ_T) * T^2 per sentence,
     negative values replaced by 0 (constant), sum / B"""

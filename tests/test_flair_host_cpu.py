@@ -364,3 +364,44 @@ def test_batch_spans_equals_get_spans_on_random_tag_sequences():
                 else:
                     ref = s.get_spans("t", **kw_ref)
                 assert [(x.tag, str(x), x.score) for x in got[b]] == [(x.tag, str(x), x.score) for x in ref], (trial, b, kw_fast)
+
+
+def test_kd_batch_assembly_reproduces_the_reference_loss():
+    """FastSequenceTagger._kd_batch -- per-sentence teacher targets (host arrays trimmed to the sentence) -> the padded batch
+    tensors of the KD loss: concatenation over teachers, path weights, distill_with_gold reweighting (gold_const / exp_score).
+    Checked end to end on the CPU: feeding its output to the fp32 oracle restatement (oracle/kd.py) must reproduce the loss the
+    REFERENCE computed for the same sentences (tests/golden/kd_loss.npz, simple_forward_distillation_loss under autograd)."""
+    import os
+    import torch
+    import tiny_assets
+    from flair.models import FastSequenceTagger
+    from oracle import kd as okd
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "kd_loss.npz"))
+    start, stop, x_idx = int(g["start"]), int(g["stop"]), int(g["x_idx"])
+    seen_gold = 0
+    for c in range(int(g["n_cases"])):
+        fake, sents, hb = tiny_assets.kd_golden_batch(g, c)
+        kd = FastSequenceTagger._kd_batch(fake, sents, hb)
+        B, n, T = g["c%d_es" % c].shape
+        kw = {}
+        if "scores" in kd:
+            assert len(kd["scores"]) == int(g["c%d_n_teachers" % c]) and tuple(kd["scores"][0].shape) == (B, n, T)
+            kw["scores_t"] = [x.cpu() for x in kd["scores"]]
+        if "targets" in kd:
+            assert tuple(kd["targets"].shape) == (B, n, int(g["c%d_best_k" % c]) * int(g["c%d_n_teachers" % c]))
+            kw["targets"] = kd["targets"].cpu().long()
+            if "weights" in kd:
+                kw["weights"], kw["att_nums"] = kd["weights"].cpu(), kd["att_nums"]
+                if fake.distill_with_gold:
+                    seen_gold += 1
+                    raw = torch.from_numpy(np.stack([s.get_teacher_weights() for s in sents], 0))
+                    want = okd.gold_reweighted(raw, kw["targets"], g["c%d_tags" % c], g["c%d_lens" % c], fake.gold_const, fake.exp_score,
+                                               kd["att_nums"])
+                    assert float((kw["weights"] - want).abs().max()) < 1e-6
+        if "exact" in kd:
+            kw["exact"] = tuple(x.cpu() for x in kd["exact"])
+        loss = okd.kd_loss(torch.from_numpy(g["c%d_es" % c]), torch.from_numpy(g["trans_s"]), g["c%d_lens" % c], g["c%d_tags" % c], start,
+                           stop, x_idx, float(g["c%d_tau" % c]), float(g["c%d_interpolation" % c]), **kw)
+        ref = float(g["c%d_loss" % c])
+        assert abs(float(loss) - ref) <= 3e-5 * max(1.0, abs(ref)), (c, float(loss), ref)
+    assert seen_gold == 2

@@ -591,12 +591,12 @@ def test_kd_teacher_targets_vs_reference_golden(golden_dir):
 
 
 def _kd_device_case(g, c):
-    """one golden case as (emissions, device batch, kd dict) for Tagger.kd_crf_terms"""
-    from kbner import batch as kb
+    """one golden case as (emissions, device batch, kd dict) for Tagger.kd_crf_terms; the kd dict is assembled by the product's
+    own host code (FastSequenceTagger._kd_batch) from sentences carrying the reference's teacher targets"""
+    import tiny_assets
+    from flair.models import FastSequenceTagger
     es, lens, tags = g["c%d_es" % c], g["c%d_lens" % c], g["c%d_tags" % c]
     B, n, T = es.shape
-    nt = int(g["c%d_n_teachers" % c])
-    posterior, crf, att, exact = [bool(x) for x in g["c%d_flags" % c]]
     x_idx = int(g["x_idx"])
     valid = np.arange(n)[None, :] < lens[:, None]
     keep = valid & (tags != x_idx)
@@ -610,16 +610,8 @@ def _kd_device_case(g, c):
         ctags[b, :len(k)] = tags[b, k]
     db = {"lengths": torch.from_numpy(lens.astype(np.int32)).cuda(), "cfeat_idx": torch.from_numpy(cfeat.reshape(-1)).cuda(),
           "ctags": torch.from_numpy(ctags).cuda(), "clens": torch.from_numpy(clens).cuda()}
-    kd = {}
-    if posterior:
-        kd["scores"] = [torch.from_numpy(g["c%d_t%d_fb_score" % (c, t)]).cuda() for t in range(nt)]
-    if crf:
-        kd["targets"] = torch.from_numpy(np.concatenate([g["c%d_t%d_decode" % (c, t)] for t in range(nt)], -1).astype(np.int32)).cuda()
-        if att:
-            kd["weights"] = torch.from_numpy(np.concatenate([g["c%d_t%d_path_score" % (c, t)] for t in range(nt)], -1)).cuda()
-            kd["att_nums"] = nt * B
-    if exact:
-        kd["exact"] = tuple(torch.from_numpy(g["c%d_t0_%s" % (c, nm)]).cuda().contiguous() for nm in ("pair", "start_score", "end_score"))
+    fake, sents, hb = tiny_assets.kd_golden_batch(g, c)
+    kd = FastSequenceTagger._kd_batch(fake, sents, hb)
     return torch.from_numpy(es).cuda(), db, kd
 
 

@@ -256,3 +256,38 @@ def build_bert_dir(path, hidden=128, layers=4, heads=2, inter=256, seed=0):
         sd[p + "output.LayerNorm.bias"] = w(hidden)
     save_file(sd, os.path.join(path, "model.safetensors"), metadata={"format": "pt"})
     return path
+
+
+def kd_golden_batch(g, c):
+    """one case of tests/golden/kd_loss.npz as the mirror sees it during distill_mode training: flair Sentences carrying the
+    teacher targets the way ModelFinetuner.assign_pretrained_teacher_targets stores them (host arrays trimmed to the sentence),
+    a stand-in for the tagger's switches, and the host batch keys FastSequenceTagger._kd_batch reads -> (fake tagger, sentences, hb)"""
+    import types
+    import numpy as np
+    from flair.data import Sentence
+    es, lens, tags = g["c%d_es" % c], g["c%d_lens" % c], g["c%d_tags" % c]
+    B, n, T = es.shape
+    nt = int(g["c%d_n_teachers" % c])
+    posterior, crf, att, exact = [bool(x) for x in g["c%d_flags" % c]]
+    with_gold, exp_score = [bool(x) for x in g["c%d_with_gold" % c]] if ("c%d_with_gold" % c) in g else (False, False)
+    sents = []
+    for b in range(B):
+        L = int(lens[b])
+        s = Sentence(" ".join("w%d" % i for i in range(L)))
+        for t in range(nt):
+            if crf:
+                s.set_teacher_target(g["c%d_t%d_decode" % (c, t)][b, :L])
+                if att:
+                    s.set_teacher_weights(g["c%d_t%d_path_score" % (c, t)][b])
+            if posterior:
+                s.set_teacher_posteriors(g["c%d_t%d_fb_score" % (c, t)][b, :L])
+            if exact:
+                s.set_teacher_posteriors(g["c%d_t%d_pair" % (c, t)][b, :max(L - 1, 0)])
+                s.set_teacher_startscores(g["c%d_t%d_start_score" % (c, t)][b])
+                s.set_teacher_endscores(g["c%d_t%d_end_score" % (c, t)][b])
+        sents.append(s)
+    fake = types.SimpleNamespace(tagset_size=T, distill_posterior=posterior, distill_crf=crf, crf_attention=att, distill_exact=exact,
+                                 distill_with_gold=with_gold, exp_score=exp_score,
+                                 gold_const=float(g["c%d_gold_const" % c]) if with_gold else 1.0)
+    hb = {"row_idx": np.zeros(B * n, np.int32), "tags": tags.astype(np.int32)}
+    return fake, sents, hb
