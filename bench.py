@@ -100,7 +100,7 @@ def main():
     ap.add_argument("--model", default="large", choices=["large", "base"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sentences", type=int, default=4)
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--blocking-allreduce", action="store_true", help="N>1: no overlap, everything exchanged after backward (A/B)")
     ap.add_argument("--compress-embedding-grad", action="store_true",
@@ -374,6 +374,24 @@ def main():
             cv["1x4_fused_by_trainer"] = {"value": round(4 / sec, 2), "ms_per_step": round(sec * 1e3, 3)}
             cv["live_rows"] = int(tg.arena.emb_flags.sum())
             extra["corpus_vocabulary_30k"] = cv
+        # BASELINE.md section 2 row 5 / SURVEY.md section 8d cfg 5 (ACE-style stack, inference): Viterbi alone and encoder + Viterbi at
+        # the four (B, n') points, the whole stack (3 XLM-R-large-sized encoders + 4 character LMs + BiLSTM + CRF) at B = 32, and
+        # FastSequenceTagger.evaluate end to end -- secondary lines, measured by tools/bench_stack.py / tools/train_throughput.py
+        try:
+            import importlib.util
+
+            def _tool(name):
+                spec = importlib.util.spec_from_file_location("kbner_tool_" + name, os.path.join(ROOT, "tools", name + ".py"))
+                mod = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(mod)
+                return mod
+            tg._acts.clear()          # the training step's activation buffers (B = 128) are not needed any more
+            torch.cuda.empty_cache()
+            extra["cfg5"] = _tool("bench_stack").measure(encoders=3, lms=4, reps=3)
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            extra["evaluate"] = _tool("train_throughput").evaluate_rate(sentences=512, batch=32, model="large")
+        except Exception as e:  # secondary measurements never cost the headline number
+            extra["cfg5_error"] = repr(e)
 
     if rank == 0:
         fl_sent = 3 * encoder_flops_per_sentence(cfg, S)

@@ -227,6 +227,12 @@ int kbner_attn_bwd(const kbner_bf16* qkv, const kbner_bf16* ctx, const kbner_bf1
 int kbner_lstm_step(const kbner_bf16* gx, int ld_gx, const int* gxi, const kbner_bf16* whh, const kbner_bf16* h_in,
                     kbner_bf16* h_out, float* c, kbner_bf16* out, int ldo, int out_dir_stride, const int* outi, int B, int Hp,
                     int ndir, void* stream);
+/* The whole recurrence in one call: `steps` time steps of `ndir` LSTMs in lockstep, one launch per step enqueued back to back
+ * (4 waves per workgroup split K and own every sequence of a batch chunk, so Whh is streamed once per step).  gxi / outi
+ * i32 [steps, ndir, B]; out_col i32 [ndir] (device): first column of direction d's h inside `out` -- character LMs whose column
+ * blocks are not equidistant run as ONE group; h bf16 [2, ndir, B, Hp] ping-pong (h[0] = h_0, result in h[steps & 1]). */
+int kbner_lstm_seq(const kbner_bf16* gx, int ld_gx, const int* gxi, const kbner_bf16* whh, kbner_bf16* h, float* c, kbner_bf16* out,
+                   int ldo, const int* out_col, const int* outi, int steps, int B, int Hp, int ndir, void* stream);
 
 /* ---------------- optimiser (transformers==3.0.0 AdamW + clip_grad_norm_, finetune_trainer.py:1010,1018) ------------- */
 int kbner_sqnorm_ws_floats(void);

@@ -256,6 +256,7 @@ class SequenceTagger(flair.nn.Model):
         head = self.stack_head
         X = head.new_input(B, n)
         sel = self.selection if (getattr(self, "embedding_selector", False) and self.selection is not None) else None
+        char_lms = []
         for slot, emb in enumerate(self._stack_embs):
             if sel is not None and float(sel[slot]) == 0.0:
                 continue   # features * 0 (:889): the block stays zero, the embedding is not even computed
@@ -280,10 +281,21 @@ class SequenceTagger(flair.nn.Model):
                 for j, li in enumerate(emb.layer_indexes):  # concatenated in the order `layers` lists them (:2843-2858)
                     ops.gather_rows_into(states[len(states) + li], db["row_idx"], X, col + j * Hh, Hh)
             elif isinstance(emb, FlairEmbeddings):
-                cids, rows = emb.char_batch(sentences, n)
-                emb.engine(flair.device).run(cids, rows, X, col)
+                char_lms.append((emb, col))     # run together below: one launch per character step for all LMs of a width
             else:
                 raise NotImplementedError("embedding class %s has no device producer" % type(emb).__name__)
+        if char_lms:
+            from kbner.stack import CharLMGroup
+            by_width = {}
+            for emb, col in char_lms:
+                by_width.setdefault(emb.engine(flair.device).Hp, []).append((emb, col))
+            for Hp, members in by_width.items():
+                key = tuple(id(e) for e, _ in members)
+                cache = self.__dict__.setdefault("_char_lm_groups", {})
+                if key not in cache:
+                    cache[key] = CharLMGroup([e.engine(flair.device) for e, _ in members])
+                batches = [e.char_batch(sentences, n) for e, _ in members]
+                cache[key].run([b[0] for b in batches], [b[1] for b in batches], X, [c for _, c in members])
         return X, lengths, B, n
 
     def train(self, mode: bool = True):

@@ -57,6 +57,7 @@ SIGNATURES = {
     "kbner_attn_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, U32, U32, P]),
     "kbner_attn_bwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, U32, U32, P, P]),
     "kbner_lstm_step": (c_int, [P, c_int, P, P, P, P, P, P, c_int, c_int, P, c_int, c_int, c_int, P]),
+    "kbner_lstm_seq": (c_int, [P, c_int, P, P, P, P, P, c_int, P, P, c_int, c_int, c_int, c_int, P]),
     "kbner_sqnorm_ws_floats": (c_int, []),
     "kbner_grad_sqnorm": (c_int, [P, c_size_t, P, P, c_int, P]),
     "kbner_mark_rows": (c_int, [P, c_int, P, c_int, P]),

@@ -28,12 +28,12 @@ def _round_up(x, m):
 
 class LSTMGroup:
     """`ndir` single-layer LSTMs of one hidden width run in lockstep (the two directions of the tagger's BiLSTM; one character
-    LM).  Holds Whh as bf16 [ndir, 4Hp, Hp] (hidden zero-padded to a multiple of 32: a padded unit has zero weights, so its c
+    LM).  Holds Whh as bf16 [ndir, 4Hp, Hp] (hidden zero-padded to a multiple of 64: a padded unit has zero weights, so its c
     and h stay exactly 0) and runs the recurrence given pre-activations and per-step row tables."""
 
     def __init__(self, w_hh_list, hidden, device):
         self.H = int(hidden)
-        self.Hp = _round_up(self.H, 32)
+        self.Hp = _round_up(self.H, 64)   # kbner_lstm_seq: a wave's k slice is 64 wide (whole 128-byte lines of Whh)
         self.ndir = len(w_hh_list)
         self.device = torch.device(device)
         whh = torch.zeros((self.ndir, 4 * self.Hp, self.Hp), dtype=F32)
@@ -52,9 +52,26 @@ class LSTMGroup:
             out[q * self.Hp:q * self.Hp + self.H] = t[q * self.H:(q + 1) * self.H]
         return out
 
-    def run(self, gx, gxi, outi, out, out_dir_stride, B, col=0):
+    def run(self, gx, gxi, outi, out, out_dir_stride, B, col=0, out_cols=None):
         """gx bf16 [rows, ndir*4Hp]; gxi / outi int32 [steps, ndir, B] (device); out bf16 [rows_out, ld]; col: first column of
-        direction 0's h inside `out`."""
+        direction 0's h inside `out`, direction d at col + d * out_dir_stride -- or out_cols: one first column per direction.
+        The whole recurrence is ONE call into the library (kbner_lstm_seq: one launch per time step, enqueued back to back)."""
+        steps = gxi.shape[0]
+        if out_cols is None:
+            out_cols = [col + d * out_dir_stride for d in range(self.ndir)]
+        if len(out_cols) != self.ndir or any(int(x) % 4 for x in out_cols):
+            raise L_.KbnerError("LSTM output column offsets: one per direction, each a multiple of 4")
+        h = torch.zeros((2, self.ndir, B, self.Hp), dtype=BF16, device=self.device)
+        c = torch.zeros((self.ndir, B, self.Hp), dtype=F32, device=self.device)
+        oc = torch.tensor([int(x) for x in out_cols], dtype=I32, device=self.device)
+        gxi, outi = gxi.contiguous(), outi.contiguous()
+        L_.call("kbner_lstm_seq", L_.ptr(gx), gx.shape[-1], L_.ptr(gxi), L_.ptr(self.whh), L_.ptr(h), L_.ptr(c), L_.ptr(out),
+                out.shape[-1], L_.ptr(oc), L_.ptr(outi), steps, B, self.Hp, self.ndir, L_.stream_ptr())
+        return h[steps & 1]
+
+    def run_stepwise(self, gx, gxi, outi, out, out_dir_stride, B, col=0):
+        """the same recurrence through the one-wave-per-tile step kernel, one library call per time step (kept as the A/B and
+        cross-check of kbner_lstm_seq)"""
         steps = gxi.shape[0]
         h = [torch.zeros((self.ndir, B, self.Hp), dtype=BF16, device=self.device) for _ in range(2)]
         c = torch.zeros((self.ndir, B, self.Hp), dtype=F32, device=self.device)
@@ -170,3 +187,35 @@ class CharLM:
         outi = torch.from_numpy(np.ascontiguousarray(out_rows, np.int32)[:, None, :]).to(self.device)
         with L_.stream_scope():
             self.grp.run(self.table, gxi, outi, X, 0, B, col=col)
+
+
+class CharLMGroup:
+    """All character LMs of one hidden width run as ONE recurrence (LSTMGroup with ndir = number of models): one launch per
+    character step for all of them instead of one per model -- the step of a 2048-unit LM is a 33.5 MB stream of Whh, and a
+    single model's launch cannot keep enough of it in flight.  Tables are stacked along the columns ([chars, ndir * 4Hp], the
+    shorter dictionaries zero-padded), every model keeps its own character ids (forward / backward LMs read the text in opposite
+    orders) and its own column block of X."""
+
+    def __init__(self, lms):
+        lms = list(lms)
+        if not lms or len({lm.Hp for lm in lms}) != 1:
+            raise ValueError("a CharLMGroup takes character LMs of one (padded) hidden width")
+        self.lms = lms
+        self.device = lms[0].device
+        self.H, self.Hp = lms[0].H, lms[0].Hp
+        self.grp = LSTMGroup.__new__(LSTMGroup)
+        self.grp.H, self.grp.Hp, self.grp.ndir, self.grp.device = self.H, self.Hp, len(lms), self.device
+        self.grp.whh = torch.cat([lm.grp.whh for lm in lms], 0).contiguous()
+        rows = max(lm.table.shape[0] for lm in lms)
+        table = torch.zeros((rows, len(lms) * 4 * self.Hp), dtype=BF16, device=self.device)
+        for d, lm in enumerate(lms):
+            table[:lm.table.shape[0], d * 4 * self.Hp:(d + 1) * 4 * self.Hp] = lm.table
+        self.table = table
+
+    def run(self, char_ids, out_rows, X, cols):
+        """char_ids / out_rows: one int [steps, B] array per model (same steps and B); cols: its first column in X"""
+        gxi = torch.from_numpy(np.ascontiguousarray(np.stack([np.asarray(c, np.int32) for c in char_ids], 1))).to(self.device)
+        outi = torch.from_numpy(np.ascontiguousarray(np.stack([np.asarray(r, np.int32) for r in out_rows], 1))).to(self.device)
+        B = gxi.shape[2]
+        with L_.stream_scope():
+            self.grp.run(self.table, gxi, outi, X, 0, B, out_cols=list(cols))

@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--vocab", type=int, default=250002)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--threads", type=int, default=os.cpu_count() or 8)
+    ap.add_argument("--no-port", action="store_true", help="skip the oracle-port leg")
     args = ap.parse_args()
     torch.set_num_threads(args.threads)
     flair = ref_import.load_reference()
@@ -135,8 +136,57 @@ def main():
            "train_step_s": [round(t, 2) for t in times], "warmup_step_s": round(warm, 2),
            "train_sentences_per_s": round(4 / (sum(times) / len(times)), 4),
            "evaluate_s_for_4_sentences": round(t_eval, 2), "evaluate_sentences_per_s": round(4 / t_eval, 4), "first_loss": l0}
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
     shutil.rmtree(work, ignore_errors=True)
+    if args.no_port:
+        return
+    # ---- the oracle PORT (oracle/train_step.py, what bench.py's cpu_baseline leg times on the GPU box) on the same workload, same
+    # process, same thread count: validates the port's timing against the true reference
+    del tagger, opt, emb, loader
+    import gc
+    gc.collect()
+    sys.path.insert(0, os.path.join(ROOT, "kb-ner_amd"))
+    from kbner import batch as kb
+    from oracle import encoder as oenc
+    from oracle import train_step as ots
+    T, start, stop, x_idx = 29, 27, 28, 9
+    ocfg = oenc.EncoderConfig(vocab_size=args.vocab, hidden_size=args.hidden, num_hidden_layers=args.layers,
+                              num_attention_heads=args.heads, intermediate_size=args.inter, max_position_embeddings=514)
+    params = oenc.init_params(ocfg, seed=kb.SEED)
+    g = torch.Generator().manual_seed(1)
+    params["linear.weight"] = torch.empty(T, ocfg.hidden_size).uniform_(-0.03, 0.03, generator=g)
+    params["linear.bias"] = torch.zeros(T)
+    tr = torch.randn(T, T, generator=g)
+    tr[start, :] = -1e12
+    tr[:, stop] = -1e12
+    params["transitions"] = tr
+    trainer = ots.OracleTrainer(params, ocfg, start, stop, x_idx, accum=2, t_total=1000)
+    del params
+    mbs = []
+    for i in range(2):
+        b = kb.synthetic_batch(2, 512, vocab=ocfg.vocab_size, T=T, x_idx=x_idx, start=start, stop=stop, n_real=16, seed=kb.SEED + i)
+        mbs.append(dict(input_ids=torch.from_numpy(b["input_ids"]), attention_mask=torch.from_numpy(b["attention_mask"]),
+                        first_idx=torch.from_numpy(b["first_idx"]), tags=torch.from_numpy(b["tags"].astype(np.int64)),
+                        lengths=torch.from_numpy(b["lengths"].astype(np.int64))))
+
+    def pstep():
+        for mb in mbs:
+            trainer.micro_batch(mb)
+        trainer.optimizer_step()
+
+    t0 = time.time()
+    pstep()
+    pwarm = time.time() - t0
+    ptimes = []
+    for _ in range(args.steps):
+        t0 = time.time()
+        pstep()
+        ptimes.append(time.time() - t0)
+    pout = {"what": "oracle PORT (oracle/train_step.py: fp32 torch restatement, no tokeniser / flair objects) on the same shape, same "
+                    "process and threads", "train_step_s": [round(t, 2) for t in ptimes], "warmup_step_s": round(pwarm, 2),
+            "train_sentences_per_s": round(4 / (sum(ptimes) / len(ptimes)), 4),
+            "port_over_reference": round((sum(times) / len(times)) / (sum(ptimes) / len(ptimes)), 3)}
+    print(json.dumps(pout), flush=True)
 
 
 if __name__ == "__main__":

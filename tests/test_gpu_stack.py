@@ -38,7 +38,49 @@ def assets(tmp_path_factory, g13):
     return d
 
 
-@pytest.mark.parametrize("B,n,D,H", [(3, 7, 40, 24), (5, 19, 96, 100), (33, 12, 64, 32), (4, 9, 128, 1000)])   # last: config 5's hidden_size 1000 -> 1024
+def test_char_lm_group_matches_single_models():
+    """kbner_lstm_seq with several character LMs as ONE group (stacked tables, per-model ids and output columns that are NOT
+    equidistant) == each model run alone through the one-wave step kernel (kbner_lstm_step), and the final states agree"""
+    from kbner import stack as K
+    rng = np.random.default_rng(7)
+    g = torch.Generator().manual_seed(5)
+    H, B, steps, n = 96, 21, 23, 4
+    lms = []
+    for i in range(3):
+        k = 1.0 / H ** 0.5
+        chars = 40 + 7 * i          # dictionaries of different sizes
+        sd = {"encoder.weight": torch.rand(chars, 20, generator=g) * 0.4 - 0.2,
+              "rnn.weight_ih_l0": (torch.rand(4 * H, 20, generator=g) * 2 - 1) * k,
+              "rnn.weight_hh_l0": (torch.rand(4 * H, H, generator=g) * 2 - 1) * k * 3,
+              "rnn.bias_ih_l0": torch.rand(4 * H, generator=g) * 0.2, "rnn.bias_hh_l0": torch.rand(4 * H, generator=g) * 0.2}
+        lms.append(K.CharLM(sd, H, "cuda"))
+    ids = [rng.integers(0, 40 + 7 * i, size=(steps, B)).astype(np.int32) for i in range(3)]
+    rows = []
+    for i in range(3):
+        r = np.full((steps, B), -1, np.int32)
+        for b in range(B):
+            for t, s in enumerate(sorted(rng.choice(np.arange(1, steps), size=n, replace=False))):
+                r[s, b] = b * n + t
+        rows.append(r)
+    cols = [0, 128, 352]            # not equidistant
+    ld = 512
+    X1 = torch.zeros((128, ld), dtype=torch.bfloat16, device="cuda")
+    X2 = torch.zeros((128, ld), dtype=torch.bfloat16, device="cuda")
+    K.CharLMGroup(lms).run(ids, rows, X1, cols)
+    for i, lm in enumerate(lms):
+        gxi = torch.from_numpy(ids[i][:, None, :].copy()).cuda()
+        outi = torch.from_numpy(rows[i][:, None, :].copy()).cuda()
+        lm.grp.run_stepwise(lm.table, gxi, outi, X2, 0, B, col=cols[i])
+    torch.cuda.synchronize()
+    a, b = X1.float().cpu().numpy(), X2.float().cpu().numpy()
+    assert np.abs(b).max() > 0.05
+    # same bf16 inputs, fp32 accumulation in a different order (4 K-slices summed through LDS): a few bf16 ulps after 23 steps
+    assert np.abs(a - b).max() <= 2e-2 * np.abs(b).max(), np.abs(a - b).max()
+    assert (np.abs(a) > 0).sum() == (np.abs(b) > 0).sum() == 3 * B * n * H
+
+
+@pytest.mark.parametrize("B,n,D,H", [(3, 7, 40, 24), (5, 19, 96, 100), (33, 12, 64, 32), (4, 9, 128, 1000),   # config 5's hidden_size 1000 -> 1024
+                                     (20, 6, 64, 96), (50, 5, 64, 64), (70, 4, 64, 32)])   # 2 / 4 sequence tiles per workgroup, two batch chunks
 def test_bilstm_head_vs_oracle(B, n, D, H):
     """input GEMM + per-step recurrence kernel (both directions, ragged lengths, hidden padded to 32) + linear vs the numpy LSTM"""
     from kbner import stack as K

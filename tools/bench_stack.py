@@ -32,13 +32,11 @@ def timed(fn, reps):
     return e0.elapsed_time(e1) / reps * 1e-3
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--encoders", type=int, default=3)
-    ap.add_argument("--lms", type=int, default=4)
-    ap.add_argument("--reps", type=int, default=3)
-    ap.add_argument("--lm-hidden", type=int, default=2048)
-    a = ap.parse_args()
+def measure(encoders=3, lms=4, reps=3, lm_hidden=2048):
+    """-> list of result dicts (the four encoder+Viterbi points, then the whole stack)"""
+    import types
+    a = types.SimpleNamespace(encoders=encoders, lms=lms, reps=reps, lm_hidden=lm_hidden)
+    results = []
     dev = "cuda"
     T, start, stop = 29, 27, 28
     cfg = engine.EncoderConfig.large(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
@@ -66,9 +64,9 @@ def main():
         dt = timed(enc_vit, a.reps)
         em = torch.randn(B, nn, T, device=dev)
         tv = timed(lambda: ops.crf_viterbi(em, trans, lens, start, stop), 20)
-        print(json.dumps({"metric": "cfg5 encoder fwd (XLM-R-large, 512 sub-tokens) + linear + Viterbi", "B": B, "n": nn,
-                          "sentences_per_s": round(B / dt, 1), "ms": round(dt * 1e3, 3), "viterbi_alone_us": round(tv * 1e6, 1),
-                          "viterbi_alone_sentences_per_s": round(B / tv)}), flush=True)
+        results.append({"metric": "cfg5 encoder fwd (XLM-R-large, 512 sub-tokens) + linear + Viterbi", "B": B, "n": nn,
+                        "sentences_per_s": round(B / dt, 1), "ms": round(dt * 1e3, 3), "viterbi_alone_us": round(tv * 1e6, 1),
+                        "viterbi_alone_sentences_per_s": round(B / tv)})
     # ---- the whole stack at B = 32, n' = 20 real tokens (sentences chunked at <EOS>), ~6 characters per token
     B, n_ = 32, 20
     H_lm, H_rnn = a.lm_hidden, 1000
@@ -113,7 +111,13 @@ def main():
             hid = e.encoder_forward(b["ids"], b["pos_ids"], b["maskbias"], B, 512)
             ops.gather_rows_into(hid, idx, X, head.cols[i], cfg.hidden_size)
 
+    lm_group = stack.CharLMGroup(lms) if lms else None
+
     def run_lms():
+        if lm_group is not None:
+            lm_group.run([char_ids] * len(lms), [out_rows] * len(lms), X, [head.cols[a.encoders + i] for i in range(len(lms))])
+
+    def run_lms_one_by_one():
         for i, lm in enumerate(lms):
             lm.run(char_ids, out_rows, X, head.cols[a.encoders + i])
 
@@ -128,13 +132,28 @@ def main():
 
     stage("encoders", run_encoders)
     stage("char_lms", run_lms)
+    stage("char_lms_one_launch_per_model_and_step", run_lms_one_by_one)
     stage("bilstm_linear_viterbi", run_head)
     stage("whole", whole)
-    print(json.dumps({"metric": "cfg5 whole stack: %d XLM-R-large encoders + %d char LMs (hidden %d, %d chars) + BiLSTM 1000 + CRF"
-                                % (a.encoders, a.lms, H_lm, steps), "B": B, "n": n_, "sentences_per_s": round(B / times["whole"], 1),
-                      "ms": {k_: round(v * 1e3, 3) for k_, v in times.items()},
-                      "lstm_step_us": {"char_lm": round(times["char_lms"] / max(a.lms, 1) / steps * 1e6, 2),
-                                       "bilstm": round(times["bilstm_linear_viterbi"] / n_ * 1e6, 2)}}), flush=True)
+    results.append({"metric": "cfg5 whole stack: %d XLM-R-large encoders + %d char LMs (hidden %d, %d chars) + BiLSTM 1000 + CRF"
+                              % (a.encoders, a.lms, H_lm, steps), "B": B, "n": n_, "sentences_per_s": round(B / times["whole"], 1),
+                    "ms": {k_: round(v * 1e3, 3) for k_, v in times.items()},
+                    "lstm_step_us": {"char_lm": round(times["char_lms"] / max(a.lms, 1) / steps * 1e6, 2),
+                                     "bilstm": round(times["bilstm_linear_viterbi"] / n_ * 1e6, 2)}})
+    del encs, head, lms, lm_group
+    torch.cuda.empty_cache()
+    return results
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--encoders", type=int, default=3)
+    ap.add_argument("--lms", type=int, default=4)
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--lm-hidden", type=int, default=2048)
+    a = ap.parse_args()
+    for r in measure(a.encoders, a.lms, a.reps, a.lm_hidden):
+        print(json.dumps(r), flush=True)
 
 
 if __name__ == "__main__":

@@ -15,22 +15,17 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--sentences", type=int, default=512)
-    ap.add_argument("--batch", type=int, default=32)
-    ap.add_argument("--accum", type=int, default=4)
-    ap.add_argument("--model", default="large", choices=["large", "base"])
-    a = ap.parse_args()
+def setup(sentences=512, model="large"):
+    """synthetic KB-NER-style corpus (12 labelled tokens + <EOS> + ~100 context tokens, ~500 sub-tokens) + a random XLM-R-sized
+    encoder directory + the drop-in objects a YAML would build -> (tagger, trainer, ColumnCorpus, tag dictionary, work dir)"""
     import tiny_assets
-    import torch
-    from flair.data import Dictionary
+    import torch  # noqa: F401
     from flair.datasets import ColumnCorpus
     from flair.embeddings import TransformerWordEmbeddings
     from flair.models import FastSequenceTagger
     from flair.trainers import ModelFinetuner
     d = tempfile.mkdtemp(prefix="kbner_tp_")
-    dims = dict(hidden=1024, layers=24, heads=16, inter=4096) if a.model == "large" else dict(hidden=768, layers=12, heads=12, inter=3072)
+    dims = dict(hidden=1024, layers=24, heads=16, inter=4096) if model == "large" else dict(hidden=768, layers=12, heads=12, inter=3072)
     tiny_assets.build_model_dir(os.path.join(d, "enc"), **dims)
     rng = np.random.default_rng(0)
     folder = os.path.join(d, "data")
@@ -43,7 +38,7 @@ def main():
         lines += ["%s B-X B-X B-X" % w for w in rng.choice(tiny_assets.WORDS, size=int(rng.integers(96, 104)))]
         return "\n".join(lines) + "\n\n"
 
-    for name, k in (("train.txt", a.sentences), ("dev.txt", 32), ("test.txt", 32)):
+    for name, k in (("train.txt", sentences), ("dev.txt", 32), ("test.txt", 32)):
         with open(os.path.join(folder, name), "w") as f:
             for i in range(k):
                 f.write(sentence(i))
@@ -53,12 +48,49 @@ def main():
     corpus = ListCorpus(train=[cc.train], dev=[cc.dev], test=[cc.test], targets=["ColumnCorpus-SYN"])
     emb = TransformerWordEmbeddings(model=os.path.join(d, "enc"), layers="-1", pooling_operation="first", fine_tune=True)
     toks = [emb.tokenize_sentence(s) for s in list(cc.train)[:64]]
-    lens = [len(t[0][0]) for t in toks]
     assert max(len(t[0]) for t in toks) == 1, "synthetic sentences must fit one window for this measurement"
     from flair.embeddings import StackedEmbeddings
     tagger = FastSequenceTagger(hidden_size=256, embeddings=StackedEmbeddings([emb]), tag_dictionary=td, tag_type="ner", use_crf=True, use_rnn=False,
                                 remove_x=True, sentence_loss=True, word_dropout=0.1, dropout=0.0, locked_dropout=0.0)
     trainer = ModelFinetuner(tagger, None, corpus, config={}, distill_mode=False, sentence_level_batch=True)
+    sub = [len(t[0][0]) for t in toks]
+    return tagger, trainer, cc, td, d, sub
+
+
+def evaluate_rate(sentences=512, batch=32, model="large"):
+    """FastSequenceTagger.evaluate (tokenise -> batch -> encoder forward -> emissions of every word token -> CRF loss -> Viterbi ->
+    labels -> span metric) in sentences/s on the synthetic corpus, second pass (the first warms the tokenizer cache and buffers)"""
+    import shutil
+    import torch
+    from flair.custom_data_loader import ColumnDataLoader
+    tagger, _, cc, td, d, sub = setup(sentences, model)
+    dl = ColumnDataLoader(list(cc.train), batch, sentence_level_batch=True)
+    dl.assign_tags("ner", td)
+    tagger.eval()
+    tagger.evaluate(dl)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tagger.evaluate(dl)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    shutil.rmtree(d, ignore_errors=True)
+    return {"value": round(sentences / dt, 1), "unit": "sentences/sec", "sentences": sentences, "batch": batch,
+            "sub_tokens_per_sentence": round(float(np.mean(sub)), 1),
+            "what": "FastSequenceTagger.evaluate end to end (host tokenisation + batching + XLM-R-%s-sized encoder forward + emissions "
+                    "+ CRF NLL + Viterbi + labels + span metric), second pass over the corpus" % model}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--sentences", type=int, default=512)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--accum", type=int, default=4)
+    ap.add_argument("--model", default="large", choices=["large", "base"])
+    a = ap.parse_args()
+    import torch
+    from flair.embeddings import StackedEmbeddings, TransformerWordEmbeddings
+    from flair.models import FastSequenceTagger
+    tagger, trainer, cc, td, d, lens = setup(a.sentences, a.model)
     out = {}
     if os.environ.get("KBNER_PROFILE"):
         import cProfile
