@@ -117,6 +117,11 @@ int kbner_scatter_rows_f32(const float* rows, const int* idx, float* dst, int R,
 /* fp32 row scatter-ADD, any W: dst[idx[r],:] += rows[r,:] (idx[r] < 0 skipped, indices unique) -- backward of the remove_x
  * compaction (sequence_tagger_model.py:2474-2488) when the KD terms need the gradient on the all-token emissions */
 int kbner_scatter_add_rows_f32(const float* rows, const int* idx, float* dst, int R, int W, void* stream);
+/* calculate_l2_loss of multi-view training (sequence_tagger_model.py:1988-1996,2026-2035), forward + backward:
+ * loss[0] += sum_r w[r] sum_h (a[r,h] - b[r,h])^2 and (da != NULL) da[r,:] += 2 * gscale * w[r] * (a[r,:] - b[r,:]);
+ * a, b, da bf16 [R,H] (H even), w f32 [R] (0 = skip the row); b is the constant (detached) view */
+int kbner_l2_rows(const kbner_bf16* a, const kbner_bf16* b, const float* w, float gscale, kbner_bf16* da, float* loss, int R, int H,
+                  void* stream);
 /* its backward (unique indices; caller zero-fills dsrc) */
 int kbner_scatter_rows(const kbner_bf16* dout, const int* idx, kbner_bf16* dsrc, int R, int H, void* stream);
 /* self.linear, sequence_tagger_model.py:1027: out f32[R,T] = x bf16[R,H] . w f32[T,H]^T + bias */

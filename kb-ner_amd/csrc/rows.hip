@@ -396,6 +396,48 @@ extern "C" int kbner_scatter_add_rows_f32(const float* rows, const int* idx, flo
   KBNER_LAUNCH_RET();
 }
 
+// Multi-view training's representation term (FastSequenceTagger._calculate_multi_view_loss with calculate_l2_loss,
+// sequence_tagger_model.py:1988-1996,2026-2035): mse_loss(orig view's token representations, the context view's (detached)) at the
+// sentence's real tokens, forward and backward in one pass over the rows:
+//     loss += sum_r w[r] * sum_h (a[r,h] - b[r,h])^2 ;   da[r,:] += 2 * gscale * w[r] * (a[r,:] - b[r,:])
+// (w[r] = sentence weight / H, 0 for padding rows; da is the bf16 gradient of the pooled rows the head's backward just wrote).
+// One wavefront per row.
+__global__ __launch_bounds__(256) void l2_rows_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b,
+                                                      const float* __restrict__ w, float gscale, bf16_t* __restrict__ da,
+                                                      float* __restrict__ loss, int R, int H) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (r >= R) return;
+  const float wr = w[r];
+  if (wr == 0.0f) return;
+  const bf16_t* ar = a + (size_t)r * H;
+  const bf16_t* br = b + (size_t)r * H;
+  bf16_t* dr = da + (size_t)r * H;
+  float acc = 0.0f;
+  for (int h = lane * 2; h < H; h += 128) {
+    const f2v x = unpack2bf(*reinterpret_cast<const uint32_t*>(ar + h));
+    const f2v y = unpack2bf(*reinterpret_cast<const uint32_t*>(br + h));
+    const float d0 = x[0] - y[0], d1 = x[1] - y[1];
+    acc += d0 * d0 + d1 * d1;
+    if (da != nullptr) {
+      const f2v g = unpack2bf(*reinterpret_cast<const uint32_t*>(dr + h));
+      *reinterpret_cast<uint32_t*>(dr + h) = pack2bf(g[0] + 2.0f * gscale * wr * d0, g[1] + 2.0f * gscale * wr * d1);
+    }
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) atomicAdd(loss, wr * acc);
+}
+
+extern "C" int kbner_l2_rows(const bf16_t* a, const bf16_t* b, const float* w, float gscale, bf16_t* da, float* loss, int R, int H,
+                             void* stream) {
+  KBNER_CHECK_ARG(R >= 0 && H > 0 && H % 2 == 0);
+  if (R == 0) return 0;
+  KBNER_CHECK_ARG(a != nullptr && b != nullptr && w != nullptr && loss != nullptr);
+  hipLaunchKernelGGL(l2_rows_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a, b, w, gscale, da, loss, R,
+                     H);
+  KBNER_LAUNCH_RET();
+}
+
 // Materialise a dropout site's multiplier (tests / debugging only: the product kernels regenerate it in registers):
 // out[z,i,j] = drop_keep(rowkey(seed, z*M+i), colkey(seed, z*N+j)) ? 1/(1-p) : 0.  Hidden-state sites: Z=1, [M tokens, H];
 // attention-probability sites: Z = B*A heads, M = N = S.

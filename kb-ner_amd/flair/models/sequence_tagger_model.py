@@ -34,7 +34,7 @@ _UNSUPPORTED_TRUE = ("use_mfvi", "use_cnn", "biaf_attention", "use_language_atte
                      "distill_emission", "posterior_constraint", "use_language_vector", "enhanced_crf",
                      "use_language_id", "use_transition_attention", "unlabel_entropy_loss", "relearn_embeddings", "map_embeddings",
                      "no_encoder", "new_drop", "use_embedding_masks", "use_gumbel", "embedding_attention",
-                     "calculate_l2_loss", "l2_loss_only", "train_initial_hidden_state")
+                     "train_initial_hidden_state")
 
 
 class SequenceTagger(flair.nn.Model):
@@ -68,18 +68,23 @@ class SequenceTagger(flair.nn.Model):
         if use_rnn and rnn_layers != 1:
             raise NotImplementedError("rnn_layers > 1 is not implemented (the KB-NER / ACE configs use the default of 1)")
         # multi-view ("cooperative learning") training: the shipped *_multiview_posterior_* YAMLs set multi_view_training +
-        # distill_posterior + temperature; the other branches of _calculate_multi_view_loss (distill_exact, L2) stay out of scope,
-        # and distill_posterior WITHOUT multi_view_training only matters to the distillation trainers (out of scope)
-        if multi_view_training and not (distill_posterior and remove_x and not use_rnn):
-            raise NotImplementedError("multi_view_training is implemented for the posterior-distillation form of the shipped "
-                                      "configs: distill_posterior: true, remove_x: true, use_rnn: false")
+        # distill_posterior + temperature; the distill_exact branch and the calculate_l2_loss / l2_loss_only terms of
+        # _calculate_multi_view_loss are implemented too (the unlabeled-data branch is not: use_unlabeled_data is refused)
+        if multi_view_training and not ((distill_posterior or distill_exact or l2_loss_only) and remove_x and not use_rnn):
+            # (with use_crf and none of them the reference's _calculate_multi_view_loss leaves `loss` unbound, :2048-2103)
+            raise NotImplementedError("multi_view_training needs distill_posterior (the shipped configs), distill_exact or "
+                                      "l2_loss_only, with remove_x: true, use_rnn: false")
+        if l2_loss_only and not calculate_l2_loss:
+            raise ValueError("l2_loss_only returns the calculate_l2_loss term (sequence_tagger_model.py:2038): enable calculate_l2_loss")
+        if (calculate_l2_loss or l2_loss_only) and not multi_view_training:
+            raise ValueError("calculate_l2_loss is a term of the multi-view loss: enable multi_view_training")
         # teacher-student knowledge distillation (`distill_mode: true` of ModelFinetuner; simple_forward_distillation_loss below):
         # distill_posterior (without multi_view_training), distill_crf (+ crf_attention, distill_with_gold, exp_score), distill_exact
-        kd_student = (distill_posterior and not multi_view_training) or distill_crf or distill_exact
+        kd_student = ((distill_posterior or distill_exact) and not multi_view_training) or distill_crf
         if kd_student and use_rnn:
             raise NotImplementedError("knowledge distillation is implemented for the fine-tuning student (use_rnn: false)")
-        if distill_exact and distill_posterior:
-            # both read / write the sentences' `_teacher_posteriors` (finetune_trainer.py:1880-1886, sequence_tagger_model.py
+        if distill_exact and distill_posterior and not multi_view_training:
+            # (multi-view training takes the distill_exact branch when both are set, :2049,2088)   both read / write the sentences' `_teacher_posteriors` (finetune_trainer.py:1880-1886, sequence_tagger_model.py
             # :2128,2163): in the reference the combination fails on the tensor shapes
             raise ValueError("distill_exact and distill_posterior share the teacher-posterior storage: enable one of them")
         if distill_exact and distill_crf:
@@ -118,7 +123,7 @@ class SequenceTagger(flair.nn.Model):
         self.distill_crf, self.distill_exact = bool(distill_crf), bool(distill_exact)
         self.distill_posterior = bool(distill_posterior)
         self.multi_view_training = bool(multi_view_training)
-        self.calculate_l2_loss = self.l2_loss_only = False
+        self.calculate_l2_loss, self.l2_loss_only = bool(calculate_l2_loss), bool(l2_loss_only)
         self.crf_attention, self.distill_with_gold, self.exp_score = bool(crf_attention), bool(distill_with_gold), bool(exp_score)
         self.gold_const = gold_const
         self.selection = None
@@ -426,6 +431,7 @@ class SequenceTagger(flair.nn.Model):
         idx, kw = multi_view
         loss = self.engine.forward_loss(db, loss_scale=loss_scale, backward=True, weights=sentence_weights, grad_ready=None)
         teacher = self.engine.last_emissions.index_select(0, torch.as_tensor(list(idx), dtype=torch.long, device=flair.device))
+        t_pooled = self.engine.last_pooled      # the context view's token representations (calculate_l2_loss); a constant
         t_lens = hb["clens"][list(idx)]
         orig = [data_points[i].orig_sent for i in idx]
         self.embeddings.embed(orig)
@@ -435,8 +441,11 @@ class SequenceTagger(flair.nn.Model):
             # part and the plain file's sentence must be the same tokens
             raise ValueError("multi-view pair mismatch: real-token counts %s (context view) vs %s (orig_sent)" %
                              (t_lens.tolist(), ohb["clens"].tolist()))
+        sel = torch.as_tensor(list(idx), dtype=torch.long, device=flair.device)
         kd = self.engine.distill_loss(odb, teacher, float(self.temperature), loss_scale=loss_scale, backward=True,
-                                      weights=kw, grad_ready=grad_ready)
+                                      weights=kw, grad_ready=grad_ready, mode="exact" if self.distill_exact else "posterior",
+                                      teacher_pooled=t_pooled.index_select(0, sel) if self.calculate_l2_loss else None,
+                                      l2_only=self.l2_loss_only)
         store_embeddings(orig, "none")
         self.last_loss_parts = (loss, kd)   # (weighted NLL of the context view, weighted distillation term): 0-d device tensors
         return loss + kd
@@ -866,7 +875,7 @@ class SequenceTagger(flair.nn.Model):
             "temperature": self.temperature, "multi_view_training": self.multi_view_training,
             "distill_posterior": self.distill_posterior, "distill_crf": self.distill_crf, "distill_exact": self.distill_exact,
             "crf_attention": self.crf_attention, "distill_with_gold": self.distill_with_gold, "exp_score": self.exp_score,
-            "gold_const": self.gold_const,
+            "gold_const": self.gold_const, "calculate_l2_loss": self.calculate_l2_loss, "l2_loss_only": self.l2_loss_only,
         }
 
     @classmethod
@@ -878,7 +887,7 @@ class SequenceTagger(flair.nn.Model):
                     sentence_loss=state["sentence_loss"], word_dropout=state.get("word_dropout", 0.0), dropout=0.0,
                     locked_dropout=0.0, temperature=state.get("temperature", 1),
                     **{k: state.get(k, False) for k in ("multi_view_training", "distill_posterior", "distill_crf", "distill_exact",
-                                                        "crf_attention", "distill_with_gold", "exp_score")},
+                                                        "crf_attention", "distill_with_gold", "exp_score", "calculate_l2_loss", "l2_loss_only")},
                     gold_const=state.get("gold_const", 1.0))
         model.engine.load_hf_state_dict(state["encoder_state_dict"])
         for k in ("linear.weight", "linear.bias", "transitions"):

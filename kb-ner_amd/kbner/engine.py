@@ -528,15 +528,23 @@ class Tagger:
         em, pooled = self.emissions(hidden, crow_idx, B, nc)
         return em, pooled, crow_idx, B, nc, R, S
 
-    def _backprop_emissions(self, demit, pooled, crow_idx, B, nc, R, S, grad_ready):
-        """d loss / d emissions f32[B,nc,T] -> head, scatter to the encoder rows, encoder backward (all into arena.g)"""
+    def _backprop_emissions(self, demit, pooled, crow_idx, B, nc, R, S, grad_ready, l2=None, l2_scale=1.0):
+        """d loss / d emissions f32[B,nc,T] -> head, scatter to the encoder rows, encoder backward (all into arena.g).
+        l2 = (other view's pooled rows bf16[B*nc,H], row weights f32[B*nc]): the representation term of multi-view training is
+        added to the pooled-row gradient here; its value is returned (0-d tensor), else None."""
         a = self.arena
         dpooled = ops.head_bwd(demit.view(B * nc, self.T), pooled, a.param("linear.weight"), a.grad("linear.weight"),
                                a.grad("linear.bias"))
+        l2_val = None
+        if l2 is not None:
+            part = torch.zeros((1,), dtype=F32, device=self.device)
+            ops.l2_rows(pooled, l2[0], l2[1], part, da=dpooled, gscale=float(l2_scale))
+            l2_val = part[0]
         ac = self.acts(R, S)
         ac.dx.zero_()
         ops.scatter_rows(dpooled, crow_idx, ac.dx)
         self.encoder_backward(ac.dx, grad_ready)
+        return l2_val
 
     def _sentence_weights(self, weights, B):
         if weights is None:
@@ -549,6 +557,7 @@ class Tagger:
     def _forward_loss(self, batch, loss_scale, backward, weights, grad_ready=None):
         em, pooled, crow_idx, B, nc, R, S = self._emit(batch)
         self.last_emissions = em   # f32 [B, nc, T] at the kept (non-S-X) tokens: the teacher view of multi-view training
+        self.last_pooled = pooled.view(B, nc, -1)   # bf16 [B, nc, H]: the same view's token representations (calculate_l2_loss)
         a = self.arena
         trans = a.param("transitions")
         logz, gold, alpha = ops.crf_nll_fwd(em, trans, batch["ctags"], batch["clens"], self.start, self.stop)
@@ -562,15 +571,40 @@ class Tagger:
             self._backprop_emissions(demit, pooled, crow_idx, B, nc, R, S, grad_ready)
         return loss[0]
 
-    def distill_loss(self, batch, teacher_emissions, tau, loss_scale=1.0, backward=True, weights=None, grad_ready=None):
-        """Multi-view posterior distillation (FastSequenceTagger._calculate_multi_view_loss, `distill_posterior` branch,
-        sequence_tagger_model.py:2080-2093): `batch` is the STUDENT view (the bare sentences), teacher_emissions f32[B,n_t,T] the
-        emissions of the same sentences' real tokens in the context view (a constant: the reference detaches it).  Returns
-        sum_b weights[b] * T^2 * sum_i KL(teacher || student tempered marginals) (default weights 1/B = the reference's
-        `.sum() / shape[0]`) as a 0-d device tensor and, if `backward`, accumulates loss_scale * its gradient into arena.g."""
-        return self._launch(self._distill_loss, batch, teacher_emissions, tau, loss_scale, backward, weights, grad_ready)
+    def distill_loss(self, batch, teacher_emissions, tau, loss_scale=1.0, backward=True, weights=None, grad_ready=None,
+                     mode="posterior", teacher_pooled=None, l2_only=False):
+        """Multi-view distillation term (FastSequenceTagger._calculate_multi_view_loss, sequence_tagger_model.py:1958-2107): `batch`
+        is the STUDENT view (the bare sentences), teacher_emissions f32[B,n_t,T] the emissions of the same sentences' real tokens in
+        the context view (a constant: the reference detaches it).
+          mode "posterior" (:2088-2101)  sum_b weights[b] * T^2 * sum_i KL(teacher || student tempered token marginals)
+          mode "exact"     (:2049-2087)  sum_b weights[b] * max(0, -(E_teacher[path score / T] - logZ_T) T^2), the teacher being the
+                                         context view's tempered pairwise posteriors under the shared transitions
+          teacher_pooled bf16[B,n_t,H]   calculate_l2_loss (:1988-1996,2026-2035): + sum_b weights[b] / H * |student token
+                                         representations - the context view's|^2 at the real tokens; l2_only (:2038): only that
+        (default weights 1/B = the reference's `.sum() / shape[0]`).  Returns a 0-d device tensor and, if `backward`, accumulates
+        loss_scale * its gradient into arena.g."""
+        return self._launch(self._distill_loss, batch, teacher_emissions, tau, loss_scale, backward, weights, grad_ready, mode,
+                            teacher_pooled, l2_only)
 
-    def _distill_loss(self, batch, te, tau, loss_scale, backward, weights, grad_ready):
+    def distill_terms(self, em, te, clens, w, tau, mode, loss_scale, dtrans):
+        """the CRF part of the multi-view term from the two views' emissions on (f32 [B,nc,T] each; te constant): -> (sum_b w[b] *
+        loss_b as a 0-d tensor, d(loss_scale * that) / d em); the transition gradient is ADDED to dtrans"""
+        trans = self.arena.param("transitions")
+        B = em.shape[0]
+        if mode == "none":
+            return torch.zeros((), dtype=F32, device=self.device), torch.zeros_like(em)
+        if mode == "exact":
+            pair, _, _ = ops.crf_pair_posterior(te, trans, clens, tau, self.start, self.stop)
+            s_sc = ((te[:, 0, :] + trans[:, self.start][None, :]) / tau).contiguous()          # :2065 (no backward variable)
+            e_sc = (trans[self.stop, :] / tau)[None, :].expand(B, self.T).contiguous()         # :2066 (no forward variable)
+            per, demit = ops.crf_exact_kd(em, trans, clens, pair, s_sc, e_sc, w * loss_scale, tau, self.start, self.stop, dtrans)
+        elif mode == "posterior":
+            per, demit = ops.crf_posterior_kl(em, te, trans, clens, w * loss_scale, tau, self.start, self.stop, dtrans)
+        else:
+            raise ValueError("distill_loss mode must be 'posterior' or 'exact'")
+        return (per * w).sum(), demit
+
+    def _distill_loss(self, batch, te, tau, loss_scale, backward, weights, grad_ready, mode="posterior", tp=None, l2_only=False):
         em, pooled, crow_idx, B, nc, R, S = self._emit(batch)
         if te.shape[0] != B or te.shape[2] != self.T:
             raise ValueError("teacher emissions must be [B, n, T] for the same B sentences")
@@ -578,13 +612,28 @@ class Tagger:
             raise ValueError("the teacher view has fewer real tokens (%d) than the student view (%d)" % (te.shape[1], nc))
         te = te[:, :nc].contiguous()
         a = self.arena
+        trans = a.param("transitions")
         w = self._sentence_weights(weights, B)
         dtr = a.grad("transitions") if backward else torch.zeros((self.T, self.T), dtype=F32, device=self.device)
-        per, demit = ops.crf_posterior_kl(em, te, a.param("transitions"), batch["clens"], w * loss_scale, tau, self.start,
-                                          self.stop, dtr)
-        loss = (per * w).sum()
+        if l2_only and tp is None:
+            raise ValueError("l2_only needs the teacher view's token representations")
+        loss, demit = self.distill_terms(em, te, batch["clens"], w, tau, "none" if l2_only else mode, loss_scale, dtr)
+        l2 = None
+        if tp is not None:
+            H = pooled.shape[1]
+            if tp.shape[0] != B or tp.shape[1] < nc or tp.shape[2] != H:
+                raise ValueError("teacher token representations must be [B, >= %d, %d]" % (nc, H))
+            valid = torch.arange(nc, device=self.device)[None, :] < batch["clens"][:, None]
+            wrow = (valid * (w / H)[:, None]).reshape(B * nc).to(F32).contiguous()
+            l2 = (tp[:, :nc].contiguous().view(B * nc, H), wrow)
+            if not backward:
+                part = torch.zeros((1,), dtype=F32, device=self.device)
+                ops.l2_rows(pooled, l2[0], wrow, part)
+                loss = loss + part[0]
         if backward:
-            self._backprop_emissions(demit, pooled, crow_idx, B, nc, R, S, grad_ready)
+            part = self._backprop_emissions(demit, pooled, crow_idx, B, nc, R, S, grad_ready, l2=l2, l2_scale=loss_scale)
+            if part is not None:
+                loss = loss + part
         return loss
 
     # ---------------------------------------------------------------- teacher-student knowledge distillation

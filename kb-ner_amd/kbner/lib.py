@@ -34,6 +34,7 @@ SIGNATURES = {
     "kbner_gather_rows": (c_int, [P, P, P, c_int, c_int, P]),
     "kbner_gather_rows_ld": (c_int, [P, c_int, P, P, c_int, c_int, c_int, P]),
     "kbner_gather_rows_f32": (c_int, [P, P, P, c_int, c_int, P]),
+    "kbner_l2_rows": (c_int, [P, P, P, c_float, P, P, c_int, c_int, P]),
     "kbner_scatter_add_rows_f32": (c_int, [P, P, P, c_int, c_int, P]),
     "kbner_scatter_rows": (c_int, [P, P, P, c_int, c_int, P]),
     "kbner_scatter_rows_f32": (c_int, [P, P, P, c_int, c_int, P]),

@@ -218,6 +218,18 @@ def scatter_add_rows_f32(rows, idx, dst):
     return dst
 
 
+def l2_rows(a, b, w, loss, da=None, gscale=1.0):
+    """loss[0] += sum_r w[r] |a[r] - b[r]|^2; da[r] += 2 gscale w[r] (a[r] - b[r]) -- multi-view calculate_l2_loss (a, b, da bf16 [R,H])"""
+    _chk(a, BF16, "a"); _chk(b, BF16, "b"); _chk(w, F32, "w"); _chk(loss, F32, "loss")
+    if da is not None:
+        _chk(da, BF16, "da")
+    R, H = a.shape
+    if tuple(b.shape) != (R, H) or w.numel() != R or (da is not None and tuple(da.shape) != (R, H)):
+        raise L.KbnerError("l2_rows: a, b, da [R,H], w [R]")
+    L.call("kbner_l2_rows", ptr(a), ptr(b), ptr(w), float(gscale), ptr(da), ptr(loss), R, H, stream_ptr())
+    return loss
+
+
 def scatter_rows(dout, idx, dsrc):
     _chk(dout, BF16, "dout"); _chk(idx, I32, "idx"); _chk(dsrc, BF16, "dsrc")
     L.call("kbner_scatter_rows", ptr(dout), ptr(idx), ptr(dsrc), idx.numel(), dout.shape[-1], stream_ptr())

@@ -88,8 +88,12 @@ def gold_reweighted(att, targets, tags, lens, gold_const, exp_score, att_nums):
 
 
 def exact_term(es, trans, lens, pair, s_sc, e_sc, tau, start, stop):
-    """:2139-2244 + _calculate_xstruct_distillation_loss (:2400-2425): -(E_teacher[score / T] - logZ_T) * T^2 per sentence,
-    negative values replaced by 0 (constant), sum / B"""
+    """:2139-2244 + _calculate_xstruct_distillation_loss (:2400-2425): sum over sentences / B"""
+    return exact_per_sentence(es, trans, lens, pair, s_sc, e_sc, tau, start, stop).sum() / es.shape[0]
+
+
+def exact_per_sentence(es, trans, lens, pair, s_sc, e_sc, tau, start, stop):
+    """-(E_teacher[score / T] - logZ_T) * T^2 per sentence, negative values replaced by 0 (a constant: no gradient)"""
     B, n, T = es.shape
     lens = torch.as_tensor(lens)
     # tempered partition: the plain recursion on es / T, trans / T (:1348-1350)
@@ -106,8 +110,7 @@ def exact_term(es, trans, lens, pair, s_sc, e_sc, tau, start, stop):
     else:
         expect = ends
     kd = -((expect - logz) * tau * tau)
-    kd = torch.where(kd < 0, torch.zeros_like(kd), kd)
-    return kd.sum() / B
+    return torch.where(kd < 0, torch.zeros_like(kd), kd)
 
 
 def target_term(es, trans, lens, tags, start, stop, x_idx=None):

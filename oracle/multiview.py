@@ -52,3 +52,32 @@ def posterior_kl(emit_s, emit_t, trans, lens, tau, start, stop):
         gt = (forward_vars(emit_t, trans, start) + backward_vars(emit_t, lens, trans, stop)) * mask[:, :, None]
     kd = torch.nn.functional.kl_div(torch.log_softmax(gs / tau, dim=-1), torch.softmax(gt / tau, dim=-1), reduction="none")
     return (kd * mask[:, :, None]).sum((1, 2)) * tau * tau
+
+
+def exact_teacher(emit_t, trans, lens, tau, start, stop):
+    """the distill_exact branch's teacher (:2065-2080): softmax over tag pairs of (alpha_{i-1}[from] + beta_i[to] + e_i[to] +
+    trans[to, from]) / T of the CONTEXT view under the shared transitions; the start score is (e_0 + trans[:, START]) / T and the end
+    score trans[STOP, :] / T -- without the backward / forward variables the KD trainer's teacher adds (finetune_trainer.py:1719-1722)"""
+    B, n, T = emit_t.shape
+    lens = torch.as_tensor(lens)
+    fv, bv = forward_vars(emit_t, trans, start), backward_vars(emit_t, lens, trans, stop)
+    ss = emit_t[:, :, :, None] + trans[None, None, :, :]
+    bm = (torch.arange(max(n - 1, 0))[None, :] < (lens - 1)[:, None]).to(emit_t.dtype)
+    pair = ((fv[:, :-1, None, :] + bv[:, 1:, :, None] + ss[:, 1:]) * bm[:, :, None, None] / tau).reshape(B, max(n - 1, 0), T * T).softmax(-1)
+    return pair, (emit_t[:, 0] + trans[None, :, start]) / tau, (trans[None, stop, :] / tau).expand(B, T)
+
+
+def exact_kd(emit_s, emit_t, trans, lens, tau, start, stop):
+    """-> per-sentence loss [B] of the distill_exact branch (:2049-2087); the teacher side is detached (:2081-2083)"""
+    from . import kd
+    with torch.no_grad():
+        pair, s_sc, e_sc = exact_teacher(emit_t, trans, lens, tau, start, stop)
+    return kd.exact_per_sentence(emit_s, trans, lens, pair, s_sc, e_sc, tau, start, stop)
+
+
+def l2_term(rep_s, rep_t, lens):
+    """calculate_l2_loss (:2026-2035): squared distance of the two views' token representations at the real tokens, summed,
+    / B / H -> per-sentence values [B] (the reference returns their sum / B); rep_t is detached (:2027)"""
+    B, n, H = rep_s.shape
+    mask = (torch.arange(n)[None, :] < torch.as_tensor(lens)[:, None]).to(rep_s.dtype)
+    return (((rep_s - rep_t.detach()) ** 2) * mask[:, :, None]).sum((1, 2)) / H

@@ -711,3 +711,56 @@ def test_kd_loss_vs_oracle(B, n, T, tau, K):
     assert np.abs(de.cpu().numpy() - ref).max() <= tol * max(1e-3, np.abs(ref).max())
     ref = tr_t.grad.numpy()
     assert np.abs(dtr.cpu().numpy() - ref).max() <= 3 * tol * max(1e-3, np.abs(ref).max())
+
+
+def test_multiview_exact_and_l2_vs_reference_golden(golden_dir):
+    """the distill_exact branch of the multi-view loss (Tagger.distill_terms mode "exact": kbner_crf_pair_posterior of the context
+    view under the shared transitions + kbner_crf_exact_kd) and the calculate_l2_loss / l2_loss_only term (kbner_l2_rows, forward +
+    gradient into the pooled rows) against FastSequenceTagger._calculate_multi_view_loss run by the reference under autograd
+    (tests/golden/multiview_branches.npz): loss, d / d student emissions, d / d student token representations, d / d transitions"""
+    from kbner import ops
+    g = np.load(os.path.join(golden_dir, "multiview_branches.npz"))
+    start, stop = int(g["start"]), int(g["stop"])
+    tg = _kd_tagger(g["trans"].shape[0], start, stop, g["trans"])
+    for c in range(int(g["n_cases"])):
+        exact, posterior, l2, l2_only = [bool(x) for x in g["c%d_flags" % c]]
+        real, tau = g["c%d_real" % c], float(g["c%d_tau" % c])
+        B, nr = len(real), int(real.max())
+        em = torch.from_numpy(g["c%d_feats_orig" % c]).cuda()
+        te = torch.from_numpy(g["c%d_feats_ctx" % c][:, :nr].copy()).cuda()
+        clens = torch.from_numpy(real.astype(np.int32)).cuda()
+        w = torch.full((B,), 1.0 / B, device="cuda")
+        dtr = torch.zeros_like(tg.arena.param("transitions"))
+        mode = "none" if l2_only else ("exact" if exact else "posterior")
+        loss, de = tg.distill_terms(em, te, clens, w, tau, mode, 1.0, dtr)
+        loss = float(loss)
+        drep = None
+        if l2:
+            # fp32-exact inputs for the bf16 kernel: the golden representations rounded to bf16 on both sides of the comparison
+            H = g["c%d_rep_orig" % c].shape[2]
+            a = torch.from_numpy(g["c%d_rep_orig" % c]).cuda().to(torch.bfloat16).contiguous().view(B * nr, H)
+            b = torch.from_numpy(g["c%d_rep_ctx" % c][:, :nr].copy()).cuda().to(torch.bfloat16).contiguous().view(B * nr, H)
+            valid = torch.arange(nr, device="cuda")[None, :] < clens[:, None]
+            wrow = (valid * (w / H)[:, None]).reshape(B * nr).float().contiguous()
+            part = torch.zeros(1, device="cuda")
+            da = torch.zeros_like(a)
+            ops.l2_rows(a, b, wrow, part, da=da)
+            want = float((((a.float() - b.float()) ** 2).sum(1) * wrow).sum())
+            assert abs(float(part) - want) <= 1e-5 * max(1.0, want)
+            want_d = (2 * wrow[:, None] * (a.float() - b.float()))
+            assert float((da.float() - want_d).abs().max()) <= 8e-3 * float(want_d.abs().max())       # bf16 gradient rows
+            # against the reference's fp32 value: bf16 rounding of the inputs only (2^-9 relative per element)
+            ref_l2 = float(g["c%d_loss" % c]) - (0.0 if l2_only else loss)
+            assert abs(float(part) - ref_l2) <= 2e-2 * max(1e-3, abs(ref_l2)), (c, float(part), ref_l2)
+            loss += float(part)
+            drep = da.float().view(B, nr, H).cpu().numpy()
+        torch.cuda.synchronize()
+        ref = float(g["c%d_loss" % c])
+        assert abs(loss - ref) <= (2e-2 if l2 else 5e-5) * max(1.0, abs(ref)), (c, loss, ref)
+        ref = g["c%d_dfeats" % c]
+        assert np.abs(de.cpu().numpy() - ref).max() <= 1e-4 * max(1e-3, np.abs(ref).max()), c
+        ref = g["c%d_dtrans" % c]
+        assert np.abs(dtr.cpu().numpy() - ref).max() <= 2e-4 * max(1e-3, np.abs(ref).max()), c
+        if drep is not None:
+            ref = g["c%d_drep" % c]
+            assert np.abs(drep - ref).max() <= 2e-2 * np.abs(ref).max(), c
