@@ -786,3 +786,71 @@ def test_train_py_command_line(tmp_path):
     assert all(len(l.split(" ")) == 4 for l in pred if l)
     out = run("--test_speed")
     assert any(l.strip().replace(".", "", 1).isdigit() for l in out.split("\n"))      # the reference prints the bare rate
+
+
+def test_train_py_distill_mode_command_line(tmp_path):
+    """the KD path as a user runs it: train a teacher with this repo's train.py, then train a student from a YAML that names the
+    teacher's YAML (`ModelFinetuner: {distill_mode: true}`, `is_teacher_list`, `ner.teachers`) -- train.py builds the teacher from
+    its own config + best-model.pt, labels the training set and trains on interpolation * KD + (1 - interpolation) * NLL;
+    --test of the student afterwards builds no teachers"""
+    import subprocess
+    import sys
+    import tiny_assets
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg, tcfg = tiny_assets.kd_config(str(tmp_path), max_epochs=2, posterior=True, crf=True, attention=True, exact=False, best_k=3)
+    tcfg["train"]["max_epochs"] = 3
+    with open(tmp_path / "cfg.yaml", "w") as f:
+        yaml.safe_dump(cfg, f)
+    with open(tmp_path / "teacher.yaml", "w") as f:
+        yaml.safe_dump(tcfg, f)
+
+    def run(config, *extra):
+        r = subprocess.run([sys.executable, os.path.join(root, "train.py"), "--config", str(tmp_path / config)] + list(extra),
+                           cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert r.returncode == 0, r.stderr.decode(errors="replace")[-3000:]
+        return r.stdout.decode(errors="replace") + r.stderr.decode(errors="replace")
+
+    run("teacher.yaml")
+    assert (tmp_path / "out" / "tiny_teacher" / "best-model.pt").exists()
+    out = run("cfg.yaml")
+    base = tmp_path / "out" / "tiny_kd_run"
+    assert "Distilling sentences as targets" in out and "Distilled 18 sentences" in out and "distill_mode: interpolation" in out
+    assert (base / "best-model.pt").exists() and (base / "loss.tsv").exists()
+    rows = [l.split("\t") for l in (base / "loss.tsv").read_text().strip().split("\n")[1:]]
+    assert len(rows) == 2 and all(float(r[3]) > 0 for r in rows) and float(rows[1][3]) < float(rows[0][3])     # the KD loss goes down
+    out = run("cfg.yaml", "--test")
+    assert "Distilling" not in out and "Testing using best model" in out
+
+
+@pytest.mark.parametrize("flags", [dict(distill_exact=True, distill_posterior=False), dict(calculate_l2_loss=True),
+                                   dict(calculate_l2_loss=True, l2_loss_only=True)])
+def test_multiview_other_branches_train(tmp_path, flags):
+    """the multi-view YAML shape with the OTHER branches of _calculate_multi_view_loss switched on (distill_exact; calculate_l2_loss on
+    top of the posterior term; l2_loss_only): the trainer runs, the second-view term is positive and finite in every micro-batch that
+    carries one, and the epoch loss goes down.  (The terms themselves are pinned to the reference in tests/test_gpu_kernels.py.)"""
+    import tiny_assets
+    from flair.config_parser import ConfigParser
+    from flair.trainers import ModelFinetuner
+    from flair.utils.from_params import Params
+    cfg = tiny_assets.multiview_config(str(tmp_path), max_epochs=3, accum=2, mini_batch_size=2, temperature=2.0)
+    cfg["model"]["FastSequenceTagger"].update(flags)
+    with open(tmp_path / "cfg.yaml", "w") as f:
+        yaml.safe_dump(cfg, f)
+    cp = ConfigParser(Params.from_file(str(tmp_path / "cfg.yaml")))
+    student = cp.create_student()
+    trainer = ModelFinetuner(student, None, cp.corpus, config=cp.config, **cp.config["ModelFinetuner"])
+    parts = []
+    fb = student.forward_backward
+
+    def spy(data_points, *a, **k):
+        out = fb(data_points, *a, **k)
+        nll, kd = student.last_loss_parts
+        if kd is not None:
+            parts.append(float(kd))
+        return out
+
+    student.forward_backward = spy
+    out = trainer.train(cp.get_target_path, **cp.config["train"])
+    assert len(parts) >= 3 and all(np.isfinite(p) and p >= 0 for p in parts) and max(parts) > 0
+    h = out["train_loss_history"]
+    assert all(np.isfinite(x) for x in h) and h[-1] < h[0], h
