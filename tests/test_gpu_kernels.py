@@ -101,6 +101,29 @@ def test_attention(st, B, S, A, ragged):
     assert r["dbias"] < 2e-2, r                        # qkv bias gradient accumulated inside the backward kernels
 
 
+def test_attention_streaming_forward_variant():
+    """the opt-in streaming forward kernel (csrc/attention3.hip, KBNER_ATTN=4 forces it for every shape) ships in the library, so it
+    is held to the default kernel's tolerances: ragged masks, dropout, S = 64 ... 512 (own process: the variant is read once)"""
+    import subprocess
+    import sys
+    code = ("import sys, json; sys.path.insert(0, 'tests'); import selftest as st\n"
+            "out = []\n"
+            "for (B, S, A, ragged, p) in ((2, 64, 2, False, 0.0), (3, 192, 2, True, 0.0), (2, 512, 4, True, 0.0), (2, 256, 2, True, 0.1), "
+            "(2, 512, 2, False, 0.1)):\n"
+            "    r = st.check_attention(B, S, A, ragged=ragged, drop_p=p)\n"
+            "    out.append({k: float(v) for k, v in r.items() if k in ('ctx', 'lse', 'dq', 'dk', 'dv')})\n"
+            "print('RESULT' + json.dumps(out))\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, KBNER_ATTN="4", PYTHONPATH=os.path.join(root, "kb-ner_amd") + os.pathsep + root)
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode(errors="replace")[-2000:]
+    import json
+    line = [l for l in r.stdout.decode().split("\n") if l.startswith("RESULT")][0]
+    for res in json.loads(line[len("RESULT"):]):
+        assert res["ctx"] < 1.5e-2 and res["lse"] < 2e-2, res
+        assert res["dq"] < 3e-2 and res["dk"] < 3e-2 and res["dv"] < 3e-2, res     # backward consumes this forward's lse
+
+
 @pytest.mark.parametrize("M,H", [(256, 128), (300, 768), (512, 1024)])
 def test_layernorm(st, M, H):
     r = st.check_layernorm(M, H)
