@@ -217,6 +217,238 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const bf16_t* __restri
   }  // items
 }
 
+// Round 3: the same panel-resident forward with 32 query rows per wave and pass.  With 16-row passes every K / V fragment read
+// out of LDS feeds ONE MFMA, and a pass moves both 64-KiB panels through the LDS pipe for 16 rows: 4 MB per head, ~260 K cycles
+// of LDS bandwidth per CU and B = 128 launch next to ~280 K cycles of MFMA + VALU issue per SIMD -- the kernel is co-limited by
+// the two.  Two 16-row blocks per wave share every fragment read (half the LDS bytes per flop, as the
+// backward kernels do since round 2).  The scores of 32 rows x 512 keys do not fit the register file, so a pass runs the keys in
+// TWO halves -- scores, exponentials and P.V of keys [0, S/2), then of [S/2, S) -- joined by ONE online-softmax step per row
+// (outputs and row sums of the first half rescaled by exp2(m_old - m_new)): not a streaming softmax, a two-block one.
+// Everything else (accumulators started at mask / scale, ones-MFMA row sums, unnormalised P into the P.V MFMAs, persistent walk
+// over heads with the next head's K panel requested after the last Q.K^T and its V panel after the last P.V) is the 16-row
+// kernel's.  Needs rpw % 256 == 0 (every wave owns whole 32-row passes) and NKB % 4 == 0.
+template <int NKB, bool DROP, bool PERSIST = false, int NP = 2>
+__global__ __launch_bounds__(512) void attn_fwd32_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ maskbias,
+                                                         bf16_t* __restrict__ ctx, float* __restrict__ lse, int H, int A, float scale,
+                                                         int rpw, uint32_t drop_seed, uint32_t drop_thresh, int nitems) {
+  constexpr int S = NKB * 16;
+  constexpr int NH = NKB / NP;  // 16-key fragments per part (NP parts of the key axis, joined by NP - 1 online-softmax steps per row)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sK = smem;
+  unsigned char* sV = smem + AT_MAXS * 128;
+  float* sMask = reinterpret_cast<float*>(smem + 2 * AT_MAXS * 128);
+  uint32_t* sCk = reinterpret_cast<uint32_t*>(sMask + AT_MAXS);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int qt = PERSIST ? 0 : blockIdx.x;
+  const int ld = 3 * H;
+  const float scale2 = scale * 1.4426950408889634f;
+  const float dscale = DROP ? drop_scale(drop_thresh) : 1.0f;
+  __shared__ int s_first_masked[2];
+  auto stage_mask = [&](int b_, int h_, int slot_) {
+    int fm = S;
+    const uint32_t bhS_ = (uint32_t)((b_ * A + h_) * S);
+    for (int i = tid; i < S; i += 512) {
+      const float m = maskbias[(size_t)b_ * S + i];
+      sMask[i] = m * (1.0f / scale);
+      if (m != 0.0f && i < fm) fm = i;
+      if (DROP) sCk[i] = drop_colkey(drop_seed, bhS_ + (uint32_t)i);
+    }
+    if (fm < S) atomicMin(&s_first_masked[slot_], fm);
+  };
+  int item = PERSIST ? (int)blockIdx.x : 0;
+  int h = PERSIST ? item % A : (int)blockIdx.y, b = PERSIST ? item / A : (int)blockIdx.z;
+  int slot = 0;
+  if (tid == 0) s_first_masked[0] = s_first_masked[1] = S;
+  __syncthreads();
+  stage_mask(b, h, 0);
+  stage_panel(qkv + (size_t)b * S * ld + h * AT_D + H, ld, S, sK, wid, lane);
+  stage_panel(qkv + (size_t)b * S * ld + h * AT_D + 2 * H, ld, S, sV, wid, lane);
+  const int g = lane >> 4, li = lane & 15;
+  const unsigned char* kb0 = sK + li * 128 + (((0 * 4 + g) ^ kc_swz(li)) << 4);
+  const unsigned char* kb1 = sK + li * 128 + (((1 * 4 + g) ^ kc_swz(li)) << 4);
+  const int vrow = g * 4 + (li >> 2);
+  const unsigned char* vb[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+    vb[db] = sV + vrow * 128 + (((db * 2 + ((li & 3) >> 1)) ^ kc_swz(vrow)) << 4) + ((li & 1) << 3);
+  const s8v ones_s = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+  const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_s);
+  for (;;) {   // items of this workgroup (one iteration unless PERSIST)
+  const bf16_t* base = qkv + (size_t)b * S * ld + h * AT_D;
+  const uint32_t bhS = (uint32_t)((b * A + h) * S);
+  const int next = item + (int)gridDim.x;
+  const bool has_next = PERSIST && next < nitems;
+  wait_vm(S / 64);   // K has landed when at most the V pieces are still in flight
+  __syncthreads();
+  const int nfree16 = s_first_masked[slot] >> 4;
+  if (has_next && tid == 0) s_first_masked[slot ^ 1] = S;
+  bool v_ready = false, k_next = false;
+  const int npass = rpw / 256;
+#pragma unroll 1
+  for (int pass = 0; pass < npass; ++pass) {
+    const int q0 = qt * rpw + wid * (rpw / 8) + pass * 32;
+    const bool active = q0 < S;
+    bf16x8 qf[2][2];
+    uint32_t rk[2] = {0u, 0u};
+    float m[2] = {-INFINITY, -INFINITY}, sum[2] = {0.0f, 0.0f};
+    f4v o[2][4], osum[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      osum[j] = (f4v){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int db = 0; db < 4; ++db) o[j][db] = (f4v){0.f, 0.f, 0.f, 0.f};
+    }
+    if (active) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        qf[j][0] = glb_frag(base, ld, q0 + j * 16, 0, lane);
+        qf[j][1] = glb_frag(base, ld, q0 + j * 16, 1, lane);
+        if (DROP) rk[j] = drop_rowkey(drop_seed, bhS + (uint32_t)(q0 + j * 16 + li));
+      }
+    }
+#pragma unroll
+    for (int half = 0; half < NP; ++half) {   // (`half`: the part index; NP = 2 in the first version)
+      f4v st[2][NH];
+      bf16x8 pbuf[2][NH / 2];
+      if (active) {
+        float mx[2] = {-INFINITY, -INFINITY};
+        const bool plain = nfree16 >= (half + 1) * NH;   // no masked key in this half (wave-uniform)
+        if (plain) {
+#pragma unroll
+          for (int f = 0; f < NH; ++f) {
+            const bf16x8 k0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s8v*>(kb0 + (half * NH + f) * 2048));
+            const bf16x8 k1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s8v*>(kb1 + (half * NH + f) * 2048));
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              f4v a = (f4v){0.f, 0.f, 0.f, 0.f};
+              a = MFMA(k0, qf[j][0], a);
+              a = MFMA(k1, qf[j][1], a);
+              mx[j] = fmaxf(fmaxf(mx[j], a[0]), a[1]);
+              mx[j] = fmaxf(fmaxf(mx[j], a[2]), a[3]);
+              st[j][f] = a;
+            }
+          }
+        } else {
+#pragma unroll
+          for (int f = 0; f < NH; ++f) {
+            const bf16x8 k0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s8v*>(kb0 + (half * NH + f) * 2048));
+            const bf16x8 k1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const s8v*>(kb1 + (half * NH + f) * 2048));
+            const f4v mk = *reinterpret_cast<const f4v*>(sMask + (half * NH + f) * 16 + g * 4);   // mask / scale
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              f4v a = MFMA(k0, qf[j][0], mk);
+              a = MFMA(k1, qf[j][1], a);
+              mx[j] = fmaxf(fmaxf(mx[j], a[0]), a[1]);
+              mx[j] = fmaxf(fmaxf(mx[j], a[2]), a[3]);
+              st[j][f] = a;
+            }
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const float mh = group4_max(mx[j]);
+          const float mn = fmaxf(m[j], mh);
+          if (half > 0) {   // online-softmax step: the earlier parts' outputs and sums to the new reference
+            const float alpha = __builtin_amdgcn_exp2f((m[j] - mn) * scale2);
+#pragma unroll
+            for (int db = 0; db < 4; ++db) o[j][db] *= alpha;
+            osum[j] *= alpha;
+            sum[j] *= alpha;
+          }
+          m[j] = mn;
+          const float nmx = -mn * scale2;
+          // exponentials are packed to the bf16 B fragments of P.V as they are produced: the fp32 score registers die here,
+          // two per packed fragment (peak 128 -> 64 live registers for the probabilities of a half)
+#pragma unroll
+          for (int kc = 0; kc < NH / 2; ++kc) {
+            f4v e[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+              const int f = 2 * kc + t;
+              f4v a = st[j][f];
+              a[0] = __builtin_amdgcn_exp2f(a[0] * scale2 + nmx);
+              a[1] = __builtin_amdgcn_exp2f(a[1] * scale2 + nmx);
+              a[2] = __builtin_amdgcn_exp2f(a[2] * scale2 + nmx);
+              a[3] = __builtin_amdgcn_exp2f(a[3] * scale2 + nmx);
+              if (DROP) {
+                sum[j] += (a[0] + a[1]) + (a[2] + a[3]);   // normaliser of the UNdropped softmax (reduced over g at the end)
+                const uint4 ck = *reinterpret_cast<const uint4*>(sCk + (half * NH + f) * 16 + g * 4);
+                a[0] = drop_keep(rk[j], ck.x, drop_thresh) ? a[0] : 0.0f;
+                a[1] = drop_keep(rk[j], ck.y, drop_thresh) ? a[1] : 0.0f;
+                a[2] = drop_keep(rk[j], ck.z, drop_thresh) ? a[2] : 0.0f;
+                a[3] = drop_keep(rk[j], ck.w, drop_thresh) ? a[3] : 0.0f;
+              }
+              e[t] = a;
+            }
+            pbuf[j][kc] = pack_b(e[0], e[1]);
+          }
+        }
+      }
+      if (half == NP - 1 && has_next && pass == npass - 1) {
+        // every wave is past the last Q.K^T / softmax of this head: sK, sMask and sCk are dead -> the next head's mask and K panel
+        __syncthreads();
+        const int hn = next % A, bn = next / A;
+        stage_mask(bn, hn, slot ^ 1);
+        stage_panel(qkv + (size_t)bn * S * ld + hn * AT_D + H, ld, S, sK, wid, lane);
+        k_next = true;
+      }
+      if (!v_ready) {  // first P.V of the item (uniform): V is needed from here on
+        wait_vm(0);
+        __syncthreads();
+        v_ready = true;
+      }
+      if (active) {
+#pragma unroll
+        for (int kc = 0; kc < NH / 2; ++kc) {
+          const bf16x8 pb0 = pbuf[0][kc];
+          const bf16x8 pb1 = pbuf[1][kc];
+          if (!DROP) {
+            osum[0] = MFMA(ones, pb0, osum[0]);
+            osum[1] = MFMA(ones, pb1, osum[1]);
+          }
+#pragma unroll
+          for (int db = 0; db < 4; ++db) {
+            const unsigned char* a = vb[db] + (half * (NH / 2) + kc) * 4096;
+            const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4v __attribute__((address_space(3)))*)(a));
+            const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4v __attribute__((address_space(3)))*)(a + 16 * 128));
+            s8v v;
+            v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+            v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+            const bf16x8 vf = __builtin_bit_cast(bf16x8, v);
+            o[0][db] = MFMA(vf, pb0, o[0][db]);
+            o[1][db] = MFMA(vf, pb1, o[1][db]);
+          }
+        }
+      }
+    }
+    if (active) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const float sm = DROP ? group4_sum(sum[j]) : osum[j][0];
+        const float inv = dscale / sm;
+        bf16_t* orow = ctx + (size_t)(b * S + q0 + j * 16 + li) * H + h * AT_D;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          uint2 u;
+          u.x = pack2bf(o[j][db][0] * inv, o[j][db][1] * inv);
+          u.y = pack2bf(o[j][db][2] * inv, o[j][db][3] * inv);
+          *reinterpret_cast<uint2*>(orow + db * 16 + g * 4) = u;
+        }
+        if (g == 0) lse[((size_t)b * A + h) * S + q0 + j * 16 + li] = (m[j] * scale2 + __log2f(sm)) * 0.6931471805599453f;
+      }
+    }
+  }
+  if (!has_next) break;
+  __syncthreads();   // every wave is done with sV: the next head's V panel
+  item = next;
+  h = item % A;
+  b = item / A;
+  slot ^= 1;
+  stage_panel(qkv + (size_t)b * S * ld + h * AT_D + 2 * H, ld, S, sV, wid, lane);
+  }  // items
+}
+
 // Column sums of a [16 rows x 64 cols] output fragment set accumulated over a workgroup's passes: the bias gradient of the
 // fused QKV projection (d qkv.bias = column sums of dQ | dK | dV), so no separate pass re-reads the 3H-wide dqkv.
 // acc[db][r] is this lane's running sum for column db*16 + g*4 + r (rows li); reduce over li, over the 8 waves, one atomic
@@ -886,6 +1118,9 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv2_kernel(const bf16_t* __rest
 }
 
 #define AT_LDS_BYTES (2 * AT_MAXS * 128 + 3 * AT_MAXS * 4)
+#ifndef KBNER_ATTN_PARTS
+#define KBNER_ATTN_PARTS 2   // key-axis parts of the 32-row forward kernel (4, for S % 128 == 0, measured slower: 263-268 vs 247-251 us)
+#endif
 
 // rows per workgroup: the whole head (one DMA of each panel per head) when the grid still covers the
 // chip several times over, otherwise smaller row tiles so small batches spread over more CUs
@@ -899,7 +1134,7 @@ static int at_cu_count() { return kbner_cu_count(); }
 
 template <int NKB, bool DROP>
 static int launch_attn_fwd2(const bf16_t* qkv, const float* maskbias, bf16_t* ctx, float* lse, int B, int H, int A, int rpw,
-                            uint32_t seed, uint32_t thresh, hipStream_t stream) {
+                            uint32_t seed, uint32_t thresh, hipStream_t stream, bool rows32) {
   static std::atomic<unsigned long long> done0{0}, done1{0};   // one bit per device (common.h)
   int r = kbner_set_max_lds_once(done0, reinterpret_cast<const void*>(attn_fwd_kernel<NKB, DROP, false>), AT_LDS_BYTES);
   if (r) return r;
@@ -907,6 +1142,24 @@ static int launch_attn_fwd2(const bf16_t* qkv, const float* maskbias, bf16_t* ct
   if (r) return r;
   const int S = NKB * 16;
   const int ncu = at_cu_count();
+  // 32 rows per wave and pass (round 3): half the LDS bytes per flop.  Not with dropout: in halves the keep tests push the S = 512
+  // instantiation over 256 VGPRs (94-148 spills), in quarters it fits but runs at 322 us against the 16-row kernel's 315
+  if (rows32 && !DROP && NKB % 4 == 0 && rpw % 256 == 0) {
+    constexpr int NP = (NKB % 8 == 0) ? KBNER_ATTN_PARTS : 2;
+    static std::atomic<unsigned long long> done2{0}, done3{0};
+    r = kbner_set_max_lds_once(done2, reinterpret_cast<const void*>(attn_fwd32_kernel<NKB, DROP, false, NP>), AT_LDS_BYTES);
+    if (r) return r;
+    r = kbner_set_max_lds_once(done3, reinterpret_cast<const void*>(attn_fwd32_kernel<NKB, DROP, true, NP>), AT_LDS_BYTES);
+    if (r) return r;
+    if (rpw == S && B * A >= 2 * ncu)
+      hipLaunchKernelGGL((attn_fwd32_kernel<NKB, DROP, true, NP>), dim3(ncu), dim3(512), AT_LDS_BYTES, stream, qkv, maskbias, ctx, lse,
+                         H, A, 0.125f, rpw, seed, thresh, B * A);
+    else
+      hipLaunchKernelGGL((attn_fwd32_kernel<NKB, DROP, false, NP>), dim3((S + rpw - 1) / rpw, A, B), dim3(512), AT_LDS_BYTES, stream,
+                         qkv, maskbias, ctx, lse, H, A, 0.125f, rpw, seed, thresh, 1);
+    hipError_t e32 = hipGetLastError();
+    return e32 == hipSuccess ? 0 : -(int)e32;
+  }
   if (rpw == S && B * A >= 2 * ncu) {   // whole heads, at least two per CU: walk them persistently, prefetching the next (-4 % at
                                         // full length, -8 % with ragged masks, tools/attn_bench.py at B = 128)
     hipLaunchKernelGGL((attn_fwd_kernel<NKB, DROP, true>), dim3(ncu), dim3(512), AT_LDS_BYTES, stream, qkv, maskbias, ctx, lse, H, A,
@@ -920,9 +1173,9 @@ static int launch_attn_fwd2(const bf16_t* qkv, const float* maskbias, bf16_t* ct
 }
 template <int NKB>
 static int launch_attn_fwd(const bf16_t* qkv, const float* maskbias, bf16_t* ctx, float* lse, int B, int H, int A, int rpw,
-                           uint32_t seed, uint32_t thresh, hipStream_t stream) {
-  if (thresh) return launch_attn_fwd2<NKB, true>(qkv, maskbias, ctx, lse, B, H, A, rpw, seed, thresh, stream);
-  return launch_attn_fwd2<NKB, false>(qkv, maskbias, ctx, lse, B, H, A, rpw, seed, thresh, stream);
+                           uint32_t seed, uint32_t thresh, hipStream_t stream, bool rows32) {
+  if (thresh) return launch_attn_fwd2<NKB, true>(qkv, maskbias, ctx, lse, B, H, A, rpw, seed, thresh, stream, rows32);
+  return launch_attn_fwd2<NKB, false>(qkv, maskbias, ctx, lse, B, H, A, rpw, seed, thresh, stream, rows32);
 }
 
 template <bool DROP>
@@ -985,15 +1238,16 @@ int kbner_attn_fwd(const bf16_t* qkv, const float* maskbias, bf16_t* ctx, float*
   // whole heads per workgroup, at least one per CU: the software-pipelined 32-row kernel
   if ((attn_variant() == 3 && S >= 256 && B * A >= at_cu_count()) || attn_variant() >= 4)   // 4: forced (tests of small cases)
     return kbner_attn_fwd3(qkv, maskbias, ctx, lse, B, S, H, A, drop_seed, drop_thresh, st);
+  const bool rows32 = attn_variant() != 1;   // KBNER_ATTN=1: the 16-row-per-pass forward of round 2 (A/B)
   switch (S / 64) {
-    case 1: return launch_attn_fwd<4>(qkv, maskbias, ctx, lse, B, H, A, rpw, drop_seed, drop_thresh, st);
-    case 2: return launch_attn_fwd<8>(qkv, maskbias, ctx, lse, B, H, A, rpw, drop_seed, drop_thresh, st);
-    case 3: return launch_attn_fwd<12>(qkv, maskbias, ctx, lse, B, H, A, rpw, drop_seed, drop_thresh, st);
-    case 4: return launch_attn_fwd<16>(qkv, maskbias, ctx, lse, B, H, A, rpw, drop_seed, drop_thresh, st);
-    case 5: return launch_attn_fwd<20>(qkv, maskbias, ctx, lse, B, H, A, rpw, drop_seed, drop_thresh, st);
-    case 6: return launch_attn_fwd<24>(qkv, maskbias, ctx, lse, B, H, A, rpw, drop_seed, drop_thresh, st);
-    case 7: return launch_attn_fwd<28>(qkv, maskbias, ctx, lse, B, H, A, rpw, drop_seed, drop_thresh, st);
-    default: return launch_attn_fwd<32>(qkv, maskbias, ctx, lse, B, H, A, rpw, drop_seed, drop_thresh, st);
+    case 1: return launch_attn_fwd<4>(qkv, maskbias, ctx, lse, B, H, A, rpw, drop_seed, drop_thresh, st, rows32);
+    case 2: return launch_attn_fwd<8>(qkv, maskbias, ctx, lse, B, H, A, rpw, drop_seed, drop_thresh, st, rows32);
+    case 3: return launch_attn_fwd<12>(qkv, maskbias, ctx, lse, B, H, A, rpw, drop_seed, drop_thresh, st, rows32);
+    case 4: return launch_attn_fwd<16>(qkv, maskbias, ctx, lse, B, H, A, rpw, drop_seed, drop_thresh, st, rows32);
+    case 5: return launch_attn_fwd<20>(qkv, maskbias, ctx, lse, B, H, A, rpw, drop_seed, drop_thresh, st, rows32);
+    case 6: return launch_attn_fwd<24>(qkv, maskbias, ctx, lse, B, H, A, rpw, drop_seed, drop_thresh, st, rows32);
+    case 7: return launch_attn_fwd<28>(qkv, maskbias, ctx, lse, B, H, A, rpw, drop_seed, drop_thresh, st, rows32);
+    default: return launch_attn_fwd<32>(qkv, maskbias, ctx, lse, B, H, A, rpw, drop_seed, drop_thresh, st, rows32);
   }
 }
 
