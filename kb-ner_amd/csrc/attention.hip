@@ -824,6 +824,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq2_kernel(const bf16_t* __restr
   const int nkc = ((klen + 63) >> 6) << 1;   // key chunks holding an unmasked key, rounded up to the loop's unroll of 2
                                              // (a fully masked extra chunk has P = 0: it adds exactly nothing)
   const float scale2 = scale * 1.4426950408889634f;
+  const float oscale = scale * dscale;   // dQ = scale / (1-p) * (dS' K), see the accumulator-start note below
   const PanelBases pK = panel_bases(sK, lane), pV = panel_bases(sV, lane);
   const bf16_t* dob = dctx + (size_t)b * S * H + h * AT_D;
   const bf16_t* ob = ctx + (size_t)b * S * H + h * AT_D;
@@ -847,6 +848,9 @@ __global__ __launch_bounds__(512) void attn_bwd_dq2_kernel(const bf16_t* __restr
       l_q[j] = -lse[sidx] / scale;   // accumulator init of the score MFMAs: exp2(scale2 * (q.k + mask/scale - lse/scale))
       d_q[j] = group4_sum(dot8(dof[j][0], glb_frag(ob, H, qj, 0, lane)) + dot8(dof[j][1], glb_frag(ob, H, qj, 1, lane)));
       if (g == 0) Dv[sidx] = d_q[j];
+      // with dropout dS = P (m dP / (1-p) - D) = (1 / (1-p)) P (m dP - (1-p) D): the 1 / (1-p) moves to the final dQ scale and the
+      // accumulators of dP start at -(1-p) D as they start at -D without dropout (a dropped element keeps that start value)
+      if (DROP) d_q[j] *= 1.0f / dscale;
       rk[j] = DROP ? drop_rowkey(drop_seed, bhS + (uint32_t)(qj + li)) : 0u;
 #pragma unroll
       for (int db = 0; db < 4; ++db) dq[j][db] = zero4;
@@ -884,7 +888,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq2_kernel(const bf16_t* __restr
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const f4v sinit = (f4v){l_q[j], l_q[j], l_q[j], l_q[j]};
-          const f4v pinit = DROP ? zero4 : (f4v){-d_q[j], -d_q[j], -d_q[j], -d_q[j]};
+          const f4v pinit = (f4v){-d_q[j], -d_q[j], -d_q[j], -d_q[j]};
           s0[j] = MFMA(k00, qf[j][0], sinit);
           s0[j] = MFMA(k01, qf[j][1], s0[j]);
           s1[j] = MFMA(k10, qf[j][0], sinit);
@@ -913,11 +917,11 @@ __global__ __launch_bounds__(512) void attn_bwd_dq2_kernel(const bf16_t* __restr
             const float pr1 = __builtin_amdgcn_exp2f(s1[j][r] * scale2);
             float dp0 = p0[j][r], dp1 = p1[j][r];
             if (DROP) {
-              dp0 = drop_keep(rk[j], ck0[r], drop_thresh) ? dp0 * dscale : 0.0f;
-              dp1 = drop_keep(rk[j], ck1[r], drop_thresh) ? dp1 * dscale : 0.0f;
+              dp0 = drop_keep(rk[j], ck0[r], drop_thresh) ? dp0 : -d_q[j];
+              dp1 = drop_keep(rk[j], ck1[r], drop_thresh) ? dp1 : -d_q[j];
             }
-            ds0[r] = DROP ? pr0 * (dp0 - d_q[j]) : pr0 * dp0;
-            ds1[r] = DROP ? pr1 * (dp1 - d_q[j]) : pr1 * dp1;
+            ds0[r] = pr0 * dp0;
+            ds1[r] = pr1 * dp1;
           }
           dsb[j] = pack_b(ds0, ds1);
         }
@@ -935,10 +939,10 @@ __global__ __launch_bounds__(512) void attn_bwd_dq2_kernel(const bf16_t* __restr
 #pragma unroll
       for (int db = 0; db < 4; ++db) {
         uint2 u;
-        u.x = pack2bf(dq[j][db][0] * scale, dq[j][db][1] * scale);
-        u.y = pack2bf(dq[j][db][2] * scale, dq[j][db][3] * scale);
+        u.x = pack2bf(dq[j][db][0] * oscale, dq[j][db][1] * oscale);
+        u.y = pack2bf(dq[j][db][2] * oscale, dq[j][db][3] * oscale);
         *reinterpret_cast<uint2*>(orow + db * 16 + g * 4) = u;
-        bsum[db] += dq[j][db] * scale;
+        bsum[db] += dq[j][db] * oscale;
       }
     }
   }
@@ -974,7 +978,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv2_kernel(const bf16_t* __rest
   const float dscale = DROP ? drop_scale(drop_thresh) : 1.0f;
   for (int i = tid; i < S; i += 512) {
     sL[i] = -lse[sbase + i] / scale;   // accumulator init of the score MFMAs (see attn_bwd_dq2_kernel)
-    sD[i] = -Dv[sbase + i];
+    sD[i] = -Dv[sbase + i] * (1.0f / dscale);   // -(1-p) D: the 1 / (1-p) of dropout leaves through the final dK / dV scales
     if (DROP) sRk[i] = drop_rowkey(drop_seed, bhS + (uint32_t)i);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1045,9 +1049,9 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv2_kernel(const bf16_t* __rest
           s0[j] = MFMA(q01, kf[j][1], s0[j]);
           s1[j] = MFMA(q10, kf[j][0], sl1);
           s1[j] = MFMA(q11, kf[j][1], s1[j]);
-          p0[j] = MFMA(o00, vf[j][0], DROP ? zero4 : nd0);
+          p0[j] = MFMA(o00, vf[j][0], nd0);
           p0[j] = MFMA(o01, vf[j][1], p0[j]);
-          p1[j] = MFMA(o10, vf[j][0], DROP ? zero4 : nd1);
+          p1[j] = MFMA(o10, vf[j][0], nd1);
           p1[j] = MFMA(o11, vf[j][1], p1[j]);
         }
         if (masked) {
@@ -1070,13 +1074,13 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv2_kernel(const bf16_t* __rest
             pr1[r] = e1;
             if (DROP) {
               const bool k0_ = drop_keep(rk0[r], ck[j], drop_thresh), k1_ = drop_keep(rk1[r], ck[j], drop_thresh);
-              pr0[r] = k0_ ? e0 * dscale : 0.0f;
-              pr1[r] = k1_ ? e1 * dscale : 0.0f;
-              dp0 = k0_ ? dp0 * dscale : 0.0f;
-              dp1 = k1_ ? dp1 * dscale : 0.0f;
+              pr0[r] = k0_ ? e0 : 0.0f;          // (kept probabilities unscaled: dV carries the 1 / (1-p))
+              pr1[r] = k1_ ? e1 : 0.0f;
+              dp0 = k0_ ? dp0 : nd0[r];          // a dropped element keeps the accumulator's start value -(1-p) D
+              dp1 = k1_ ? dp1 : nd1[r];
             }
-            ds0[r] = DROP ? e0 * (dp0 + nd0[r]) : e0 * dp0;
-            ds1[r] = DROP ? e1 * (dp1 + nd1[r]) : e1 * dp1;
+            ds0[r] = e0 * dp0;
+            ds1[r] = e1 * dp1;
           }
           pb[j] = pack_b(pr0, pr1);
           dsb[j] = pack_b(ds0, ds1);
@@ -1099,15 +1103,16 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv2_kernel(const bf16_t* __rest
 #pragma unroll
       for (int db = 0; db < 4; ++db) {
         uint2 u;
-        u.x = pack2bf(dk[j][db][0] * scale, dk[j][db][1] * scale);
-        u.y = pack2bf(dk[j][db][2] * scale, dk[j][db][3] * scale);
+        const float ks = scale * dscale;
+        u.x = pack2bf(dk[j][db][0] * ks, dk[j][db][1] * ks);
+        u.y = pack2bf(dk[j][db][2] * ks, dk[j][db][3] * ks);
         *reinterpret_cast<uint2*>(krow + db * 16 + g * 4) = u;
         uint2 w;
-        w.x = pack2bf(dv[j][db][0], dv[j][db][1]);
-        w.y = pack2bf(dv[j][db][2], dv[j][db][3]);
+        w.x = pack2bf(dv[j][db][0] * dscale, dv[j][db][1] * dscale);
+        w.y = pack2bf(dv[j][db][2] * dscale, dv[j][db][3] * dscale);
         *reinterpret_cast<uint2*>(vrow + db * 16 + g * 4) = w;
-        bsk[db] += dk[j][db] * scale;
-        bsv[db] += dv[j][db];
+        bsk[db] += dk[j][db] * ks;
+        bsv[db] += dv[j][db] * dscale;
       }
     }
   }
