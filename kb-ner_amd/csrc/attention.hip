@@ -532,8 +532,10 @@ __global__ __launch_bounds__(AT_NWB * 64) void attn_bwd_dq_kernel(const bf16_t* 
     const size_t sidx = ((size_t)b * A + h) * S + q0 + li;
     const float l_q = lse[sidx] * 1.4426950408889634f;  // log2 domain
     // D = sum_d dO[q,d] O[q,d]: each lane group g holds 16 of the 64 d of row q0+li in its two fragments
-    const float d_q = group4_sum(dot8(do0, glb_frag(ob, H, q0, 0, lane)) + dot8(do1, glb_frag(ob, H, q0, 1, lane)));
-    if (g == 0) Dv[sidx] = d_q;
+    const float d_true = group4_sum(dot8(do0, glb_frag(ob, H, q0, 0, lane)) + dot8(do1, glb_frag(ob, H, q0, 1, lane)));
+    if (g == 0) Dv[sidx] = d_true;
+    // dropout: dS = (1 / (1-p)) P (m dP - (1-p) D) -- the 1 / (1-p) leaves through the final dQ scale (see attn_bwd_dq2_kernel)
+    const float d_q = DROP ? d_true * (1.0f / dscale) : d_true;
     const uint32_t rk = DROP ? drop_rowkey(drop_seed, bhS + (uint32_t)(q0 + li)) : 0u;
     f4v dq[4];
 #pragma unroll
@@ -551,7 +553,7 @@ __global__ __launch_bounds__(AT_NWB * 64) void attn_bwd_dq_kernel(const bf16_t* 
   P1 = MFMA(kc_at(pV.kc[1], (CO) + 2048), do1, P1)
     const f4v zero4 = (f4v){0.f, 0.f, 0.f, 0.f};
     // without dropout the dP accumulators START at -D (one query per lane): dS = P * (dP - D) loses its subtraction
-    const f4v pinit = DROP ? zero4 : (f4v){-d_q, -d_q, -d_q, -d_q};
+    const f4v pinit = (f4v){-d_q, -d_q, -d_q, -d_q};
     f4v s0, s1, p0, p1;
     DQ_SP(s0, s1, p0, p1, 0);
     for (int kc = 0; kc < nkc; ++kc) {
@@ -579,11 +581,11 @@ __global__ __launch_bounds__(AT_NWB * 64) void attn_bwd_dq_kernel(const bf16_t* 
         const float pr1 = __builtin_amdgcn_exp2f(s1[r] * scale2 + mb1[r] - l_q);
         float dp0 = p0[r], dp1 = p1[r];
         if (DROP) {
-          dp0 = drop_keep(rk, ck0[r], drop_thresh) ? dp0 * dscale : 0.0f;
-          dp1 = drop_keep(rk, ck1[r], drop_thresh) ? dp1 * dscale : 0.0f;
+          dp0 = drop_keep(rk, ck0[r], drop_thresh) ? dp0 : -d_q;
+          dp1 = drop_keep(rk, ck1[r], drop_thresh) ? dp1 : -d_q;
         }
-        ds0[r] = DROP ? pr0 * (dp0 - d_q) : pr0 * dp0;
-        ds1[r] = DROP ? pr1 * (dp1 - d_q) : pr1 * dp1;
+        ds0[r] = pr0 * dp0;
+        ds1[r] = pr1 * dp1;
       }
       const bf16x8 dsb = pack_b(ds0, ds1);
 #pragma unroll
@@ -595,10 +597,11 @@ __global__ __launch_bounds__(AT_NWB * 64) void attn_bwd_dq_kernel(const bf16_t* 
 #pragma unroll
     for (int db = 0; db < 4; ++db) {
       uint2 u;
-      u.x = pack2bf(dq[db][0] * scale, dq[db][1] * scale);
-      u.y = pack2bf(dq[db][2] * scale, dq[db][3] * scale);
+      const float os = scale * dscale;
+      u.x = pack2bf(dq[db][0] * os, dq[db][1] * os);
+      u.y = pack2bf(dq[db][2] * os, dq[db][3] * os);
       *reinterpret_cast<uint2*>(orow + db * 16 + g * 4) = u;
-      bsum[db] += dq[db] * scale;
+      bsum[db] += dq[db] * os;
     }
   }
   if (dbias != nullptr) flush_colsum<AT_NWB>(bsum, red, dbias + h * AT_D, wid, lane, tid);
@@ -636,7 +639,7 @@ __global__ __launch_bounds__(AT_NWB * 64) void attn_bwd_dkv_kernel(const bf16_t*
   const float dscale = DROP ? drop_scale(drop_thresh) : 1.0f;
   for (int i = tid; i < S; i += AT_NWB * 64) {
     sL[i] = lse[sbase + i] * 1.4426950408889634f;  // log2 domain
-    sD[i] = -Dv[sbase + i];  // negated: the dP accumulators start at -D (no-dropout variant), dS = P * (dP + (-D)) otherwise
+    sD[i] = -Dv[sbase + i] * (1.0f / dscale);  // the dP accumulators start at -(1-p) D (= -D without dropout)
     if (DROP) sRk[i] = drop_rowkey(drop_seed, bhS + (uint32_t)i);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -667,9 +670,9 @@ __global__ __launch_bounds__(AT_NWB * 64) void attn_bwd_dkv_kernel(const bf16_t*
   S0 = MFMA(kc_at(pQ.kc[1], (CO)), kf1, S0);             \
   S1 = MFMA(kc_at(pQ.kc[0], (CO) + 2048), kf0, zero4);   \
   S1 = MFMA(kc_at(pQ.kc[1], (CO) + 2048), kf1, S1);      \
-  P0 = MFMA(kc_at(pO.kc[0], (CO)), vf0, DROP ? zero4 : nd_at((CO), 0));  \
+  P0 = MFMA(kc_at(pO.kc[0], (CO)), vf0, nd_at((CO), 0));  \
   P0 = MFMA(kc_at(pO.kc[1], (CO)), vf1, P0);             \
-  P1 = MFMA(kc_at(pO.kc[0], (CO) + 2048), vf0, DROP ? zero4 : nd_at((CO), 16)); \
+  P1 = MFMA(kc_at(pO.kc[0], (CO) + 2048), vf0, nd_at((CO), 16)); \
   P1 = MFMA(kc_at(pO.kc[1], (CO) + 2048), vf1, P1)
     const f4v zero4 = (f4v){0.f, 0.f, 0.f, 0.f};
     f4v s0, s1, p0, p1;
@@ -703,13 +706,13 @@ __global__ __launch_bounds__(AT_NWB * 64) void attn_bwd_dkv_kernel(const bf16_t*
         pr1[r] = e1;
         if (DROP) {  // dV sees mask * P / (1-p); dS = P * (mask * dP / (1-p) - D)
           const bool k0_ = drop_keep(rk0[r], ck, drop_thresh), k1_ = drop_keep(rk1[r], ck, drop_thresh);
-          pr0[r] = k0_ ? e0 * dscale : 0.0f;
-          pr1[r] = k1_ ? e1 * dscale : 0.0f;
-          dp0 = k0_ ? dp0 * dscale : 0.0f;
-          dp1 = k1_ ? dp1 * dscale : 0.0f;
+          pr0[r] = k0_ ? e0 : 0.0f;
+          pr1[r] = k1_ ? e1 : 0.0f;
+          dp0 = k0_ ? dp0 : da[r];     // da / dbv hold -(1-p) D, the accumulators' start value
+          dp1 = k1_ ? dp1 : dbv[r];
         }
-        ds0[r] = DROP ? e0 * (dp0 + da[r]) : e0 * dp0;   // da / dbv hold -D
-        ds1[r] = DROP ? e1 * (dp1 + dbv[r]) : e1 * dp1;
+        ds0[r] = e0 * dp0;
+        ds1[r] = e1 * dp1;
       }
       const bf16x8 pb = pack_b(pr0, pr1);
       const bf16x8 dsb = pack_b(ds0, ds1);
@@ -727,15 +730,16 @@ __global__ __launch_bounds__(AT_NWB * 64) void attn_bwd_dkv_kernel(const bf16_t*
 #pragma unroll
     for (int db = 0; db < 4; ++db) {
       uint2 u;
-      u.x = pack2bf(dk[db][0] * scale, dk[db][1] * scale);
-      u.y = pack2bf(dk[db][2] * scale, dk[db][3] * scale);
+      const float ks = scale * dscale;
+      u.x = pack2bf(dk[db][0] * ks, dk[db][1] * ks);
+      u.y = pack2bf(dk[db][2] * ks, dk[db][3] * ks);
       *reinterpret_cast<uint2*>(krow + db * 16 + g * 4) = u;
       uint2 w;
-      w.x = pack2bf(dv[db][0], dv[db][1]);
-      w.y = pack2bf(dv[db][2], dv[db][3]);
+      w.x = pack2bf(dv[db][0] * dscale, dv[db][1] * dscale);
+      w.y = pack2bf(dv[db][2] * dscale, dv[db][3] * dscale);
       *reinterpret_cast<uint2*>(vrow + db * 16 + g * 4) = w;
-      bsk[db] += dk[db] * scale;
-      bsv[db] += dv[db];
+      bsk[db] += dk[db] * ks;
+      bsv[db] += dv[db] * dscale;
     }
   }
   if (dbias != nullptr) {
