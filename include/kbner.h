@@ -163,6 +163,7 @@ int kbner_dropout_mask(float* out, int Z, int M, int N, uint32_t seed, uint32_t 
 #define KBNER_GEMM_TN 2 /* C[M,N] = Amem[K,M]^T . Bmem[K,N]   wgrad    */
 #define KBNER_EPI_BIAS 1
 #define KBNER_EPI_GELU 2 /* C = gelu(pre), out2 = gelu'(pre) as bf16, pre = bf16(alpha*acc + bias): the derivative is saved, not the pre-activation */
+#define KBNER_EPI_GELU_FWD 1024 /* C = gelu(pre) alone, no derivative output: the forward of inference (evaluate, frozen encoders) */
 #define KBNER_EPI_ADD 4
 #define KBNER_EPI_DGELU 8 /* C = (alpha*acc) * aux, aux = the gelu'(pre) saved by KBNER_EPI_GELU (BertIntermediate's gelu backward) */
 #define KBNER_EPI_ATOMIC32 16

@@ -23,6 +23,7 @@
 #define EPI_BIAS 1     // + bias[n]
 #define EPI_GELU 2     // C = gelu(pre), out2 = gelu'(pre) (bf16)
 #define EPI_ADD 4      // + addend[m,n] (bf16)
+#define EPI_GELU_FWD 1024  // C = gelu(pre) alone (inference)
 #define EPI_DGELU 8    // * aux[m,n]  (aux = the gelu'(pre) the forward epilogue stored)
 #define EPI_ATOMIC32 16  // atomicAdd into C32 (fp32), no bf16 output
 #define EPI_DROP 128     // dropout on (acc*alpha + bias) before the residual add
@@ -213,6 +214,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
         v[1] *= __uint_as_float(u.x & 0xffff0000u);
         v[2] *= __uint_as_float(u.y << 16);
         v[3] *= __uint_as_float(u.y & 0xffff0000u);
+      }
+      if (epi & EPI_GELU_FWD) {
+        const f2v y0 = gelu2(unpack2bf(pack2bf(v[0], v[1]))), y1 = gelu2(unpack2bf(pack2bf(v[2], v[3])));
+        v[0] = y0[0]; v[1] = y0[1]; v[2] = y1[0]; v[3] = y1[1];
       }
       if (epi & EPI_GELU) {
         // C = gelu(pre), out2 = gelu'(pre), both evaluated at the bf16-rounded pre-activation (same as gemm256.hip)

@@ -21,6 +21,7 @@
 #define EPI_STORE32 256  // C32[m,n] = result (fp32, plain stores): one split-K slab, summed by kbner_splitk_finish
 #define EPI_COLSUM_WS 512  // with EPI_COLSUM: colsum is a workspace f32 [2 * M/256, N]; row 2*tile_row + wave_row receives this
                            // tile's column sums by plain stores (no atomics); kbner_colsum_rows_f32 folds the rows afterwards
+#define EPI_GELU_FWD 1024  // C = gelu(pre), NO derivative output: the forward of inference (evaluate, frozen stack encoders)
 #define EPI_DROP 128   // dropout on (acc*alpha + bias) BEFORE the residual add (BertSelfOutput / BertOutput); not with COLSUM
 
 #define G2_MAXP 16
@@ -344,6 +345,14 @@ static __device__ __forceinline__ void epilogue256(const GemmProblem& g, f4v (&a
           v[2 * r + 1] *= gg[1];
         }
       }
+      if (epi & EPI_GELU_FWD) {   // inference: the activation alone (no erf derivative, no second output)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const f2v y = gelu2(unpack2bf(pack2bf(v[2 * r], v[2 * r + 1])));
+          v[2 * r] = y[0];
+          v[2 * r + 1] = y[1];
+        }
+      }
       if (epi & EPI_GELU) {
         // C = gelu(pre), out2 = gelu'(pre), both evaluated at the bf16-rounded pre-activation
         uint4 du;
@@ -607,6 +616,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GroupArgs ga) {
       case 0: epilogue256<0, MI>(g, acc, m0, n0, wm, wn, lane, scr); break;
       case EPI_BIAS: epilogue256<EPI_BIAS, MI>(g, acc, m0, n0, wm, wn, lane, scr); break;
       case EPI_BIAS | EPI_GELU: epilogue256<(EPI_BIAS | EPI_GELU), MI>(g, acc, m0, n0, wm, wn, lane, scr); break;
+      case EPI_BIAS | EPI_GELU_FWD: epilogue256<(EPI_BIAS | EPI_GELU_FWD), MI>(g, acc, m0, n0, wm, wn, lane, scr); break;
       case EPI_BIAS | EPI_ADD: epilogue256<(EPI_BIAS | EPI_ADD), MI>(g, acc, m0, n0, wm, wn, lane, scr); break;
       case EPI_BIAS | EPI_ADD | EPI_DROP: epilogue256<(EPI_BIAS | EPI_ADD | EPI_DROP), MI>(g, acc, m0, n0, wm, wn, lane, scr); break;
       default: epilogue256<-1, MI>(g, acc, m0, n0, wm, wn, lane, scr); break;
@@ -730,7 +740,8 @@ static int gemm_grouped_impl(int layout, int nprob, const kbner_gemm_problem* pr
     if (s.epi & EPI_COLSUM) KBNER_CHECK_ARG(s.colsum != nullptr && !(s.epi & (EPI_ATOMIC32 | EPI_RMW32 | EPI_STORE32)));
     if (s.epi & EPI_COLSUM_WS) KBNER_CHECK_ARG((s.epi & EPI_COLSUM) != 0 && s.N % 4 == 0);
     if (s.epi & EPI_STORE32) KBNER_CHECK_ARG(s.epi == EPI_STORE32);
-    if (s.epi & EPI_DROP) KBNER_CHECK_ARG(!(s.epi & (EPI_ATOMIC32 | EPI_RMW32 | EPI_COLSUM | EPI_GELU | EPI_DGELU)));
+    if (s.epi & EPI_DROP) KBNER_CHECK_ARG(!(s.epi & (EPI_ATOMIC32 | EPI_RMW32 | EPI_COLSUM | EPI_GELU | EPI_DGELU | EPI_GELU_FWD)));
+    if (s.epi & EPI_GELU_FWD) KBNER_CHECK_ARG(!(s.epi & (EPI_GELU | EPI_DGELU | EPI_ATOMIC32 | EPI_RMW32 | EPI_STORE32 | EPI_COLSUM)));
     GemmProblem& d = ga.p[i];
     d.A = s.A; d.B = s.B; d.C = s.C; d.C32 = s.C32; d.bias = s.bias; d.addend = s.addend; d.aux = s.aux; d.out2 = s.out2; d.colsum = s.colsum;
     d.M = s.M; d.N = s.N; d.K = s.K; d.lda = s.lda; d.ldb = s.ldb; d.ldc = s.ldc; d.ldc32 = s.ldc32; d.ldadd = s.ldadd;

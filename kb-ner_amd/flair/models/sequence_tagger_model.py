@@ -273,14 +273,14 @@ class SequenceTagger(flair.nn.Model):
                 hb = kb.assemble(ids, am, first, np.zeros(first.shape, np.int64), lens, None, first_row=first_row)
                 db = kb.to_device(hb, flair.device)
                 enc = self._encoder_for(emb)
-                hidden = enc.encoder_forward(db["ids"], db["pos_ids"], db["maskbias"], db["R"], db["S"])
+                hidden = enc.encoder_forward(db["ids"], db["pos_ids"], db["maskbias"], db["R"], db["S"], need_grad=False)
                 ops.gather_rows_into(hidden, db["row_idx"], X, col, enc.cfg.hidden_size)
             elif isinstance(emb, BertEmbeddings):
                 ids, am, first, lens = emb.prepare_stack_batch(sentences)
                 hb = kb.assemble(ids, am, first, np.zeros(first.shape, np.int64), lens, None, position_mode="absolute")
                 db = kb.to_device(hb, flair.device)
                 enc = self._encoder_for(emb)
-                enc.encoder_forward(db["ids"], db["pos_ids"], db["maskbias"], db["R"], db["S"])
+                enc.encoder_forward(db["ids"], db["pos_ids"], db["maskbias"], db["R"], db["S"], need_grad=False)
                 states = enc.acts(db["R"], db["S"]).x      # hidden_states[0..L] (0 = embedding output)
                 Hh = enc.cfg.hidden_size
                 for j, li in enumerate(emb.layer_indexes):  # concatenated in the order `layers` lists them (:2843-2858)

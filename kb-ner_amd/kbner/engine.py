@@ -16,7 +16,7 @@ import torch
 
 from . import lib as L_
 from . import ops
-from .lib import EPI_ADD, EPI_ATOMIC32, EPI_BIAS, EPI_COLSUM, EPI_COLSUM_WS, EPI_DGELU, EPI_GELU, EPI_RMW32, GEMM_NN, GEMM_NT, GEMM_TN
+from .lib import EPI_ADD, EPI_ATOMIC32, EPI_BIAS, EPI_COLSUM, EPI_COLSUM_WS, EPI_DGELU, EPI_GELU, EPI_GELU_FWD, EPI_RMW32, GEMM_NN, GEMM_NT, GEMM_TN
 
 BF16, F32, I32 = torch.bfloat16, torch.float32, torch.int32
 
@@ -372,8 +372,10 @@ class Tagger:
             ops.gemm(layout, A, W, Mp, N, K, C=C, bias=bias, addend=addend, epi=epi, drop=drop, occupancy=True)
 
     # ---------------------------------------------------------------- encoder
-    def encoder_forward(self, ids, pos_ids, maskbias, B, S):
-        """ids/pos_ids i32[Mp], maskbias f32[B,S] -> last hidden state bf16 [Mp,H] (rows >= B*S are padding)."""
+    def encoder_forward(self, ids, pos_ids, maskbias, B, S, need_grad=True):
+        """ids/pos_ids i32[Mp], maskbias f32[B,S] -> last hidden state bf16 [Mp,H] (rows >= B*S are padding).
+        need_grad=False (inference: evaluate, the frozen encoders of an embedding stack) runs the FFN-up epilogue without the
+        gelu' output that only encoder_backward reads; a backward after such a forward fails loudly."""
         cfg, a = self.cfg, self.arena
         H, F_, A, L = cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads, cfg.num_hidden_layers
         ac = self.acts(B, S)
@@ -391,12 +393,16 @@ class Tagger:
             ops.gemm(GEMM_NT, ac.ctx[l], a.bf(p + "o.weight"), Mp, H, H, C=ac.h1[l], bias=a.param(p + "o.bias"), addend=x,
                      epi=EPI_BIAS | EPI_ADD, drop=d_o, occupancy=True)
             ops.ln_fwd(ac.h1[l], a.param(p + "ln1.g"), a.param(p + "ln1.b"), eps, ac.x1[l], ac.st1[l][0], ac.st1[l][1])
-            ops.gemm(GEMM_NT, ac.x1[l], a.bf(p + "ffn1.weight"), Mp, F_, H, C=ac.act[l], out2=ac.dact[l],
-                     bias=a.param(p + "ffn1.bias"), epi=EPI_BIAS | EPI_GELU, occupancy=True)
+            if need_grad:
+                ops.gemm(GEMM_NT, ac.x1[l], a.bf(p + "ffn1.weight"), Mp, F_, H, C=ac.act[l], out2=ac.dact[l],
+                         bias=a.param(p + "ffn1.bias"), epi=EPI_BIAS | EPI_GELU, occupancy=True)
+            else:
+                ops.gemm(GEMM_NT, ac.x1[l], a.bf(p + "ffn1.weight"), Mp, F_, H, C=ac.act[l],
+                         bias=a.param(p + "ffn1.bias"), epi=EPI_BIAS | EPI_GELU_FWD, occupancy=True)
             self._long_k_gemm(GEMM_NT, ac.act[l], a.bf(p + "ffn2.weight"), Mp, H, F_, ac.h2[l], ac, bias=a.param(p + "ffn2.bias"),
                               addend=ac.x1[l], drop=d_f)
             ops.ln_fwd(ac.h2[l], a.param(p + "ln2.g"), a.param(p + "ln2.b"), eps, ac.x[l + 1], ac.st2[l][0], ac.st2[l][1])
-        self._enc_saved = (ids, pos_ids, maskbias, B, S, d_emb, d_layers)
+        self._enc_saved = (ids, pos_ids, maskbias, B, S, d_emb, d_layers) if need_grad else None
         return ac.x[L]
 
     def encoder_backward(self, dx_top, grad_ready=None):
@@ -406,6 +412,8 @@ class Tagger:
         bucket's all-reduce while backward continues below (kbner.dp.GradReducer)."""
         cfg, a = self.cfg, self.arena
         H, F_, A, L = cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads, cfg.num_hidden_layers
+        if self._enc_saved is None:
+            raise RuntimeError("encoder_backward needs an encoder_forward(need_grad=True) before it (the last forward kept no gelu')")
         ids, pos_ids, maskbias, B, S, d_emb, d_layers = self._enc_saved
         ac = self.acts(B, S)
         Mp = ac.Mp
@@ -735,7 +743,7 @@ class Tagger:
     def forward_features(self, batch):
         """FastSequenceTagger.forward (sequence_tagger_model.py:844): emissions for ALL word tokens."""
         B, S = batch["B"], batch["S"]
-        hidden = self.encoder_forward(batch["ids"], batch["pos_ids"], batch["maskbias"], batch.get("R", B), S)
+        hidden = self.encoder_forward(batch["ids"], batch["pos_ids"], batch["maskbias"], batch.get("R", B), S, need_grad=False)
         n = batch["row_idx"].numel() // B
         em, _ = self.emissions(hidden, batch["row_idx"], B, n)
         return em

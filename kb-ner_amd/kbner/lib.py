@@ -77,6 +77,7 @@ GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 EPI_BIAS, EPI_GELU, EPI_ADD, EPI_DGELU, EPI_ATOMIC32, EPI_RMW32, EPI_COLSUM, EPI_DROP = 1, 2, 4, 8, 16, 32, 64, 128
 EPI_STORE32 = 256
 EPI_COLSUM_WS = 512
+EPI_GELU_FWD = 1024
 
 
 class GemmProblem(ctypes.Structure):

@@ -13,7 +13,7 @@ for _p in (ROOT, os.path.join(ROOT, "kb-ner_amd")):
 
 from kbner import batch as kb  # noqa: E402
 from kbner import engine, ops  # noqa: E402
-from kbner.lib import EPI_ADD, EPI_ATOMIC32, EPI_BIAS, EPI_DGELU, EPI_GELU, EPI_RMW32, GEMM_NN, GEMM_NT, GEMM_TN  # noqa: E402
+from kbner.lib import EPI_ADD, EPI_ATOMIC32, EPI_BIAS, EPI_DGELU, EPI_GELU, EPI_GELU_FWD, EPI_RMW32, GEMM_NN, GEMM_NT, GEMM_TN  # noqa: E402
 
 BF16, F32, I32 = torch.bfloat16, torch.float32, torch.int32
 DEV = "cuda"
@@ -92,6 +92,8 @@ def check_gemm(layout, M, N, K, epi=0, splitk=1, seed=0, drop_p=0.0):
         cdf = 0.5 * (1 + torch.erf(pre / np.sqrt(2.0)))
         ref_pre = cdf + pre * torch.exp(-0.5 * pre * pre) / np.sqrt(2 * np.pi)   # out2 = gelu'(pre)
         ref = torch.nn.functional.gelu(pre)
+    if epi & EPI_GELU_FWD:  # the activation alone, at the bf16-rounded pre-activation like EPI_GELU
+        ref = torch.nn.functional.gelu(ref.float().to(BF16).double())
     if epi & (EPI_ATOMIC32 | EPI_RMW32):
         C32 = torch.full((M, N), 1.0, dtype=F32, device=DEV)
         ops.gemm(layout, Ad, Bd, M, N, K, C32=C32, epi=epi, splitk=splitk, **kw)

@@ -35,6 +35,8 @@ def test_probe_mfma_layout(st):
     # persistent path: more tiles than CUs (tile-boundary prefetch + counted vmcnt over the epilogue stores)
     (0, 4096, 5120, 128, 1 | 2, 1), (0, 8192, 2560, 192, 1 | 4, 1), (1, 4096, 5120, 128, 8, 1), (1, 5120, 4096, 64, 4, 1),
     (2, 5120, 4096, 128, 32, 1), (2, 4096, 5120, 64, 16, 1), (0, 16384, 4096, 64, 0, 1),
+    # inference epilogue: gelu without the derivative output (128 kernel, 256 kernel, persistent)
+    (0, 128, 384, 64, 1 | 1024, 1), (0, 512, 256, 128, 1 | 1024, 1), (0, 4096, 5120, 128, 1 | 1024, 1),
 ])
 def test_gemm(st, layout, M, N, K, epi, sk):
     # tolerance: bf16 output rounding (2^-9 relative per element) on fp32-accumulated products
@@ -260,6 +262,14 @@ def test_encoder_d64_three_layers_vs_hf_golden(golden_dir):
         errs.append(float(np.linalg.norm(out[valid] - ref[valid]) / np.linalg.norm(ref[valid])))
     print("encoder_d64 per-layer rel L2:", errs)
     assert max(errs) < 2e-2, errs
+    # the inference forward (FFN-up epilogue without the gelu' output) gives the SAME bits, and refuses a backward
+    keep = [x.clone() for x in ac.x]
+    tg.encoder_forward(bd["ids"], bd["pos_ids"], bd["maskbias"], b["B"], b["S"], need_grad=False)
+    torch.cuda.synchronize()
+    for l in range(L + 1):
+        assert torch.equal(keep[l], ac.x[l]), l
+    with pytest.raises(RuntimeError):
+        tg.encoder_backward(torch.zeros_like(ac.x[L]))
 
 
 def test_full_step_vs_oracle(st):

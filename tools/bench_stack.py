@@ -58,7 +58,7 @@ def measure(encoders=3, lms=4, reps=3, lm_hidden=2048):
         lens = torch.full((B,), nn, dtype=torch.int32, device=dev)
 
         def enc_vit():
-            hid = encs[0].encoder_forward(b["ids"], b["pos_ids"], b["maskbias"], B, 512)
+            hid = encs[0].encoder_forward(b["ids"], b["pos_ids"], b["maskbias"], B, 512, need_grad=False)
             em, _ = encs[0].emissions(hid, idx, B, nn)
             return encs[0].viterbi(em, lens)
         dt = timed(enc_vit, a.reps)
@@ -108,7 +108,7 @@ def measure(encoders=3, lms=4, reps=3, lm_hidden=2048):
 
     def run_encoders():
         for i, e in enumerate(encs):
-            hid = e.encoder_forward(b["ids"], b["pos_ids"], b["maskbias"], B, 512)
+            hid = e.encoder_forward(b["ids"], b["pos_ids"], b["maskbias"], B, 512, need_grad=False)
             ops.gather_rows_into(hid, idx, X, head.cols[i], cfg.hidden_size)
 
     lm_group = stack.CharLMGroup(lms) if lms else None
