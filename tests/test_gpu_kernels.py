@@ -746,6 +746,54 @@ def test_kd_loss_vs_oracle(B, n, T, tau, K):
     assert np.abs(dtr.cpu().numpy() - ref).max() <= 3 * tol * max(1e-3, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("B,n", [(32, 450), (4, 512)])
+def test_kd_kernels_full_size_properties(B, n):
+    """the distillation kernels at the sizes the path really runs (KD terms cover ALL word tokens of a knowledge-augmented sentence:
+    n ~ 300-450, T = 29), where the fp64 autograd restatement takes minutes -- size-independent properties instead:
+    (a) every position's forward-backward scores log-sum to the sentence's log-partition (kbner_crf_nll_fwd);
+    (b) every pair posterior is a distribution over the T x T tag pairs;
+    (c) a student that IS the teacher has zero posterior-KL loss and gradient;
+    (d) at temperature 1 the exact term's gradient vanishes for a student that is the teacher (its loss is the path entropy > 0)."""
+    from kbner import ops
+    from oracle import crf as ocrf
+    T, start, stop = 29, 27, 28
+    rng = np.random.default_rng(1000 * B + n)
+    trans = torch.from_numpy(ocrf.init_transitions(T, start, stop, rng).astype(np.float32)).cuda()
+    em = torch.from_numpy(rng.standard_normal((B, n, T)).astype(np.float32)).cuda()
+    lens_h = rng.integers(n // 2, n + 1, size=B)
+    lens_h[0], lens_h[-1] = n, 1
+    lens = torch.from_numpy(lens_h.astype(np.int32)).cuda()
+    valid = (torch.arange(n, device="cuda")[None, :] < lens[:, None])
+    w = torch.full((B,), 1.0 / B, device="cuda")
+    # (a)
+    score = ops.crf_fb_score(em, trans, lens, start, stop)
+    logz, _, _ = ops.crf_nll_fwd(em, trans, torch.zeros((B, n), dtype=torch.int32, device="cuda"), lens, start, stop)
+    lse = torch.logsumexp(score.double(), dim=-1)
+    dev = ((lse - logz.double()[:, None]).abs() * valid).max().item()
+    assert dev <= 2e-6 * n * max(1.0, float(logz.abs().max())) / 100.0 + 1e-3, dev
+    assert float((score * ~valid[:, :, None]).abs().max()) == 0.0          # zero past the sentence
+    # (b)
+    pair, s_sc, e_sc = ops.crf_pair_posterior(em, trans, lens, 1.0, start, stop)
+    pv = torch.arange(n - 1, device="cuda")[None, :] < (lens - 1)[:, None]
+    tot = pair.double().sum(-1)
+    assert float(((tot - 1.0).abs() * pv).max()) < 1e-4 and float(pair.min()) >= 0.0
+    # ... and its marginal over the previous tag is the token posterior of (a)
+    marg = pair.view(B, n - 1, T, T).double().sum(-1)                    # [to, from] summed over from
+    post = torch.softmax(score.double(), dim=-1)[:, 1:]
+    assert float(((marg - post).abs() * pv[:, :, None]).max()) < 1e-3
+    # (c)
+    dtr = torch.zeros((T, T), device="cuda")
+    loss, de = ops.crf_posterior_kl_scores(em, score, trans, lens, w, 3.0, start, stop, dtr)
+    assert float(loss.abs().max()) < 1e-3 * max(1.0, n / 100.0), float(loss.abs().max())
+    assert float(de.abs().max()) < 1e-4 and float(dtr.abs().max()) < 1e-3, (float(de.abs().max()), float(dtr.abs().max()))
+    # (d)
+    dtr.zero_()
+    loss, de = ops.crf_exact_kd(em, trans, lens, pair, s_sc, e_sc, w, 1.0, start, stop, dtr)
+    torch.cuda.synchronize()
+    assert float(loss.min()) >= 0.0
+    assert float(de.abs().max()) < 2e-4 and float(dtr.abs().max()) < 2e-3, (float(de.abs().max()), float(dtr.abs().max()))
+
+
 def test_multiview_exact_and_l2_vs_reference_golden(golden_dir):
     """the distill_exact branch of the multi-view loss (Tagger.distill_terms mode "exact": kbner_crf_pair_posterior of the context
     view under the shared transitions + kbner_crf_exact_kd) and the calculate_l2_loss / l2_loss_only term (kbner_l2_rows, forward +
