@@ -59,14 +59,14 @@ __global__ __launch_bounds__(512, 2) void k(const unsigned short* A, const unsig
   for (int i = 0; i < 16; ++i) acc[i] = (f4v){0.f, 0.f, 0.f, 0.f};
   issue(0, smem);
   for (int t = 0; t < ktiles; ++t) {
-    if (touch && t > 0) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");   // (non-touching waves: conservative, their last op is a DMA piece -- wait for it below)
-    if (!touch || t == 0 || !(touch == 1 || (wid >= 4 ? (local & 7) == 0 : (local >> 3) == 0))) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (touch && touch != 9 && t > 0) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");   // (non-touching waves: conservative, their last op is a DMA piece -- wait for it below)
+    if (!touch || touch == 9 || t == 0 || !(touch == 1 || (wid >= 4 ? (local & 7) == 0 : (local >> 3) == 0))) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     unsigned char* cur = smem + (t & 1) * 65536;
     unsigned char* nxt = smem + ((t + 1) & 1) * 65536;
-    if (t + 1 < ktiles) issue(t + 1, nxt);
-    if (touch) {
+    if (t + 1 < ktiles && touch != 9) issue(t + 1, nxt);
+    if (touch && touch != 9) {
       const int tt = min(t + dist, ktiles - 1);
       const bool isb = wid >= 4;
       const bool mine = touch == 1 || (isb ? (local & 7) == 0 : (local >> 3) == 0);
@@ -105,6 +105,98 @@ __global__ __launch_bounds__(512, 2) void k(const unsigned short* A, const unsig
   }
 }
 
+
+// Ring variant (round 2's five-slot idea, here with all 160 KiB of LDS: 3 A slots + 2 B slots of 32 KiB): the A slice is issued TWO
+// steps ahead, the B slice one; issue order inside a step is B(t+1) then A(t+2) so that the counted wait at the next step
+// (vmcnt = the 4 A pieces just issued) covers B(t+1) and the older A(t+1).  SPREAD 1: A(t+2) is issued after half of the step's
+// MFMAs instead of right after the barrier.
+template <int READS, int MFMA, int SPREAD>
+__global__ __launch_bounds__(512, 2) void kring(const unsigned short* A, const unsigned short* B, int ld, int ktiles, int share,
+                                                int a_rows_total, int a_row_base, float* sink) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+  const int apanel = share == 4 ? xcd * 8 + (local & 7) : (int)blockIdx.x;
+  const int bpanel = share == 4 ? (local >> 3) : (int)(blockIdx.x & 15);
+  const size_t arow0 = (size_t)a_row_base + (size_t)(apanel * 256) % a_rows_total;
+  unsigned voff[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int q = wid * 4 + j;
+    const int row = q * 8 + (lane >> 3), pos = lane & 7;
+    voff[j] = (unsigned)(row * ld + ((pos ^ ((row >> 1) & 7)) << 3)) * 2u;
+  }
+  auto issueA = [&](int t) {
+    glds16x4(A + arow0 * ld + (size_t)t * 64, voff[0], voff[1], voff[2], voff[3], smem + (t % 3) * 32768 + wid * 4096);
+  };
+  auto issueB = [&](int t) {
+    glds16x4(B + (size_t)(bpanel * 256) * ld + (size_t)t * 64, voff[0], voff[1], voff[2], voff[3], smem + 98304 + (t & 1) * 32768 + wid * 4096);
+  };
+  f4v acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = (f4v){0.f, 0.f, 0.f, 0.f};
+  issueA(0);
+  issueB(0);
+  if (ktiles > 1) issueA(1);
+  for (int t = 0; t < ktiles; ++t) {
+    if (t + 1 < ktiles) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // only A(t+1) may still fly
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const unsigned char* ca = smem + (t % 3) * 32768;
+    const unsigned char* cb = smem + 98304 + (t & 1) * 32768;
+    if (t + 1 < ktiles) issueB(t + 1);
+    if (SPREAD == 0 && t + 2 < ktiles) issueA(t + 2);
+    constexpr int NR = READS > 0 ? READS : 2;
+    bf16x8 f[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      const unsigned char* src = (i & 1) ? cb : ca;
+      const s8v v = *reinterpret_cast<const s8v*>(src + ((wid * 7 + i) & 31) * 1024 + lane * 16);
+      f[i] = __builtin_bit_cast(bf16x8, v);
+    }
+    if constexpr (MFMA > 0) {
+#pragma unroll
+      for (int i = 0; i < MFMA / 2; ++i) acc[i & 15] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[i % NR], f[(i * 5 + 1) % NR], acc[i & 15], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (SPREAD == 1 && t + 2 < ktiles) issueA(t + 2);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = MFMA / 2; i < MFMA; ++i) acc[i & 15] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[i % NR], f[(i * 5 + 1) % NR], acc[i & 15], 0, 0, 0);
+    } else {
+      if (SPREAD == 1 && t + 2 < ktiles) issueA(t + 2);
+#pragma unroll
+      for (int i = 0; i < NR; ++i) asm volatile("" ::"v"(f[i]));
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (MFMA > 0) {
+    float s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s2 += acc[i][0];
+    if (s2 == 123.456f) sink[0] = s2;
+  }
+}
+
+template <int READS, int MFMA, int SPREAD>
+static void run_ring(const char* what, const unsigned short* A, const unsigned short* B, int K, int src, float* sink) {
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(kring<READS, MFMA, SPREAD>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+  const int ktiles = K / 64;
+  float best = 1e9;
+  for (int rep = 0; rep < 5; ++rep) {
+    const int a_rows = src == 0 ? 4096 : 16384;
+    const int base = src == 0 ? 0 : (rep & 3) * 16384;
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((kring<READS, MFMA, SPREAD>), dim3(256), dim3(512), 163840, 0, A, B, K, ktiles, 4, a_rows, base, sink);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    if (rep && ms < best) best = ms;
+  }
+  printf("%-34s A %-8s share 4 reads %2d mfma %2d A-issue %s : %.2f us per K step\n", what, src ? "HBM" : "resident", READS, MFMA,
+         SPREAD ? "mid-step" : "after the barrier", best * 1e3 / ktiles);
+}
+
 template <int READS, int MFMA>
 static void run(const char* what, const unsigned short* A, const unsigned short* B, int K, int src, int share, float* sink, int touch = 0,
                 int dist = 2, int pad = 0) {
@@ -140,6 +232,15 @@ int main() {
   run<24, 64>("DMA + reads + MFMA", A, B, K, 0, 4, sink);
   run<24, 64>("DMA + reads + MFMA", A, B, K, 1, 4, sink);
   run<24, 64>("DMA + reads + MFMA", A, B, K, 1, 1, sink);
+  run<24, 64>("reads + MFMA, NO in-loop DMA (touch 9)", A, B, K, 0, 4, sink, 9);
+  run<24, 0>("reads only, NO in-loop DMA (touch 9)", A, B, K, 0, 4, sink, 9);
+  run_ring<0, 0, 0>("RING: DMA only", A, B, K, 1, sink);
+  run_ring<0, 0, 0>("RING: DMA only", A, B, K, 0, sink);
+  run_ring<24, 64, 0>("RING: DMA + reads + MFMA", A, B, K, 1, sink);
+  run_ring<24, 64, 1>("RING: DMA + reads + MFMA", A, B, K, 1, sink);
+  run_ring<24, 64, 0>("RING: DMA + reads + MFMA", A, B, K, 0, sink);
+  run_ring<24, 64, 1>("RING: DMA + reads + MFMA", A, B, K, 0, sink);
+  run_ring<24, 64, 1>("RING: DMA + reads + MFMA", A, B, K, 1, sink);
   // leading dimension K + pad elements (row stride not a power of two): do the 256 rows of a K slice spread over more channels?
   for (int pad : {0, 64, 128, 192, 256, 8}) {
     run<0, 0>("DMA only", A, B, K, 1, 4, sink, 0, 2, pad);
