@@ -25,6 +25,9 @@
 #define EPI_DROP 128   // dropout on (acc*alpha + bias) BEFORE the residual add (BertSelfOutput / BertOutput); not with COLSUM
 
 #define G2_MAXP 16
+#ifndef KBNER_GEMM_VARIANT_DEFAULT
+#define KBNER_GEMM_VARIANT_DEFAULT 0
+#endif
 
 struct GemmProblem {
   const bf16_t* A;
@@ -224,7 +227,7 @@ static __device__ __forceinline__ void pick_tile(const GroupArgs& ga, int id, in
 // exposes a full memory latency.  Here the flags fold at compile time, the operand loads of row fragment mi+1 are
 // issued before fragment mi is processed, and sched_barriers keep the compiler from interleaving all eight fragments
 // (which spills).
-template <int EPI_CT, int MI = 8>
+template <int EPI_CT, int MI = 8, bool DRAIN = false>
 static __device__ __forceinline__ void epilogue256(const GemmProblem& g, f4v (&acc)[MI][4], int m0, int n0, int wm, int wn,
                                                    int lane, unsigned char* scr) {
   const int epi = EPI_CT >= 0 ? EPI_CT : g.epi;
@@ -429,16 +432,31 @@ static __device__ __forceinline__ void epilogue256(const GemmProblem& g, f4v (&a
       }
     }
   }
+  // The generic variant issues its operand / bias loads and consumes them under runtime flags: hipcc's waitcnt pass (path-
+  // insensitive) must assume a path on which a load is issued and never consumed, carries that "pending" load into the next
+  // tile's main loop and drains vmcnt(0) in front of the first ds_read that reuses its destination register -- i.e. it waits for
+  // the LDS-DMA in flight there (once per tile in gemm256_kernel's peeled first K step, in EVERY K step of the ping-pong loop).
+  // A compiler-visible vmcnt(0) here (DRAIN: the ping-pong kernel's generic variant; it also drains this tile's stores) keeps the state clean;
+  // the specialised variants consume every load on straight-line code.
+  if constexpr (EPI_CT < 0 && DRAIN) __builtin_amdgcn_s_waitcnt(0x0F70);
 }
 
 // -DG2_TRACE (tools/gemm_trace.sh, never the product build): wave 0 stamps s_memtime at tile start / main-loop end /
 // epilogue end so tools/gemm_trace.py can split a persistent workgroup's time per tile.
 #ifdef G2_TRACE
+// effective shader clock of a launch: s_memtime (shader cycles) against s_memrealtime (constant 100 MHz) at workgroup start / end
+__device__ unsigned long long g2_clk[256 * 4];
+#define G2_CLK(slot)                                                                   \
+  if (threadIdx.x == 0 && blockIdx.x < 256) {                                          \
+    g2_clk[blockIdx.x * 4 + (slot) * 2] = __builtin_readcyclecounter();                \
+    g2_clk[blockIdx.x * 4 + (slot) * 2 + 1] = __builtin_amdgcn_s_memrealtime();        \
+  }
 __device__ unsigned long long g2_trace[256 * 32 * 4];
 #define G2_T(slot)                                                                        \
   if (threadIdx.x == 0 && tile_no < 32) g2_trace[(blockIdx.x * 32 + tile_no) * 4 + (slot)] = __builtin_readcyclecounter();
 #else
 #define G2_T(slot)
+#define G2_CLK(slot)
 #endif
 
 // Dynamic tile scheduling (DYN = true; data-parallel training, where RCCL's kernels take CUs away while a bucket is in flight):
@@ -479,6 +497,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GroupArgs ga) {
   // stores run under that flight and the next main loop starts without a cold prologue.
   const int total = ga.total_tiles;
   int id = blockIdx.x;
+  G2_CLK(0)
   if (DYN) {
     if (tid == 0) *s_next = draw_tile(ga.sched, blockIdx.x & 7, total);
     __syncthreads();
@@ -632,11 +651,1091 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GroupArgs ga) {
   }
   G2_T(2)
   ++tile_no;
-  if (!has_next) break;
+  if (!has_next) { G2_CLK(1) break; }
   // stores this wave issued after the in-flight DMA: 2 per 16-row fragment (4 with a second output / fp32 outputs)
   pend = (epi & EPI_ATOMIC32) ? 0 : ((epi & (EPI_GELU | EPI_RMW32 | EPI_STORE32)) ? 4 * MI : 2 * MI);
   id = id_next;
   }  // persistent tile loop
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Round 4: the PING-PONG main loop.  Same tile (256 x 256 x 64, 8 waves of 128 x 64), same LDS images, fragment maps and
+// epilogues as gemm256_kernel; what changes is WHEN a wave does what.  In gemm256_kernel all 8 waves run the same phase at the
+// same time: after each K step's barrier every wave first queues its 8 LDS-DMA pieces (in-order VMEM issue: the 64 pieces of a
+// stage pass the CU's one address pipe at ~16+ cycles each, and a wave cannot issue its fragment reads before its last piece has
+// been accepted), then waits for the first fragments -- ~800-1000 cycles per K step in which no SIMD has an MFMA to issue
+// (measured: 1.55 us per step against 1.03 us of MFMA issue).  Here the two waves of a SIMD (wave w and w + 4: group 0 = waves
+// 0-3 = the tile's upper 128 rows, group 1 = waves 4-7) run HALF A PHASE APART: while one group issues 32 back-to-back MFMAs on
+// fragments it already holds in registers (a "compute" phase: one K = 32 half step of its 128 x 64 sub-tile), the other group
+// does everything that is not an MFMA (a "memory" phase: DMA issue for a later stage, the 8-16 fragment reads of its next
+// compute phase, address arithmetic, the counted waits).  An s_barrier ends every phase and flips the roles, so the matrix pipe
+// of a SIMD always has exactly one wave feeding it and the LDS / VMEM issue of the other wave runs under it.
+//
+// Ring instead of two stages: fragments are held in registers, so a stage's LDS slot is free as soon as both groups have READ it.
+// 160 KiB = 3 A slots + 2 B slots of 32 KiB.  Stage t's B fragments (both k halves) are read in the first memory phase of the
+// stage, which frees B's slot two phases early; per stage and wave: M0 = issue A(t+2), read A(k half 0) + B(both halves);
+// C0 = 32 MFMAs; M1 = issue B(t+2), read A(k half 1); C1 = 32 MFMAs.  A(t+2) has 7-8 phases (two K steps) to land, B(t+2) 5-6
+// -- against one K step in the two-stage loop, whose period was the HBM flight of a stage (tools/micro/dma_mix.hip).
+// The stage counter runs on across tiles (persistent walk): the next tile's first two stages are in flight during the epilogue.
+// The epilogue's per-wave transpose scratch is the wave's own 4 KiB of the A slot the tile consumed last (that slot's next DMA
+// -- stage 2 of the next tile, the wave's own pieces -- is issued by the same wave after its epilogue).
+// Group 1 runs one phase behind group 0: one extra leading barrier at kernel start, one extra trailing barrier for group 0.
+// At a tile boundary group 0 runs its epilogue AFTER the barrier that ends its last compute phase and group 1 BEFORE the
+// barrier that ends the phase after its last compute phase: both epilogues sit in the same barrier interval and overlap.
+#define PP_B_BASE (3 * TILE2_BYTES)
+#define PP_LDS_BYTES (5 * TILE2_BYTES)
+#define PP_FLAG_PRIO 2        // s_setprio 1 around the compute phases
+#define PP_FLAG_STRONGWAIT 4  // debugging: every DMA wait is vmcnt(0)
+#define PP_FLAG_SPEC584 8     // NN: the compile-time-specialised GELU' x + column-sum epilogue (spills ~60 registers) instead of the generic one
+#define PP_FLAG_NODMA 16      // ablation (timing only, wrong results): no LDS-DMA inside the K loop
+#define PP_FLAG_NOMFMA 32     // ablation (timing only, wrong results): no MFMAs
+#define PP_FLAG_NOREADS 128   // ablation (timing only): fragment reads only in the first K step of a tile
+#define PP_FLAG_FINE 2048     // the fine-grained ring loop (gemm256f_kernel)
+#define PP_FLAG_RING 256      // the ring loop (gemm256r_kernel)
+#define PP_FLAG_ROT 64        // the rotated two-barrier loop (gemm256rot_kernel)
+
+static __device__ __forceinline__ void pp_barrier() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("" ::: "memory");
+}
+
+// the per-lane source offsets of a wave's four 1-KiB pieces of an operand tile (stage256's arithmetic, kept apart from the issue)
+template <bool KS, bool ISB>
+static __device__ __forceinline__ void stage_voff(int ld, int wid, int lane, unsigned (&voff)[4]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int q = wid * 4 + j;
+    if (!KS) {
+      const int row = q * 8 + (lane >> 3);
+      const int pos = lane & 7;
+      voff[j] = (unsigned)(row * ld + ((pos ^ (ISB ? kcb_swz(row) : kc_swz(row))) << 3)) * 2u - (unsigned)j * 1024u;
+    } else {
+      const int kr = q * 2 + (lane >> 5);
+      const int pos = lane & 31;
+      voff[j] = (unsigned)(kr * ld + ((pos ^ (ks_swz(kr) << 1)) << 3)) * 2u - (unsigned)j * 1024u;
+    }
+  }
+}
+// piece J of the four (voff already carries the - J KiB of glds16x4's addressing)
+template <int J>
+static __device__ __forceinline__ void glds16_piece(const void* sbase, unsigned voff, unsigned dst) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3"
+               :
+               : "v"(voff), "s"(sbase), "s"(dst), "n"(J * 1024)
+               : "memory", "m0");
+}
+
+template <bool A_KS, bool B_KS, int MODE>
+__global__ __launch_bounds__(512, 2) void gemm256pp_kernel(const GroupArgs ga) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wid >> 2;
+  const int wm = grp, wn = wid & 3;
+  const int total = ga.total_tiles;
+  const int gstep = (int)gridDim.x;
+  const int flags = ga.pad_;
+  const bool prio = (flags & PP_FLAG_PRIO) != 0;
+  const bool strong = (flags & PP_FLAG_STRONGWAIT) != 0;
+  const bool spec584 = (flags & PP_FLAG_SPEC584) != 0;
+  const bool nodma = (flags & PP_FLAG_NODMA) != 0;
+  const bool nomfma = (flags & PP_FLAG_NOMFMA) != 0;
+  const bool noreads = (flags & PP_FLAG_NOREADS) != 0;
+
+  // ---- issue cursor: the (tile, K stage) the next DMA belongs to; runs two stages ahead of the consumer, across tiles
+  int i_id = blockIdx.x, i_t = 0, i_nt = 0, i_m0 = 0, i_n0 = 0, i_lda = 0, i_ldb = 0;
+  const bf16_t* i_A = nullptr;
+  const bf16_t* i_B = nullptr;
+  bool i_valid = true;
+  int ia = 0, ib = 0;   // ring slots of the next issue
+#define PP_ILOAD()                                      \
+  {                                                     \
+    GemmProblem gi;                                     \
+    pick_tile<256>(ga, i_id, total, gi, i_m0, i_n0);    \
+    i_nt = gi.K / BK2;                                  \
+    i_A = gi.A;                                         \
+    i_B = gi.B;                                         \
+    i_lda = gi.lda;                                     \
+    i_ldb = gi.ldb;                                     \
+  }
+#define PP_ISSUE_A()                                                                                   \
+  {                                                                                                    \
+    stage256<A_KS, false, 256>(i_A, i_lda, i_m0, i_t * BK2, smem + ia * TILE2_BYTES, wid, lane_m);      \
+    ia = (ia == 2) ? 0 : ia + 1;                                                                       \
+  }
+#define PP_ISSUE_B()                                                                                         \
+  {                                                                                                          \
+    stage256<B_KS, true>(i_B, i_ldb, i_n0, i_t * BK2, smem + PP_B_BASE + ib * TILE2_BYTES, wid, lane_m);      \
+    ib ^= 1;                                                                                                 \
+  }
+#define PP_IADV()                 \
+  {                               \
+    if (++i_t == i_nt) {          \
+      i_t = 0;                    \
+      i_id += gstep;              \
+      if (i_id < total) PP_ILOAD() \
+      else i_valid = false;       \
+    }                             \
+  }
+#define PP_WAIT(issued, n)                                                                  \
+  {                                                                                         \
+    if ((issued) && !strong) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory");          \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                   \
+  }
+
+  // lane_m: the main loop's copy of the lane id, made opaque again at every tile start so that hipcc RECOMPUTES the ~25 lane-
+  // constant fragment / DMA address registers after an epilogue instead of spilling them across it (the NN layout's scratch
+  // reloads at tile start left compiler-tracked loads pending into the K loop, i.e. vmcnt(0) waits in front of the DMA)
+  int lane_m = lane;
+  asm volatile("" : "+v"(lane_m));
+  PP_ILOAD();
+  PP_ISSUE_A();
+  PP_ISSUE_B();
+  PP_IADV();
+  {
+    const bool two = i_valid;
+    if (two) {
+      PP_ISSUE_A();
+      PP_ISSUE_B();
+      PP_IADV();
+    }
+    PP_WAIT(two, 8);
+  }
+  pp_barrier();                  // stage 0 of the first tile is visible to everybody
+  if (grp == 1) pp_barrier();    // group 1 starts one phase late
+
+  int id = blockIdx.x;
+  int ca = 0, cb = 0;            // ring slots of the stage being consumed
+  for (;;) {
+    int m0, n0, nt;
+    {
+      GemmProblem gm;
+      pick_tile<256>(ga, id, total, gm, m0, n0);
+      nt = gm.K / BK2;
+    }
+    f4v acc[8][4];
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
+    lane_m = lane;
+    asm volatile("" : "+v"(lane_m));
+
+    for (int t = 0; t < nt; ++t) {
+      const unsigned char* sa = smem + ca * TILE2_BYTES;
+      const unsigned char* sb = smem + PP_B_BASE + cb * TILE2_BYTES;
+      const bool iss = i_valid && !nodma;
+      const bool adv = i_valid;
+      bf16x8 a[8], b0[4], b1[4];
+      // MODE 1: what the compute phase needs to issue the four pieces of an operand tile
+      unsigned pv[4] = {0u, 0u, 0u, 0u};
+      const bf16_t* pbase = nullptr;
+      unsigned pdst = 0u;
+      // ---- M0: A(t+2) -> the slot stage t-1 used; fragments of k half 0 and all of B
+      if (MODE == 0) {
+        if (iss) PP_ISSUE_A();
+      } else if (iss) {
+        stage_voff<A_KS, false>(i_lda, wid, lane_m, pv);
+        pbase = A_KS ? i_A + (size_t)(i_t * BK2) * i_lda + i_m0 : i_A + (size_t)i_m0 * i_lda + i_t * BK2;
+        pdst = (unsigned)(size_t)(lds_void*)(smem + ia * TILE2_BYTES + wid * 4096);
+        ia = (ia == 2) ? 0 : ia + 1;
+      }
+      if (!noreads || t == 0) {
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) b0[ni] = fragB256<B_KS>(sb, wn * 64, ni, 0, lane_m);
+#pragma unroll
+      for (int mi = 0; mi < 8; ++mi) a[mi] = frag256<A_KS>(sa, wm * 128 + mi * 16, 0, lane_m);
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) b1[ni] = fragB256<B_KS>(sb, wn * 64, ni, 1, lane_m);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      pp_barrier();
+      // ---- C0
+      if (prio) __builtin_amdgcn_s_setprio(1);
+      if (!nomfma) {
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[ni], a[mi], acc[mi][ni], 0, 0, 0);
+          if (MODE == 1 && (mi & 1)) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (iss) {
+              if (mi == 1) glds16_piece<0>(pbase, pv[0], pdst);
+              if (mi == 3) glds16_piece<1>(pbase, pv[1], pdst);
+              if (mi == 5) glds16_piece<2>(pbase, pv[2], pdst);
+              if (mi == 7) glds16_piece<3>(pbase, pv[3], pdst);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+      if (prio) __builtin_amdgcn_s_setprio(0);
+      pp_barrier();
+      // ---- M1: B(t+2) -> the slot stage t used (both groups have read all of it); fragments of k half 1
+      if (MODE == 0) {
+        if (iss) PP_ISSUE_B();
+      } else if (iss) {
+        stage_voff<B_KS, true>(i_ldb, wid, lane_m, pv);
+        pbase = B_KS ? i_B + (size_t)(i_t * BK2) * i_ldb + i_n0 : i_B + (size_t)i_n0 * i_ldb + i_t * BK2;
+        pdst = (unsigned)(size_t)(lds_void*)(smem + PP_B_BASE + ib * TILE2_BYTES + wid * 4096);
+        ib ^= 1;
+      }
+      if (!noreads) {
+#pragma unroll
+      for (int mi = 0; mi < 8; ++mi) a[mi] = frag256<A_KS>(sa, wm * 128 + mi * 16, 1, lane_m);
+      }
+      if (adv) PP_IADV();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      // this wave's pieces of stage t+1 have landed.  Younger in its queue: MODE 0 A(t+2), B(t+2); MODE 1 (group 1 issues
+      // B(t+2) in the compute phase that follows) A(t+2) only
+      if (grp == 1) {
+        if (MODE == 0) PP_WAIT(iss, 8) else PP_WAIT(iss, 4)
+      }
+      pp_barrier();
+      // ---- C1
+      if (prio) __builtin_amdgcn_s_setprio(1);
+      if (!nomfma) {
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[ni], a[mi], acc[mi][ni], 0, 0, 0);
+          if (MODE == 1 && (mi & 1)) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (iss) {
+              if (mi == 1) glds16_piece<0>(pbase, pv[0], pdst);
+              if (mi == 3) glds16_piece<1>(pbase, pv[1], pdst);
+              if (mi == 5) glds16_piece<2>(pbase, pv[2], pdst);
+              if (mi == 7) glds16_piece<3>(pbase, pv[3], pdst);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+      if (prio) __builtin_amdgcn_s_setprio(0);
+      if (grp == 0) PP_WAIT(iss, 8);
+      ca = (ca == 2) ? 0 : ca + 1;
+      cb ^= 1;
+      if (t + 1 < nt) pp_barrier();
+    }
+
+    if (grp == 0) pp_barrier();
+    GemmProblem g;
+    {
+      int mm, nn;
+      pick_tile<256>(ga, id, total, g, mm, nn);
+    }
+    const int epi = g.epi;
+    const int last_a = (ca == 0) ? 2 : ca - 1;
+    unsigned char* scr = smem + last_a * TILE2_BYTES + wid * 4096;
+    if (!B_KS) {
+      switch (epi) {
+        case 0: epilogue256<0, 8>(g, acc, m0, n0, wm, wn, lane, scr); break;
+        case EPI_BIAS: epilogue256<EPI_BIAS, 8>(g, acc, m0, n0, wm, wn, lane, scr); break;
+        case EPI_BIAS | EPI_GELU: epilogue256<(EPI_BIAS | EPI_GELU), 8>(g, acc, m0, n0, wm, wn, lane, scr); break;
+        case EPI_BIAS | EPI_GELU_FWD: epilogue256<(EPI_BIAS | EPI_GELU_FWD), 8>(g, acc, m0, n0, wm, wn, lane, scr); break;
+        case EPI_BIAS | EPI_ADD: epilogue256<(EPI_BIAS | EPI_ADD), 8>(g, acc, m0, n0, wm, wn, lane, scr); break;
+        case EPI_BIAS | EPI_ADD | EPI_DROP: epilogue256<(EPI_BIAS | EPI_ADD | EPI_DROP), 8>(g, acc, m0, n0, wm, wn, lane, scr); break;
+        default: epilogue256<-1, 8, true>(g, acc, m0, n0, wm, wn, lane, scr); break;
+      }
+    } else if (A_KS && epi == EPI_RMW32) {
+      epilogue256<EPI_RMW32, 8>(g, acc, m0, n0, wm, wn, lane, scr);
+    } else if (!A_KS && epi == EPI_ADD) {
+      epilogue256<EPI_ADD, 8>(g, acc, m0, n0, wm, wn, lane, scr);
+    } else if (!A_KS && epi == 0) {
+      epilogue256<0, 8>(g, acc, m0, n0, wm, wn, lane, scr);
+    } else if (!A_KS && spec584 && epi == (EPI_DGELU | EPI_COLSUM | EPI_COLSUM_WS)) {
+      epilogue256<(EPI_DGELU | EPI_COLSUM | EPI_COLSUM_WS), 8>(g, acc, m0, n0, wm, wn, lane, scr);
+    } else {
+      epilogue256<-1, 8, true>(g, acc, m0, n0, wm, wn, lane, scr);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the scratch reads are done before this wave's next DMA lands there
+    if (grp == 1) pp_barrier();
+    id += gstep;
+    if (id >= total) break;
+  }
+  if (grp == 0) pp_barrier();   // pairs with group 1's last trailing barrier
+#undef PP_ILOAD
+#undef PP_ISSUE_A
+#undef PP_ISSUE_B
+#undef PP_IADV
+#undef PP_WAIT
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The ROTATED ping-pong loop (what the measurements of the four-barrier version above led to; tools/gemm_pp_lab.py,
+// profiles/round4_pp_lab_phase_ablation.txt: per K step of an 8192^3 NT problem the two-stage loop takes 1.59 us, the four-
+// barrier ping-pong 1.53, its memory phases alone 1.05, its phases with neither DMA nor MFMA 0.69 -- i.e. ~140 cycles per
+// barrier interval are rendezvous, and its first memory phase (16 fragment reads + 4 DMA pieces, ~640 cycles) is longer than a
+// 32-MFMA compute phase (~544)).  Same ring, same phases, but only TWO barriers per K step, and the two groups run the phases of
+// an interval in OPPOSITE ORDER instead of meeting at a barrier after every phase:
+//     group 0:  b  M0(t) C0(t)        b  M1(t) C1(t)
+//     group 1:  b  C1(t-1) M0(t)      b  C0(t) M1(t)
+// After a barrier group 1 issues 32 MFMAs on fragments it already holds while group 0 issues DMA and reads; then the roles
+// swap without a rendezvous (if a memory phase runs long the partner's MFMAs simply start later; the matrix pipe arbitrates).
+// Group 1's last compute phase of a tile falls behind the first barrier of the next tile, so BOTH groups run the epilogue of
+// tile n after that barrier (concurrently), in front of their first memory phase of tile n + 1.  DMA balance: M0 carries two of
+// A(t+2)'s four pieces, M1 the other two and B(t+2) (whose slot is free once both groups have passed the mid-step barrier).
+template <int J0>
+static __device__ __forceinline__ void glds16_pair(const void* sbase, unsigned v0, unsigned v1, unsigned dst) {
+  asm volatile(
+      "s_mov_b32 m0, %3\n\ts_nop 0\n\t"
+      "global_load_lds_dwordx4 %0, %2 offset:%4\n\t"
+      "global_load_lds_dwordx4 %1, %2 offset:%5"
+      :
+      : "v"(v0), "v"(v1), "s"(sbase), "s"(dst), "n"(J0 * 1024), "n"(J0 * 1024 + 1024)
+      : "memory", "m0");
+}
+
+template <bool A_KS, bool B_KS>
+__global__ __launch_bounds__(512, 2) void gemm256rot_kernel(const GroupArgs ga) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wid >> 2;
+  const int wm = grp, wn = wid & 3;
+  const int total = ga.total_tiles;
+  const int gstep = (int)gridDim.x;
+  const int flags = ga.pad_;
+  const bool prio = (flags & PP_FLAG_PRIO) != 0;
+  const bool strong = (flags & PP_FLAG_STRONGWAIT) != 0;
+  const bool nodma = (flags & PP_FLAG_NODMA) != 0;
+  const bool nomfma = (flags & PP_FLAG_NOMFMA) != 0;
+  const bool noreads = (flags & PP_FLAG_NOREADS) != 0;
+
+  int i_id = blockIdx.x, i_t = 0, i_nt = 0, i_m0 = 0, i_n0 = 0, i_lda = 0, i_ldb = 0;
+  const bf16_t* i_A = nullptr;
+  const bf16_t* i_B = nullptr;
+  bool i_valid = true;
+  int ia = 0, ib = 0;
+#define PR_ILOAD()                                      \
+  {                                                     \
+    GemmProblem gi;                                     \
+    pick_tile<256>(ga, i_id, total, gi, i_m0, i_n0);    \
+    i_nt = gi.K / BK2;                                  \
+    i_A = gi.A;                                         \
+    i_B = gi.B;                                         \
+    i_lda = gi.lda;                                     \
+    i_ldb = gi.ldb;                                     \
+  }
+#define PR_IADV()                 \
+  {                               \
+    if (++i_t == i_nt) {          \
+      i_t = 0;                    \
+      i_id += gstep;              \
+      if (i_id < total) PR_ILOAD() \
+      else i_valid = false;       \
+    }                             \
+  }
+#define PR_WAIT(issued, n)                                                                  \
+  {                                                                                         \
+    if ((issued) && !strong) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory");          \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                   \
+  }
+#define PR_MMA(bfr)                                                                                                        \
+  {                                                                                                                        \
+    if (prio) __builtin_amdgcn_s_setprio(1);                                                                               \
+    if (!nomfma) {                                                                                                         \
+      _Pragma("unroll") for (int mi = 0; mi < 8; ++mi) _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) acc[mi][ni] =       \
+          __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], a[mi], acc[mi][ni], 0, 0, 0);                                     \
+    }                                                                                                                      \
+    if (prio) __builtin_amdgcn_s_setprio(0);                                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                                                     \
+  }
+
+  int lane_m = lane;
+  asm volatile("" : "+v"(lane_m));
+  PR_ILOAD();
+  for (int s0 = 0; s0 < 2; ++s0) {   // stages 0 and 1 of this workgroup's walk
+    if (i_valid) {
+      stage256<A_KS, false, 256>(i_A, i_lda, i_m0, i_t * BK2, smem + ia * TILE2_BYTES, wid, lane_m);
+      stage256<B_KS, true>(i_B, i_ldb, i_n0, i_t * BK2, smem + PP_B_BASE + ib * TILE2_BYTES, wid, lane_m);
+      ia = ia + 1;
+      ib ^= 1;
+      PR_IADV();
+      if (s0 == 0) {
+        const bool two = i_valid;
+        if (!two) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else {
+        PR_WAIT(true, 8);
+      }
+    }
+  }
+
+  int id = blockIdx.x;
+  int ca = 0, cb = 0;
+  bool started = false;
+  int p_id = 0, p_m0 = 0, p_n0 = 0, p_last_a = 0;   // the tile whose epilogue is due
+  f4v acc[8][4];
+  bf16x8 a[8], b0[4], b1[4];
+#pragma unroll
+  for (int mi = 0; mi < 8; ++mi) a[mi] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) b1[ni] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
+
+  for (;;) {
+    const bool have = id < total;
+    int m0 = 0, n0 = 0, nt = 1;
+    if (have) {
+      GemmProblem gm;
+      pick_tile<256>(ga, id, total, gm, m0, n0);
+      nt = gm.K / BK2;
+    }
+    pp_barrier();   // b(0,0) of this tile: its stage 0 is visible; the slot of the previous stage's A is free
+    if (grp == 1 && started) PR_MMA(b1);   // C1 of the previous tile's last K step
+    if (started) {
+    int lane_e = lane;   // opaque: the epilogue's lane constants are recomputed per tile, not kept live across the K loop
+    asm volatile("" : "+v"(lane_e));
+    GemmProblem g;
+    {
+      int mm, nn;
+      pick_tile<256>(ga, p_id, total, g, mm, nn);
+    }
+    const int epi = g.epi;
+    unsigned char* scr = smem + p_last_a * TILE2_BYTES + wid * 4096;
+    if (!B_KS) {
+      switch (epi) {
+        case 0: epilogue256<0, 8>(g, acc, p_m0, p_n0, wm, wn, lane_e, scr); break;
+        case EPI_BIAS: epilogue256<EPI_BIAS, 8>(g, acc, p_m0, p_n0, wm, wn, lane_e, scr); break;
+        case EPI_BIAS | EPI_GELU: epilogue256<(EPI_BIAS | EPI_GELU), 8>(g, acc, p_m0, p_n0, wm, wn, lane_e, scr); break;
+        case EPI_BIAS | EPI_GELU_FWD: epilogue256<(EPI_BIAS | EPI_GELU_FWD), 8>(g, acc, p_m0, p_n0, wm, wn, lane_e, scr); break;
+        case EPI_BIAS | EPI_ADD: epilogue256<(EPI_BIAS | EPI_ADD), 8>(g, acc, p_m0, p_n0, wm, wn, lane_e, scr); break;
+        case EPI_BIAS | EPI_ADD | EPI_DROP: epilogue256<(EPI_BIAS | EPI_ADD | EPI_DROP), 8>(g, acc, p_m0, p_n0, wm, wn, lane_e, scr); break;
+        default: epilogue256<-1, 8, true>(g, acc, p_m0, p_n0, wm, wn, lane_e, scr); break;
+      }
+    } else if (A_KS && epi == EPI_RMW32) {
+      epilogue256<EPI_RMW32, 8>(g, acc, p_m0, p_n0, wm, wn, lane_e, scr);
+    } else if (!A_KS && epi == EPI_ADD) {
+      epilogue256<EPI_ADD, 8>(g, acc, p_m0, p_n0, wm, wn, lane_e, scr);
+    } else if (!A_KS && epi == 0) {
+      epilogue256<0, 8>(g, acc, p_m0, p_n0, wm, wn, lane_e, scr);
+    } else {
+      epilogue256<-1, 8, true>(g, acc, p_m0, p_n0, wm, wn, lane_e, scr);
+    }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // scratch reads done before this wave's next DMA lands there
+    }
+    if (!have) break;
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
+    lane_m = lane;
+    asm volatile("" : "+v"(lane_m));
+    for (int t = 0; t < nt; ++t) {
+      if (t > 0) {
+        pp_barrier();   // b(t,0): stage t is visible; the slot of A(t-1) is free
+        if (grp == 1) PR_MMA(b1);   // C1 of the previous K step
+      }
+      const unsigned char* sa = smem + ca * TILE2_BYTES;
+      const unsigned char* sb = smem + PP_B_BASE + cb * TILE2_BYTES;
+      const bool iss = i_valid && !nodma;
+      const bool adv = i_valid;
+      // ---- M0: two pieces of A(t+2); fragments of k half 0 and all of B
+      unsigned pv[4] = {0u, 0u, 0u, 0u};
+      const bf16_t* pbase = nullptr;
+      unsigned pdst = 0u;
+      if (iss) {
+        stage_voff<A_KS, false>(i_lda, wid, lane_m, pv);
+        pbase = A_KS ? i_A + (size_t)(i_t * BK2) * i_lda + i_m0 : i_A + (size_t)i_m0 * i_lda + i_t * BK2;
+        pdst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void*)(smem + ia * TILE2_BYTES + wid * 4096));
+        glds16_pair<0>(pbase, pv[0], pv[1], pdst);
+      }
+      if (!noreads || t == 0) {
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) b0[ni] = fragB256<B_KS>(sb, wn * 64, ni, 0, lane_m);
+#pragma unroll
+      for (int mi = 0; mi < 8; ++mi) a[mi] = frag256<A_KS>(sa, wm * 128 + mi * 16, 0, lane_m);
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) b1[ni] = fragB256<B_KS>(sb, wn * 64, ni, 1, lane_m);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      if (grp == 0) PR_MMA(b0);   // C0
+      pp_barrier();   // b(t,1): both groups have read all of B(t)
+      if (grp == 1) PR_MMA(b0);   // C0
+      // ---- M1: the other two pieces of A(t+2), B(t+2); fragments of k half 1
+      if (iss) {
+        int lane_p = lane_m;   // opaque: the two offsets are recomputed here instead of staying live across the compute phase
+        asm volatile("" : "+v"(lane_p));
+        stage_voff<A_KS, false>(i_lda, wid, lane_p, pv);
+        glds16_pair<2>(pbase, pv[2], pv[3], pdst);
+        ia = (ia == 2) ? 0 : ia + 1;
+        stage256<B_KS, true>(i_B, i_ldb, i_n0, i_t * BK2, smem + PP_B_BASE + ib * TILE2_BYTES, wid, lane_m);
+        ib ^= 1;
+      }
+      if (!noreads) {
+#pragma unroll
+      for (int mi = 0; mi < 8; ++mi) a[mi] = frag256<A_KS>(sa, wm * 128 + mi * 16, 1, lane_m);
+      }
+      if (adv) PR_IADV();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      if (grp == 0) PR_MMA(b1);   // C1 (group 1: after the next barrier)
+      PR_WAIT(iss, 8);            // this wave's pieces of stage t+1 have landed (younger: A(t+2), B(t+2))
+      ca = (ca == 2) ? 0 : ca + 1;
+      cb ^= 1;
+      started = true;
+    }
+    p_id = id;
+    p_m0 = m0;
+    p_n0 = n0;
+    p_last_a = (ca == 0) ? 2 : ca - 1;
+    id += gstep;
+  }
+#undef PR_ILOAD
+#undef PR_IADV
+#undef PR_WAIT
+#undef PR_MMA
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The RING loop (round 4, what the ping-pong measurements above led back to).  Findings: an s_barrier at which the matrix pipe
+// runs dry costs 100-280 cycles of MFMA time (4-barrier ping-pong with MFMAs only: 1.29 us per K step against 1.03 of MFMA
+// issue; rotated 2-barrier: 1.31), so phases separated by barriers cannot win; what the two-stage loop of rounds 1-3 loses per
+// K step is (a) the burst of 8 LDS-DMA pieces every wave queues right after the barrier (~47 cycles of issue each, nobody has
+// an MFMA to issue meanwhile), and (b) the latency of the first fragment reads of the new stage, also behind the barrier.
+// Here: ONE barrier per K step as before, identical code in all 8 waves (the two waves of a SIMD interleave by themselves), but
+//   * operand RING, 3 A slots + 2 B slots of 32 KiB: A(t+2) and B(t+1) are issued during step t, so their issue is not tied to
+//     the barrier -- one piece in front of each of the first six MFMA groups of the step (hidden under the partner wave's
+//     MFMAs) -- and A has two steps to land (B, the small re-used operand of the forward / dgrad layouts, one);
+//   * the LAST MFMA group of a step is held back across the barrier: after the barrier a wave first requests the first
+//     fragments of the new stage, then issues the 8 held MFMAs, which cover that LDS latency;
+//   * the wait for the DMA sits in front of the barrier that precedes the epilogue, so no epilogue store is ever in the vmcnt
+//     queue in front of a load that must be waited for (no `pend` bookkeeping); that same barrier frees the A slot consumed
+//     last, whose wave-private 4 KiB are the epilogue's transpose scratch.
+template <bool A_KS, bool B_KS>
+__global__ __launch_bounds__(512, 2) void gemm256r_kernel(const GroupArgs ga) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 2, wn = wid & 3;
+  const int total = ga.total_tiles;
+  const int gstep = (int)gridDim.x;
+  const int flags = ga.pad_;
+  const bool nodma = (flags & PP_FLAG_NODMA) != 0;
+  const bool strong = (flags & PP_FLAG_STRONGWAIT) != 0;
+  const bool nobar = (flags & 512) != 0;      // ablation (timing only): no barrier in the K loop
+  const bool halfreads = (flags & 1024) != 0;  // ablation (timing only): the a1 fragments are never reloaded
+  const bool nomfma = (flags & PP_FLAG_NOMFMA) != 0;
+
+  int lane_m = lane;   // opaque copy for the main loop's address arithmetic (see gemm256pp_kernel)
+  asm volatile("" : "+v"(lane_m));
+  // ---- two issue cursors (tile, K stage) running ahead of the consumer across tiles: A by two stages, B by one
+  int a_id = blockIdx.x, a_t = 0, a_nt = 0, a_m0 = 0, a_ld = 0;
+  const bf16_t* a_P = nullptr;
+  bool a_ok = true;
+  int ia = 0;
+  unsigned va[4];
+  int b_id = blockIdx.x, b_t = 0, b_nt = 0, b_n0 = 0, b_ld = 0;
+  const bf16_t* b_P = nullptr;
+  bool b_ok = true;
+  int ib = 0;
+  unsigned vb[4];
+#define RR_ALOAD()                                   \
+  {                                                  \
+    GemmProblem gi;                                  \
+    int nn_;                                         \
+    pick_tile<256>(ga, a_id, total, gi, a_m0, nn_);  \
+    a_nt = gi.K / BK2;                               \
+    a_P = gi.A;                                      \
+    a_ld = gi.lda;                                   \
+    stage_voff<A_KS, false>(a_ld, wid, lane_m, va);  \
+  }
+#define RR_BLOAD()                                   \
+  {                                                  \
+    GemmProblem gi;                                  \
+    int mm_;                                         \
+    pick_tile<256>(ga, b_id, total, gi, mm_, b_n0);  \
+    b_nt = gi.K / BK2;                               \
+    b_P = gi.B;                                      \
+    b_ld = gi.ldb;                                   \
+    stage_voff<B_KS, true>(b_ld, wid, lane_m, vb);   \
+  }
+#define RR_AADV()                   \
+  {                                 \
+    if (++a_t == a_nt) {            \
+      a_t = 0;                      \
+      a_id += gstep;                \
+      if (a_id < total) RR_ALOAD()  \
+      else a_ok = false;            \
+    }                               \
+    ia = (ia == 2) ? 0 : ia + 1;    \
+  }
+#define RR_BADV()                   \
+  {                                 \
+    if (++b_t == b_nt) {            \
+      b_t = 0;                      \
+      b_id += gstep;                \
+      if (b_id < total) RR_BLOAD()  \
+      else b_ok = false;            \
+    }                               \
+    ib ^= 1;                        \
+  }
+#define RR_ABASE() (A_KS ? a_P + (size_t)(a_t * BK2) * a_ld + a_m0 : a_P + (size_t)a_m0 * a_ld + a_t * BK2)
+#define RR_BBASE() (B_KS ? b_P + (size_t)(b_t * BK2) * b_ld + b_n0 : b_P + (size_t)b_n0 * b_ld + b_t * BK2)
+#define RR_ADST() __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void*)(smem + ia * TILE2_BYTES + wid * 4096))
+#define RR_BDST() __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void*)(smem + PP_B_BASE + ib * TILE2_BYTES + wid * 4096))
+
+  RR_ALOAD();
+  RR_BLOAD();
+  {
+    const bf16_t* pa = RR_ABASE();
+    const unsigned da = RR_ADST();
+    glds16_pair<0>(pa, va[0], va[1], da);
+    glds16_pair<2>(pa, va[2], va[3], da);
+    RR_AADV();
+    const bf16_t* pb = RR_BBASE();
+    const unsigned db = RR_BDST();
+    glds16_pair<0>(pb, vb[0], vb[1], db);
+    glds16_pair<2>(pb, vb[2], vb[3], db);
+    RR_BADV();
+    if (a_ok) {
+      const bf16_t* pa1 = RR_ABASE();
+      const unsigned da1 = RR_ADST();
+      glds16_pair<0>(pa1, va[0], va[1], da1);
+      glds16_pair<2>(pa1, va[2], va[3], da1);
+      RR_AADV();
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  }
+  pp_barrier();   // stage 0 of the first tile is visible
+
+  int id = blockIdx.x;
+  int ca = 0, cb = 0;
+#define RR_SB() __builtin_amdgcn_sched_barrier(0)
+#define RR_LOADB(dst, ks) _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) dst[ni] = fragB256<B_KS>(sb, wn * 64, ni, ks, lane_m)
+#define RR_LOADA(dst, ks, pr)                                          \
+  dst[0] = frag256<A_KS>(sa, wm * 128 + (2 * (pr)) * 16, ks, lane_m);  \
+  dst[1] = frag256<A_KS>(sa, wm * 128 + (2 * (pr) + 1) * 16, ks, lane_m)
+#define RR_MM(a, b, pr)                                                                                              \
+  if (!nomfma) _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) acc[2 * (pr) + j][ni] = \
+      __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[ni], a[j], acc[2 * (pr) + j][ni], 0, 0, 0)
+  for (;;) {
+    int m0, n0, nt;
+    {
+      GemmProblem gm;
+      pick_tile<256>(ga, id, total, gm, m0, n0);
+      nt = gm.K / BK2;
+    }
+    bf16x8 b0[4], b1[4], a0[2], a1[2];
+    a1[0] = a1[1] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned char* sa = smem + ca * TILE2_BYTES;
+    const unsigned char* sb = smem + PP_B_BASE + cb * TILE2_BYTES;
+    RR_LOADB(b0, 0);
+    RR_LOADA(a0, 0, 0);
+    f4v acc[8][4];
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
+    RR_SB();
+    for (int t = 0; t < nt; ++t) {
+      // DMA of this step: B(t+1) first (one step to land), then A(t+2); one pair / piece in front of an MFMA group
+      const bool isb = b_ok && !nodma, isa = a_ok && !nodma;
+      const bf16_t* pb = RR_BBASE();
+      const unsigned db = RR_BDST();
+      const bf16_t* pa = RR_ABASE();
+      const unsigned da = RR_ADST();
+      if (isb) glds16_pair<0>(pb, vb[0], vb[1], db);
+      if (!halfreads) { RR_LOADA(a1, 0, 1); } RR_SB(); RR_MM(a0, b0, 0); RR_SB();
+      if (isb) glds16_pair<2>(pb, vb[2], vb[3], db);
+      RR_LOADA(a0, 0, 2); RR_SB(); RR_MM(a1, b0, 1); RR_SB();
+      if (isa) glds16_piece<0>(pa, va[0], da);
+      if (!halfreads) { RR_LOADA(a1, 0, 3); } RR_SB(); RR_MM(a0, b0, 2); RR_SB();
+      if (isa) glds16_piece<1>(pa, va[1], da);
+      RR_LOADB(b1, 1);
+      RR_LOADA(a0, 1, 0); RR_SB(); RR_MM(a1, b0, 3); RR_SB();
+      if (isa) glds16_piece<2>(pa, va[2], da);
+      if (!halfreads) { RR_LOADA(a1, 1, 1); } RR_SB(); RR_MM(a0, b1, 0); RR_SB();
+      if (isa) glds16_piece<3>(pa, va[3], da);
+      RR_LOADA(a0, 1, 2); RR_SB(); RR_MM(a1, b1, 1); RR_SB();
+      if (!halfreads) { RR_LOADA(a1, 1, 3); } RR_SB(); RR_MM(a0, b1, 2); RR_SB();
+      if (b_ok) RR_BADV();
+      if (a_ok) RR_AADV();
+      // B(t+1) (and the older A(t+1)) have landed: the only younger pieces in this wave's queue are A(t+2)'s four
+      if (isa && !strong) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (!nobar) pp_barrier();
+      ca = (ca == 2) ? 0 : ca + 1;
+      cb ^= 1;
+      if (t + 1 < nt) {
+        sa = smem + ca * TILE2_BYTES;
+        sb = smem + PP_B_BASE + cb * TILE2_BYTES;
+        RR_LOADB(b0, 0);
+        RR_LOADA(a0, 0, 0);
+        RR_SB();
+        RR_MM(a1, b1, 3);   // the group held back across the barrier: covers the latency of the six reads just issued
+        RR_SB();           // (written out in both branches so that hipcc counts lgkmcnt(6) here instead of merging to lgkmcnt(0))
+      } else {
+        RR_MM(a1, b1, 3);
+        RR_SB();
+      }
+    }
+    GemmProblem g;
+    {
+      int mm, nn;
+      pick_tile<256>(ga, id, total, g, mm, nn);
+    }
+    const int epi = g.epi;
+    const int last_a = (ca == 0) ? 2 : ca - 1;
+    unsigned char* scr = smem + last_a * TILE2_BYTES + wid * 4096;
+    if (!B_KS) {
+      switch (epi) {
+        case 0: epilogue256<0, 8>(g, acc, m0, n0, wm, wn, lane, scr); break;
+        case EPI_BIAS: epilogue256<EPI_BIAS, 8>(g, acc, m0, n0, wm, wn, lane, scr); break;
+        case EPI_BIAS | EPI_GELU: epilogue256<(EPI_BIAS | EPI_GELU), 8>(g, acc, m0, n0, wm, wn, lane, scr); break;
+        case EPI_BIAS | EPI_GELU_FWD: epilogue256<(EPI_BIAS | EPI_GELU_FWD), 8>(g, acc, m0, n0, wm, wn, lane, scr); break;
+        case EPI_BIAS | EPI_ADD: epilogue256<(EPI_BIAS | EPI_ADD), 8>(g, acc, m0, n0, wm, wn, lane, scr); break;
+        case EPI_BIAS | EPI_ADD | EPI_DROP: epilogue256<(EPI_BIAS | EPI_ADD | EPI_DROP), 8>(g, acc, m0, n0, wm, wn, lane, scr); break;
+        default: epilogue256<-1, 8, true>(g, acc, m0, n0, wm, wn, lane, scr); break;
+      }
+    } else if (A_KS && epi == EPI_RMW32) {
+      epilogue256<EPI_RMW32, 8>(g, acc, m0, n0, wm, wn, lane, scr);
+    } else if (!A_KS && epi == EPI_ADD) {
+      epilogue256<EPI_ADD, 8>(g, acc, m0, n0, wm, wn, lane, scr);
+    } else if (!A_KS && epi == 0) {
+      epilogue256<0, 8>(g, acc, m0, n0, wm, wn, lane, scr);
+    } else {
+      epilogue256<-1, 8, true>(g, acc, m0, n0, wm, wn, lane, scr);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // scratch reads done before this wave's next DMA lands there
+    id += gstep;
+    if (id >= total) break;
+    lane_m = lane;
+    asm volatile("" : "+v"(lane_m));
+  }
+#undef RR_ALOAD
+#undef RR_BLOAD
+#undef RR_AADV
+#undef RR_BADV
+#undef RR_ABASE
+#undef RR_BBASE
+#undef RR_ADST
+#undef RR_BDST
+#undef RR_SB
+#undef RR_LOADB
+#undef RR_LOADA
+#undef RR_MM
+}
+
+template <bool A_KS, bool B_KS>
+static int launch256r(GroupArgs& ga, int flags, hipStream_t stream) {
+  static std::atomic<unsigned long long> attr_done{0};
+  const int r = kbner_set_max_lds_once(attr_done, reinterpret_cast<const void*>(gemm256r_kernel<A_KS, B_KS>), PP_LDS_BYTES);
+  if (r) return r;
+  ga.pad_ = flags;
+  const int grid = ga.total_tiles < ga.ncu ? ga.total_tiles : ga.ncu;
+  hipLaunchKernelGGL((gemm256r_kernel<A_KS, B_KS>), dim3(grid), dim3(512), PP_LDS_BYTES, stream, ga);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The FINE-GRAINED ring loop (round 4, final form).  What the variants above taught: the two waves of a SIMD run IDENTICAL code
+// from the same barrier, so they stay in lockstep -- both issue their MFMA groups at the same time (sharing the pipe) and both
+// sit in their non-MFMA chunks (fragment reads, address arithmetic, DMA pieces: ~150 issue cycles per 8-MFMA group) at the same
+// time, when the matrix pipe has nothing to do: pipe busy ~2/3, which is the 1.55-1.65 us per K step every coarse-grained
+// variant lands on (two-stage 1.59-1.64, ping-pong 1.53-1.61, ring 1.57-1.65) against 1.08 us of MFMA issue on random data.
+// Here the non-MFMA work is cut into single instructions placed BETWEEN the MFMAs of a quad (one A fragment x four B
+// fragments): an MFMA leaves the pipe busy for 16 cycles (32 with the partner wave's), a fragment read or an address op costs
+// an issue slot of ~4, so lockstep no longer matters.  The one long instruction, an LDS-DMA piece (~50-60 cycles of issue), is
+// issued by group 0 (waves 0-3) after even quads and by group 1 (waves 4-7: the other wave of every SIMD) after odd quads.
+// Ring, cursors, waits, held last quad and epilogue as in gemm256r_kernel.
+// ABL (trace builds only): compile-time ablations for cycle accounting -- 1 no barrier in the K loop, 2 no fragment reads after a
+// tile's first K step, 4 no MFMAs (timing only, wrong results)
+template <bool A_KS, bool B_KS, int ABL = 0>
+__global__ __launch_bounds__(512, 2) void gemm256f_kernel(const GroupArgs ga) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 2, wn = wid & 3;
+  const int grp = wm;
+  const int total = ga.total_tiles;
+  const int gstep = (int)gridDim.x;
+  const int flags = ga.pad_;
+  const bool nodma = (flags & PP_FLAG_NODMA) != 0;
+  const bool strong = (flags & PP_FLAG_STRONGWAIT) != 0;
+
+  G2_CLK(0)
+  int lane_m = lane;
+  asm volatile("" : "+v"(lane_m));
+  int a_id = blockIdx.x, a_t = 0, a_nt = 0, a_m0 = 0, a_ld = 0;
+  const bf16_t* a_P = nullptr;
+  bool a_ok = true;
+  int ia = 0;
+  unsigned va[4];
+  int b_id = blockIdx.x, b_t = 0, b_nt = 0, b_n0 = 0, b_ld = 0;
+  const bf16_t* b_P = nullptr;
+  bool b_ok = true;
+  int ib = 0;
+  unsigned vb[4];
+#define RF_ALOAD()                                   \
+  {                                                  \
+    GemmProblem gi;                                  \
+    int nn_;                                         \
+    pick_tile<256>(ga, a_id, total, gi, a_m0, nn_);  \
+    a_nt = gi.K / BK2;                               \
+    a_P = gi.A;                                      \
+    a_ld = gi.lda;                                   \
+    stage_voff<A_KS, false>(a_ld, wid, lane_m, va);  \
+  }
+#define RF_BLOAD()                                   \
+  {                                                  \
+    GemmProblem gi;                                  \
+    int mm_;                                         \
+    pick_tile<256>(ga, b_id, total, gi, mm_, b_n0);  \
+    b_nt = gi.K / BK2;                               \
+    b_P = gi.B;                                      \
+    b_ld = gi.ldb;                                   \
+    stage_voff<B_KS, true>(b_ld, wid, lane_m, vb);   \
+  }
+#define RF_AADV()                   \
+  {                                 \
+    if (++a_t == a_nt) {            \
+      a_t = 0;                      \
+      a_id += gstep;                \
+      if (a_id < total) RF_ALOAD()  \
+      else a_ok = false;            \
+    }                               \
+    ia = (ia == 2) ? 0 : ia + 1;    \
+  }
+#define RF_BADV()                   \
+  {                                 \
+    if (++b_t == b_nt) {            \
+      b_t = 0;                      \
+      b_id += gstep;                \
+      if (b_id < total) RF_BLOAD()  \
+      else b_ok = false;            \
+    }                               \
+    ib ^= 1;                        \
+  }
+#define RF_ABASE() (A_KS ? a_P + (size_t)(a_t * BK2) * a_ld + a_m0 : a_P + (size_t)a_m0 * a_ld + a_t * BK2)
+#define RF_BBASE() (B_KS ? b_P + (size_t)(b_t * BK2) * b_ld + b_n0 : b_P + (size_t)b_n0 * b_ld + b_t * BK2)
+#define RF_ADST() __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void*)(smem + ia * TILE2_BYTES + wid * 4096))
+#define RF_BDST() __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void*)(smem + PP_B_BASE + ib * TILE2_BYTES + wid * 4096))
+
+  RF_ALOAD();
+  RF_BLOAD();
+  {
+    const bf16_t* pa = RF_ABASE();
+    const unsigned da = RF_ADST();
+    glds16_pair<0>(pa, va[0], va[1], da);
+    glds16_pair<2>(pa, va[2], va[3], da);
+    RF_AADV();
+    const bf16_t* pb = RF_BBASE();
+    const unsigned db = RF_BDST();
+    glds16_pair<0>(pb, vb[0], vb[1], db);
+    glds16_pair<2>(pb, vb[2], vb[3], db);
+    RF_BADV();
+    if (a_ok) {
+      const bf16_t* pa1 = RF_ABASE();
+      const unsigned da1 = RF_ADST();
+      glds16_pair<0>(pa1, va[0], va[1], da1);
+      glds16_pair<2>(pa1, va[2], va[3], da1);
+      RF_AADV();
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  }
+  pp_barrier();
+
+  int id = blockIdx.x;
+  int ca = 0, cb = 0;
+#define RF_SB() __builtin_amdgcn_sched_barrier(0)
+#define RF_FA(ks, mi) (((ABL & 2) && t > 0) ? af[0] : frag256<A_KS>(sa, wm * 128 + (mi) * 16, ks, lane_m))
+#define RF_FB(ks, ni) (((ABL & 2) && t > 0) ? bq[0][0] : fragB256<B_KS>(sb, wn * 64, ni, ks, lane_m))
+#define RF_MFMA(mi, ni, bfr, afr) if (!(ABL & 4)) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr, afr, acc[mi][ni], 0, 0, 0)
+  for (;;) {
+    int m0, n0, nt;
+    {
+      GemmProblem gm;
+      pick_tile<256>(ga, id, total, gm, m0, n0);
+      nt = gm.K / BK2;
+    }
+    bf16x8 bq[2][4], af[2], afh;
+    const unsigned char* sa = smem + ca * TILE2_BYTES;
+    const unsigned char* sb = smem + PP_B_BASE + cb * TILE2_BYTES;
+    {
+      const int t = 0;
+      (void)t;
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) bq[0][ni] = RF_FB(0, ni);
+      af[0] = RF_FA(0, 0);
+    }
+    f4v acc[8][4];
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
+    RF_SB();
+    for (int t = 0; t < nt; ++t) {
+      const bool isb = b_ok && !nodma, isa = a_ok && !nodma;
+      const bf16_t* pb = RF_BBASE();
+      const unsigned db = RF_BDST();
+      const bf16_t* pa = RF_ABASE();
+      const unsigned da = RF_ADST();
+      RF_SB();
+      // quads 0..14 (quad q = A fragment (k half q >> 3, row block q & 7) x the four B fragments of that k half)
+#pragma unroll
+      for (int q = 0; q < 15; ++q) {
+        const int ks = q >> 3, mi = q & 7;
+        RF_MFMA(mi, 0, bq[ks][0], af[q & 1]);
+        RF_SB();
+        // the A fragment of the next quad (quad 15's goes to the buffer that is held across the barrier)
+        if (q + 1 < 15) af[(q + 1) & 1] = RF_FA((q + 1) >> 3, (q + 1) & 7);
+        else afh = RF_FA(1, 7);
+        RF_SB();
+        RF_MFMA(mi, 1, bq[ks][1], af[q & 1]);
+        RF_SB();
+        // the B fragments of k half 1, one per quad 3..6
+        if (q >= 3 && q <= 6) bq[1][q - 3] = RF_FB(1, q - 3);
+        RF_SB();
+        RF_MFMA(mi, 2, bq[ks][2], af[q & 1]);
+        RF_SB();
+        // one LDS-DMA piece per two quads and wave; the two waves of a SIMD (groups 0 / 1) take alternate quads.
+        // B(t+1) first (it has this step to land), then A(t+2)
+        if ((q & 1) == grp) {
+          const int j = q >> 1;   // 0..7 (group 1: 0..6, its eighth piece follows quad 14 below)
+          if (j == 0 && isb) glds16_piece<0>(pb, vb[0], db);
+          if (j == 1 && isb) glds16_piece<1>(pb, vb[1], db);
+          if (j == 2 && isb) glds16_piece<2>(pb, vb[2], db);
+          if (j == 3 && isb) glds16_piece<3>(pb, vb[3], db);
+          if (j == 4 && isa) glds16_piece<0>(pa, va[0], da);
+          if (j == 5 && isa) glds16_piece<1>(pa, va[1], da);
+          if (j == 6 && isa) glds16_piece<2>(pa, va[2], da);
+          if (j == 7 && isa) glds16_piece<3>(pa, va[3], da);
+        }
+        RF_SB();
+        RF_MFMA(mi, 3, bq[ks][3], af[q & 1]);
+        RF_SB();
+      }
+      if (grp == 1 && isa) glds16_piece<3>(pa, va[3], da);
+      if (b_ok) RF_BADV();
+      if (a_ok) RF_AADV();
+      if (isa && !strong) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // (the builtin, not inline asm: hipcc must KNOW the LGKM queue is empty here -- scalar loads of a cursor's tile crossing
+      // above would otherwise leave it assuming mixed SMEM / LDS events and turn every later counted lgkmcnt into lgkmcnt(0))
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      if (!(ABL & 1)) pp_barrier();
+      ca = (ca == 2) ? 0 : ca + 1;
+      cb ^= 1;
+      if (t + 1 < nt) {
+        sa = smem + ca * TILE2_BYTES;
+        sb = smem + PP_B_BASE + cb * TILE2_BYTES;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) bq[0][ni] = RF_FB(0, ni);
+        af[0] = RF_FA(0, 0);
+        RF_SB();
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) RF_MFMA(7, ni, bq[1][ni], afh);   // quad 15, held across the barrier
+        RF_SB();
+      } else {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) RF_MFMA(7, ni, bq[1][ni], afh);
+        RF_SB();
+      }
+    }
+    GemmProblem g;
+    {
+      int mm, nn;
+      pick_tile<256>(ga, id, total, g, mm, nn);
+    }
+    const int epi = g.epi;
+    const int last_a = (ca == 0) ? 2 : ca - 1;
+    unsigned char* scr = smem + last_a * TILE2_BYTES + wid * 4096;
+    if (!B_KS) {
+      switch (epi) {
+        case 0: epilogue256<0, 8>(g, acc, m0, n0, wm, wn, lane, scr); break;
+        case EPI_BIAS: epilogue256<EPI_BIAS, 8>(g, acc, m0, n0, wm, wn, lane, scr); break;
+        case EPI_BIAS | EPI_GELU: epilogue256<(EPI_BIAS | EPI_GELU), 8>(g, acc, m0, n0, wm, wn, lane, scr); break;
+        case EPI_BIAS | EPI_GELU_FWD: epilogue256<(EPI_BIAS | EPI_GELU_FWD), 8>(g, acc, m0, n0, wm, wn, lane, scr); break;
+        case EPI_BIAS | EPI_ADD: epilogue256<(EPI_BIAS | EPI_ADD), 8>(g, acc, m0, n0, wm, wn, lane, scr); break;
+        case EPI_BIAS | EPI_ADD | EPI_DROP: epilogue256<(EPI_BIAS | EPI_ADD | EPI_DROP), 8>(g, acc, m0, n0, wm, wn, lane, scr); break;
+        default: epilogue256<-1, 8, true>(g, acc, m0, n0, wm, wn, lane, scr); break;
+      }
+    } else if (A_KS && epi == EPI_RMW32) {
+      epilogue256<EPI_RMW32, 8>(g, acc, m0, n0, wm, wn, lane, scr);
+    } else if (!A_KS && epi == EPI_ADD) {
+      epilogue256<EPI_ADD, 8>(g, acc, m0, n0, wm, wn, lane, scr);
+    } else if (!A_KS && epi == 0) {
+      epilogue256<0, 8>(g, acc, m0, n0, wm, wn, lane, scr);
+    } else {
+      epilogue256<-1, 8, true>(g, acc, m0, n0, wm, wn, lane, scr);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    id += gstep;
+    if (id >= total) { G2_CLK(1) break; }
+    lane_m = lane;
+    asm volatile("" : "+v"(lane_m));
+  }
+#undef RF_ALOAD
+#undef RF_BLOAD
+#undef RF_AADV
+#undef RF_BADV
+#undef RF_ABASE
+#undef RF_BBASE
+#undef RF_ADST
+#undef RF_BDST
+#undef RF_SB
+#undef RF_FA
+#undef RF_FB
+#undef RF_MFMA
+}
+
+template <bool A_KS, bool B_KS, int ABL = 0>
+static int launch256f(GroupArgs& ga, int flags, hipStream_t stream) {
+  static std::atomic<unsigned long long> attr_done{0};
+  const int r = kbner_set_max_lds_once(attr_done, reinterpret_cast<const void*>(gemm256f_kernel<A_KS, B_KS, ABL>), PP_LDS_BYTES);
+  if (r) return r;
+  ga.pad_ = flags;
+  const int grid = ga.total_tiles < ga.ncu ? ga.total_tiles : ga.ncu;
+  hipLaunchKernelGGL((gemm256f_kernel<A_KS, B_KS, ABL>), dim3(grid), dim3(512), PP_LDS_BYTES, stream, ga);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+// which main loop the 256-row static launches use: bit 0 = ping-pong (gemm256pp_kernel), bits 1.. = its PP_FLAG_* options.
+// Process-wide, atomic; set through kbner_gemm_set_variant (include/kbner.h).
+static std::atomic<int> g_gemm_variant{KBNER_GEMM_VARIANT_DEFAULT};
+
+template <bool A_KS, bool B_KS>
+static int launch256rot(GroupArgs& ga, int flags, hipStream_t stream) {
+  static std::atomic<unsigned long long> attr_done{0};
+  const int r = kbner_set_max_lds_once(attr_done, reinterpret_cast<const void*>(gemm256rot_kernel<A_KS, B_KS>), PP_LDS_BYTES);
+  if (r) return r;
+  ga.pad_ = flags;
+  const int grid = ga.total_tiles < ga.ncu ? ga.total_tiles : ga.ncu;
+  hipLaunchKernelGGL((gemm256rot_kernel<A_KS, B_KS>), dim3(grid), dim3(512), PP_LDS_BYTES, stream, ga);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
+template <bool A_KS, bool B_KS, int MODE>
+static int launch256pp(GroupArgs& ga, int flags, hipStream_t stream) {
+  static std::atomic<unsigned long long> attr_done{0};
+  const int r = kbner_set_max_lds_once(attr_done, reinterpret_cast<const void*>(gemm256pp_kernel<A_KS, B_KS, MODE>), PP_LDS_BYTES);
+  if (r) return r;
+  ga.pad_ = flags;
+  const int grid = ga.total_tiles < ga.ncu ? ga.total_tiles : ga.ncu;
+  hipLaunchKernelGGL((gemm256pp_kernel<A_KS, B_KS, MODE>), dim3(grid), dim3(512), PP_LDS_BYTES, stream, ga);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
 }
 
 template <bool A_KS, bool B_KS, bool DYN, int TM = 256>
@@ -675,6 +1774,9 @@ struct kbner_gemm_problem {
 extern "C" int kbner_debug_read_trace(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g2_trace), sizeof(unsigned long long) * 256 * 32 * 4);
 }
+extern "C" int kbner_debug_read_clk(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g2_clk), sizeof(unsigned long long) * 256 * 4);
+}
 #endif
 
 static int pick_tile_rows(int layout, int nprob, const kbner_gemm_problem* probs, bool dyn);
@@ -694,6 +1796,13 @@ int kbner_gemm_tile_rows(int layout, int M, int N) {
 // Constraints per problem: M % 256 == 0, N % 256 == 0, K % 64 == 0, lda/ldb % 8 == 0.
 static int gemm_grouped_impl(int layout, int nprob, const kbner_gemm_problem* probs, int* sched, void* stream);
 static int pick_tile_rows(int layout, int nprob, const kbner_gemm_problem* probs, bool dyn);
+
+int kbner_gemm_set_variant(int variant) {
+  KBNER_CHECK_ARG(variant >= 0 && variant < 32768);
+  g_gemm_variant.store(variant, std::memory_order_relaxed);
+  return 0;
+}
+int kbner_gemm_get_variant(void) { return g_gemm_variant.load(std::memory_order_relaxed); }
 
 int kbner_gemm_bf16_grouped(int layout, int nprob, const kbner_gemm_problem* probs, void* stream) {
   return gemm_grouped_impl(layout, nprob, probs, nullptr, stream);
@@ -768,6 +1877,48 @@ static int gemm_grouped_impl(int layout, int nprob, const kbner_gemm_problem* pr
     }
   }
   if (TM == 128) return layout == 0 ? launch256<false, false, false, 128>(ga, st) : launch256<false, true, false, 128>(ga, st);
+  const int variant = g_gemm_variant.load(std::memory_order_relaxed);
+#ifdef G2_TRACE
+  if ((variant & PP_FLAG_FINE) && layout == 0 && (variant & 0x7000)) {   // cycle-accounting ablations, NT only
+    switch ((variant >> 12) & 7) {
+      case 1: return launch256f<false, false, 1>(ga, variant, st);
+      case 2: return launch256f<false, false, 2>(ga, variant, st);
+      case 3: return launch256f<false, false, 3>(ga, variant, st);
+      case 4: return launch256f<false, false, 4>(ga, variant, st);
+      case 5: return launch256f<false, false, 5>(ga, variant, st);
+      case 6: return launch256f<false, false, 6>(ga, variant, st);
+      default: return launch256f<false, false, 7>(ga, variant, st);
+    }
+  }
+#endif
+  if (variant & PP_FLAG_FINE) {
+    switch (layout) {
+      case 0: return launch256f<false, false>(ga, variant, st);
+      case 1: return launch256f<false, true>(ga, variant, st);
+      default: return launch256f<true, true>(ga, variant, st);
+    }
+  }
+  if (variant & PP_FLAG_RING) {
+    switch (layout) {
+      case 0: return launch256r<false, false>(ga, variant, st);
+      case 1: return launch256r<false, true>(ga, variant, st);
+      default: return launch256r<true, true>(ga, variant, st);
+    }
+  }
+  if ((variant & 1) && (variant & PP_FLAG_ROT)) {
+    switch (layout) {
+      case 0: return launch256rot<false, false>(ga, variant, st);
+      case 1: return launch256rot<false, true>(ga, variant, st);
+      default: return launch256rot<true, true>(ga, variant, st);
+    }
+  }
+  if (variant & 1) {
+    switch (layout) {
+      case 0: return launch256pp<false, false, 0>(ga, variant, st);
+      case 1: return launch256pp<false, true, 0>(ga, variant, st);
+      default: return launch256pp<true, true, 0>(ga, variant, st);
+    }
+  }
   switch (layout) {
     case 0: return launch256<false, false, false>(ga, st);
     case 1: return launch256<false, true, false>(ga, st);

@@ -54,6 +54,8 @@ SIGNATURES = {
     "kbner_colsum_rows_f32": (c_int, [P, c_int, c_int, P, P]),
     "kbner_gemm_tile_rows": (c_int, [c_int, c_int, c_int]),
     "kbner_gemm_bf16_grouped_dyn": (c_int, [c_int, c_int, P, P, P]),
+    "kbner_gemm_set_variant": (c_int, [c_int]),
+    "kbner_gemm_get_variant": (c_int, []),
     "kbner_splitk_finish": (c_int, [P, c_int, P, P, c_int, P, c_int, c_int, c_int, U32, U32, P]),
     "kbner_attn_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, U32, U32, P]),
     "kbner_attn_bwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, U32, U32, P, P]),
@@ -108,6 +110,9 @@ def load():
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    v = os.environ.get("KBNER_GEMM_VARIANT")   # A/B switch of the 256-row GEMM main loop (include/kbner.h: kbner_gemm_set_variant)
+    if v:
+        lib.kbner_gemm_set_variant(int(v))
     return lib
 
 

@@ -352,6 +352,14 @@ def make_problem(A, B, M, N, K, C=None, C32=None, bias=None, addend=None, aux=No
                          drop[0], drop[1])
 
 
+def gemm_variant(v=None):
+    """main loop of the 256-row GEMM launches (include/kbner.h: kbner_gemm_set_variant); -> the previous value"""
+    prev = int(L.load().kbner_gemm_get_variant())
+    if v is not None:
+        L.call("kbner_gemm_set_variant", int(v))
+    return prev
+
+
 def gemm_grouped(layout, problems):
     """problems: list (<= 16) of L.GemmProblem (make_problem) of one layout; 256x256x64 8-wave kernel.
     -> True when the launch used the dynamic tile draw (always 256-row tiles), False for the static kernel."""
