@@ -26,7 +26,7 @@
 
 #define G2_MAXP 16
 #ifndef KBNER_GEMM_VARIANT_DEFAULT
-#define KBNER_GEMM_VARIANT_DEFAULT 0
+#define KBNER_GEMM_VARIANT_DEFAULT 2048
 #endif
 
 struct GemmProblem {
@@ -746,6 +746,7 @@ __global__ __launch_bounds__(512, 2) void gemm256pp_kernel(const GroupArgs ga) {
   const bool nodma = (flags & PP_FLAG_NODMA) != 0;
   const bool nomfma = (flags & PP_FLAG_NOMFMA) != 0;
   const bool noreads = (flags & PP_FLAG_NOREADS) != 0;
+  G2_CLK(0)
 
   // ---- issue cursor: the (tile, K stage) the next DMA belongs to; runs two stages ahead of the consumer, across tiles
   int i_id = blockIdx.x, i_t = 0, i_nt = 0, i_m0 = 0, i_n0 = 0, i_lda = 0, i_ldb = 0;
@@ -959,6 +960,7 @@ __global__ __launch_bounds__(512, 2) void gemm256pp_kernel(const GroupArgs ga) {
     if (id >= total) break;
   }
   if (grp == 0) pp_barrier();   // pairs with group 1's last trailing barrier
+  G2_CLK(1)
 #undef PP_ILOAD
 #undef PP_ISSUE_A
 #undef PP_ISSUE_B
@@ -1007,6 +1009,7 @@ __global__ __launch_bounds__(512, 2) void gemm256rot_kernel(const GroupArgs ga) 
   const bool nodma = (flags & PP_FLAG_NODMA) != 0;
   const bool nomfma = (flags & PP_FLAG_NOMFMA) != 0;
   const bool noreads = (flags & PP_FLAG_NOREADS) != 0;
+  G2_CLK(0)
 
   int i_id = blockIdx.x, i_t = 0, i_nt = 0, i_m0 = 0, i_n0 = 0, i_lda = 0, i_ldb = 0;
   const bf16_t* i_A = nullptr;
@@ -1191,6 +1194,7 @@ __global__ __launch_bounds__(512, 2) void gemm256rot_kernel(const GroupArgs ga) 
     p_last_a = (ca == 0) ? 2 : ca - 1;
     id += gstep;
   }
+  G2_CLK(1)
 #undef PR_ILOAD
 #undef PR_IADV
 #undef PR_WAIT
@@ -1198,129 +1202,142 @@ __global__ __launch_bounds__(512, 2) void gemm256rot_kernel(const GroupArgs ga) 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// The RING loop (round 4, what the ping-pong measurements above led back to).  Findings: an s_barrier at which the matrix pipe
-// runs dry costs 100-280 cycles of MFMA time (4-barrier ping-pong with MFMAs only: 1.29 us per K step against 1.03 of MFMA
-// issue; rotated 2-barrier: 1.31), so phases separated by barriers cannot win; what the two-stage loop of rounds 1-3 loses per
-// K step is (a) the burst of 8 LDS-DMA pieces every wave queues right after the barrier (~47 cycles of issue each, nobody has
-// an MFMA to issue meanwhile), and (b) the latency of the first fragment reads of the new stage, also behind the barrier.
-// Here: ONE barrier per K step as before, identical code in all 8 waves (the two waves of a SIMD interleave by themselves), but
-//   * operand RING, 3 A slots + 2 B slots of 32 KiB: A(t+2) and B(t+1) are issued during step t, so their issue is not tied to
-//     the barrier -- one piece in front of each of the first six MFMA groups of the step (hidden under the partner wave's
-//     MFMAs) -- and A has two steps to land (B, the small re-used operand of the forward / dgrad layouts, one);
-//   * the LAST MFMA group of a step is held back across the barrier: after the barrier a wave first requests the first
+// The RING loop (round 4).  Cycle accounting (tools/gemm_clk.sh, profiles/round4_gemm_cycle_accounting.txt: s_memtime against
+// s_memrealtime inside the kernels) says every main loop tried takes 2900-3060 shader cycles per K step against 2100 of MFMA
+// pipe time per SIMD, whatever the wall clock does (the chip runs these kernels at 1.7-1.8 GHz on random data and 2.3 on zeros:
+// wall-time A/Bs mostly measure power).  An MFMA blocks its wave's issue for its 16.4 cycles and every other instruction for
+// ~4-5, so the two waves of a SIMD only keep the pipe busy if neither stalls: the two-stage loop of rounds 1-3 (93 non-MFMA
+// instructions per wave and step) loses ~800 cycles per step to what happens at its barrier -- all eight waves queue their 8
+// LDS-DMA pieces right behind it (~50 cycles of issue each, both waves of every SIMD at the same time) and then wait out the
+// latency of the new stage's first fragment reads --, and the ping-pong / fine-grained variants above spend what they win there
+// on extra scalar work (branches, cursor arithmetic: 200 non-MFMA instructions per step = 1100 cycles per wave).
+// This loop keeps the two-stage loop's instruction stream (identical code in all 8 waves, 8-MFMA groups with the next group's
+// fragments read one group ahead, one barrier per K step) and changes what happens around the barrier:
+//   * operand RING (3 A slots + 2 B slots of 32 KiB): the DMA of a step is no longer tied to its barrier.  A wave's four pieces of
+//     B(t+1) and of A(t+2) go out as two bursts in the middle of step t, at DIFFERENT points for the two waves of a SIMD (group
+//     0 = waves 0-3 after MFMA groups 0 and 2, group 1 = waves 4-7 after groups 2 and 4), so the partner wave has the matrix
+//     pipe to itself meanwhile; A has two steps to land, B (the L2-resident weight in the forward / dgrad layouts) most of one;
+//   * the LAST MFMA group of a step is held back across the barrier: behind the barrier a wave first requests the first six
 //     fragments of the new stage, then issues the 8 held MFMAs, which cover that LDS latency;
-//   * the wait for the DMA sits in front of the barrier that precedes the epilogue, so no epilogue store is ever in the vmcnt
-//     queue in front of a load that must be waited for (no `pend` bookkeeping); that same barrier frees the A slot consumed
-//     last, whose wave-private 4 KiB are the epilogue's transpose scratch.
-template <bool A_KS, bool B_KS>
+//   * the DMA wait sits in front of the barrier that precedes the EPILOGUE too, so no epilogue store is ever queued in front of a
+//     load that has to be waited for (no `pend` bookkeeping), and that barrier frees the A slot consumed last, whose wave-private
+//     4 KiB are the epilogue's transpose scratch (the slot's next DMA, A(2) of the next tile, is the wave's own pieces);
+//   * running pointers instead of per-step address arithmetic: ~35 scalar instructions per step.
+// ABL (trace builds): compile-time ablations for cycle accounting: 1 no barrier, 2 fragment reads only in a tile's first step,
+// 4 no MFMAs, 8 no in-loop DMA (timing only, wrong results).
+static __device__ __forceinline__ void glds16_quad(const void* sbase, unsigned v0, unsigned v1, unsigned v2, unsigned v3, unsigned dst) {
+  // v_j already carries the - j KiB of the immediate offsets (stage_voff)
+  asm volatile(
+      "s_mov_b32 m0, %5\n\ts_nop 0\n\t"
+      "global_load_lds_dwordx4 %0, %4\n\t"
+      "global_load_lds_dwordx4 %1, %4 offset:1024\n\t"
+      "global_load_lds_dwordx4 %2, %4 offset:2048\n\t"
+      "global_load_lds_dwordx4 %3, %4 offset:3072"
+      :
+      : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(sbase), "s"(dst)
+      : "memory", "m0");
+}
+
+template <bool A_KS, bool B_KS, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void gemm256r_kernel(const GroupArgs ga) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid >> 2, wn = wid & 3;
+  const int grp = wm;
   const int total = ga.total_tiles;
   const int gstep = (int)gridDim.x;
-  const int flags = ga.pad_;
-  const bool nodma = (flags & PP_FLAG_NODMA) != 0;
-  const bool strong = (flags & PP_FLAG_STRONGWAIT) != 0;
-  const bool nobar = (flags & 512) != 0;      // ablation (timing only): no barrier in the K loop
-  const bool halfreads = (flags & 1024) != 0;  // ablation (timing only): the a1 fragments are never reloaded
-  const bool nomfma = (flags & PP_FLAG_NOMFMA) != 0;
+  G2_CLK(0)
 
   int lane_m = lane;   // opaque copy for the main loop's address arithmetic (see gemm256pp_kernel)
   asm volatile("" : "+v"(lane_m));
-  // ---- two issue cursors (tile, K stage) running ahead of the consumer across tiles: A by two stages, B by one
-  int a_id = blockIdx.x, a_t = 0, a_nt = 0, a_m0 = 0, a_ld = 0;
-  const bf16_t* a_P = nullptr;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void*)smem);
+  // ---- two issue cursors running ahead of the consumer across tiles (A by two K stages, B by one): a running source pointer,
+  // the steps left in the cursor's tile, the LDS address of the wave's four pieces in the next ring slot
+  int a_id = blockIdx.x, a_left = 0;
+  const bf16_t* a_ptr = nullptr;
+  size_t a_stride = 0;
   bool a_ok = true;
-  int ia = 0;
+  unsigned a_dst = lds0 + wid * 4096;
   unsigned va[4];
-  int b_id = blockIdx.x, b_t = 0, b_nt = 0, b_n0 = 0, b_ld = 0;
-  const bf16_t* b_P = nullptr;
+  int b_id = blockIdx.x, b_left = 0;
+  const bf16_t* b_ptr = nullptr;
+  size_t b_stride = 0;
   bool b_ok = true;
-  int ib = 0;
+  unsigned b_dst = lds0 + PP_B_BASE + wid * 4096;
   unsigned vb[4];
-#define RR_ALOAD()                                   \
-  {                                                  \
-    GemmProblem gi;                                  \
-    int nn_;                                         \
-    pick_tile<256>(ga, a_id, total, gi, a_m0, nn_);  \
-    a_nt = gi.K / BK2;                               \
-    a_P = gi.A;                                      \
-    a_ld = gi.lda;                                   \
-    stage_voff<A_KS, false>(a_ld, wid, lane_m, va);  \
+#define RR_ALOAD()                                                                        \
+  {                                                                                       \
+    GemmProblem gi;                                                                       \
+    int m_, n_;                                                                           \
+    pick_tile<256>(ga, a_id, total, gi, m_, n_);                                          \
+    a_left = gi.K / BK2;                                                                  \
+    a_ptr = A_KS ? gi.A + m_ : gi.A + (size_t)m_ * gi.lda;                               \
+    a_stride = A_KS ? (size_t)BK2 * gi.lda : (size_t)BK2;                                 \
+    stage_voff<A_KS, false>(gi.lda, wid, lane_m, va);                                     \
   }
-#define RR_BLOAD()                                   \
-  {                                                  \
-    GemmProblem gi;                                  \
-    int mm_;                                         \
-    pick_tile<256>(ga, b_id, total, gi, mm_, b_n0);  \
-    b_nt = gi.K / BK2;                               \
-    b_P = gi.B;                                      \
-    b_ld = gi.ldb;                                   \
-    stage_voff<B_KS, true>(b_ld, wid, lane_m, vb);   \
+#define RR_BLOAD()                                                                        \
+  {                                                                                       \
+    GemmProblem gi;                                                                       \
+    int m_, n_;                                                                           \
+    pick_tile<256>(ga, b_id, total, gi, m_, n_);                                          \
+    b_left = gi.K / BK2;                                                                  \
+    b_ptr = B_KS ? gi.B + n_ : gi.B + (size_t)n_ * gi.ldb;                               \
+    b_stride = B_KS ? (size_t)BK2 * gi.ldb : (size_t)BK2;                                 \
+    stage_voff<B_KS, true>(gi.ldb, wid, lane_m, vb);                                      \
   }
-#define RR_AADV()                   \
-  {                                 \
-    if (++a_t == a_nt) {            \
-      a_t = 0;                      \
-      a_id += gstep;                \
-      if (a_id < total) RR_ALOAD()  \
-      else a_ok = false;            \
-    }                               \
-    ia = (ia == 2) ? 0 : ia + 1;    \
+#define RR_AADV()                                                       \
+  {                                                                     \
+    a_ptr += a_stride;                                                  \
+    a_dst = (a_dst + TILE2_BYTES >= lds0 + PP_B_BASE) ? a_dst - 2 * TILE2_BYTES : a_dst + TILE2_BYTES; \
+    if (--a_left == 0) {                                                \
+      a_id += gstep;                                                    \
+      if (a_id < total) RR_ALOAD()                                      \
+      else a_ok = false;                                                \
+    }                                                                   \
   }
-#define RR_BADV()                   \
-  {                                 \
-    if (++b_t == b_nt) {            \
-      b_t = 0;                      \
-      b_id += gstep;                \
-      if (b_id < total) RR_BLOAD()  \
-      else b_ok = false;            \
-    }                               \
-    ib ^= 1;                        \
+#define RR_BADV()                                                       \
+  {                                                                     \
+    b_ptr += b_stride;                                                  \
+    b_dst = (2 * (lds0 + PP_B_BASE + wid * 4096) + TILE2_BYTES) - b_dst; \
+    if (--b_left == 0) {                                                \
+      b_id += gstep;                                                    \
+      if (b_id < total) RR_BLOAD()                                      \
+      else b_ok = false;                                                \
+    }                                                                   \
   }
-#define RR_ABASE() (A_KS ? a_P + (size_t)(a_t * BK2) * a_ld + a_m0 : a_P + (size_t)a_m0 * a_ld + a_t * BK2)
-#define RR_BBASE() (B_KS ? b_P + (size_t)(b_t * BK2) * b_ld + b_n0 : b_P + (size_t)b_n0 * b_ld + b_t * BK2)
-#define RR_ADST() __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void*)(smem + ia * TILE2_BYTES + wid * 4096))
-#define RR_BDST() __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void*)(smem + PP_B_BASE + ib * TILE2_BYTES + wid * 4096))
+#define RR_ABURST() glds16_quad(a_ptr, va[0], va[1], va[2], va[3], a_dst)
+#define RR_BBURST() glds16_quad(b_ptr, vb[0], vb[1], vb[2], vb[3], b_dst)
 
   RR_ALOAD();
   RR_BLOAD();
-  {
-    const bf16_t* pa = RR_ABASE();
-    const unsigned da = RR_ADST();
-    glds16_pair<0>(pa, va[0], va[1], da);
-    glds16_pair<2>(pa, va[2], va[3], da);
+  RR_ABURST();
+  RR_AADV();
+  RR_BBURST();
+  RR_BADV();
+  if (a_ok) {
+    RR_ABURST();
     RR_AADV();
-    const bf16_t* pb = RR_BBASE();
-    const unsigned db = RR_BDST();
-    glds16_pair<0>(pb, vb[0], vb[1], db);
-    glds16_pair<2>(pb, vb[2], vb[3], db);
-    RR_BADV();
-    if (a_ok) {
-      const bf16_t* pa1 = RR_ABASE();
-      const unsigned da1 = RR_ADST();
-      glds16_pair<0>(pa1, va[0], va[1], da1);
-      glds16_pair<2>(pa1, va[2], va[3], da1);
-      RR_AADV();
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   pp_barrier();   // stage 0 of the first tile is visible
 
   int id = blockIdx.x;
-  int ca = 0, cb = 0;
+  unsigned sa_off = 0, sb_off = PP_B_BASE;   // ring slots of the stage being consumed (byte offsets into smem)
 #define RR_SB() __builtin_amdgcn_sched_barrier(0)
-#define RR_LOADB(dst, ks) _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) dst[ni] = fragB256<B_KS>(sb, wn * 64, ni, ks, lane_m)
-#define RR_LOADA(dst, ks, pr)                                          \
-  dst[0] = frag256<A_KS>(sa, wm * 128 + (2 * (pr)) * 16, ks, lane_m);  \
-  dst[1] = frag256<A_KS>(sa, wm * 128 + (2 * (pr) + 1) * 16, ks, lane_m)
-#define RR_MM(a, b, pr)                                                                                              \
-  if (!nomfma) _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) acc[2 * (pr) + j][ni] = \
+#define RR_RD (!(ABL & 2) || t == 0)
+#define RR_LOADB(dst, ks) \
+  if (RR_RD) _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) dst[ni] = fragB256<B_KS>(smem + sb_off, wn * 64, ni, ks, lane_m)
+#define RR_LOADA(dst, ks, pr)                                                            \
+  if (RR_RD) {                                                                           \
+    dst[0] = frag256<A_KS>(smem + sa_off, wm * 128 + (2 * (pr)) * 16, ks, lane_m);       \
+    dst[1] = frag256<A_KS>(smem + sa_off, wm * 128 + (2 * (pr) + 1) * 16, ks, lane_m);   \
+  }
+#define RR_MM(a, b, pr)                                                                                                              \
+  if (!(ABL & 4)) _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) acc[2 * (pr) + j][ni] = \
       __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[ni], a[j], acc[2 * (pr) + j][ni], 0, 0, 0)
   for (;;) {
     int m0, n0, nt;
@@ -1330,11 +1347,17 @@ __global__ __launch_bounds__(512, 2) void gemm256r_kernel(const GroupArgs ga) {
       nt = gm.K / BK2;
     }
     bf16x8 b0[4], b1[4], a0[2], a1[2];
-    a1[0] = a1[1] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-    const unsigned char* sa = smem + ca * TILE2_BYTES;
-    const unsigned char* sb = smem + PP_B_BASE + cb * TILE2_BYTES;
-    RR_LOADB(b0, 0);
-    RR_LOADA(a0, 0, 0);
+    if (ABL & 2) {
+      a1[0] = a1[1] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) b1[ni] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    }
+    {
+      const int t = 0;
+      (void)t;
+      RR_LOADB(b0, 0);
+      RR_LOADA(a0, 0, 0);
+    }
     f4v acc[8][4];
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi)
@@ -1342,38 +1365,38 @@ __global__ __launch_bounds__(512, 2) void gemm256r_kernel(const GroupArgs ga) {
       for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
     RR_SB();
     for (int t = 0; t < nt; ++t) {
-      // DMA of this step: B(t+1) first (one step to land), then A(t+2); one pair / piece in front of an MFMA group
-      const bool isb = b_ok && !nodma, isa = a_ok && !nodma;
-      const bf16_t* pb = RR_BBASE();
-      const unsigned db = RR_BDST();
-      const bf16_t* pa = RR_ABASE();
-      const unsigned da = RR_ADST();
-      if (isb) glds16_pair<0>(pb, vb[0], vb[1], db);
-      if (!halfreads) { RR_LOADA(a1, 0, 1); } RR_SB(); RR_MM(a0, b0, 0); RR_SB();
-      if (isb) glds16_pair<2>(pb, vb[2], vb[3], db);
+      const bool isb = b_ok && !(ABL & (8 | 16)), isa = a_ok && !(ABL & (8 | 32));   // 16 / 32: no B / no A bursts
+      // DMA bursts at eight positions of the step, two waves (of different SIMDs) per position: the CU's one address pipe takes
+      // ~16 cycles per 1-KiB piece, so four waves bursting together each wait ~50 cycles per piece, two waves ~20
+      const int wp = wid >> 1;
+      RR_LOADA(a1, 0, 1); RR_SB(); RR_MM(a0, b0, 0); RR_SB();
+      if (wp == 0 && isb) RR_BBURST();
       RR_LOADA(a0, 0, 2); RR_SB(); RR_MM(a1, b0, 1); RR_SB();
-      if (isa) glds16_piece<0>(pa, va[0], da);
-      if (!halfreads) { RR_LOADA(a1, 0, 3); } RR_SB(); RR_MM(a0, b0, 2); RR_SB();
-      if (isa) glds16_piece<1>(pa, va[1], da);
+      if (wp == 1 && isb) RR_BBURST();
+      RR_LOADA(a1, 0, 3); RR_SB(); RR_MM(a0, b0, 2); RR_SB();
+      if (wp == 2 && isb) RR_BBURST();
       RR_LOADB(b1, 1);
       RR_LOADA(a0, 1, 0); RR_SB(); RR_MM(a1, b0, 3); RR_SB();
-      if (isa) glds16_piece<2>(pa, va[2], da);
-      if (!halfreads) { RR_LOADA(a1, 1, 1); } RR_SB(); RR_MM(a0, b1, 0); RR_SB();
-      if (isa) glds16_piece<3>(pa, va[3], da);
+      if (wp == 3 && isb) RR_BBURST();
+      RR_LOADA(a1, 1, 1); RR_SB(); RR_MM(a0, b1, 0); RR_SB();
+      if (wp == 0 && isa) RR_ABURST();
       RR_LOADA(a0, 1, 2); RR_SB(); RR_MM(a1, b1, 1); RR_SB();
-      if (!halfreads) { RR_LOADA(a1, 1, 3); } RR_SB(); RR_MM(a0, b1, 2); RR_SB();
+      if (wp == 1 && isa) RR_ABURST();
+      RR_LOADA(a1, 1, 3); RR_SB(); RR_MM(a0, b1, 2); RR_SB();
+      if (wp == 2 && isa) RR_ABURST();
+      if (wp == 3 && isa) RR_ABURST();
       if (b_ok) RR_BADV();
       if (a_ok) RR_AADV();
       // B(t+1) (and the older A(t+1)) have landed: the only younger pieces in this wave's queue are A(t+2)'s four
-      if (isa && !strong) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      if (isa) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (!nobar) pp_barrier();
-      ca = (ca == 2) ? 0 : ca + 1;
-      cb ^= 1;
+      // (the builtin, not inline asm: hipcc must KNOW the LGKM queue is empty here -- the scalar loads of a cursor's tile crossing
+      // would otherwise leave it assuming mixed SMEM / LDS events and turn every later counted lgkmcnt into lgkmcnt(0))
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      if (!(ABL & 1)) pp_barrier();
+      sa_off = (sa_off == 2 * TILE2_BYTES) ? 0u : sa_off + TILE2_BYTES;
+      sb_off = (2 * PP_B_BASE + TILE2_BYTES) - sb_off;
       if (t + 1 < nt) {
-        sa = smem + ca * TILE2_BYTES;
-        sb = smem + PP_B_BASE + cb * TILE2_BYTES;
         RR_LOADB(b0, 0);
         RR_LOADA(a0, 0, 0);
         RR_SB();
@@ -1390,8 +1413,8 @@ __global__ __launch_bounds__(512, 2) void gemm256r_kernel(const GroupArgs ga) {
       pick_tile<256>(ga, id, total, g, mm, nn);
     }
     const int epi = g.epi;
-    const int last_a = (ca == 0) ? 2 : ca - 1;
-    unsigned char* scr = smem + last_a * TILE2_BYTES + wid * 4096;
+    // the A slot consumed last (sa_off already points at the next one)
+    unsigned char* scr = smem + ((sa_off == 0) ? 2 * TILE2_BYTES : sa_off - TILE2_BYTES) + wid * 4096;
     if (!B_KS) {
       switch (epi) {
         case 0: epilogue256<0, 8>(g, acc, m0, n0, wm, wn, lane, scr); break;
@@ -1417,45 +1440,43 @@ __global__ __launch_bounds__(512, 2) void gemm256r_kernel(const GroupArgs ga) {
     lane_m = lane;
     asm volatile("" : "+v"(lane_m));
   }
+  G2_CLK(1)
 #undef RR_ALOAD
 #undef RR_BLOAD
 #undef RR_AADV
 #undef RR_BADV
-#undef RR_ABASE
-#undef RR_BBASE
-#undef RR_ADST
-#undef RR_BDST
+#undef RR_ABURST
+#undef RR_BBURST
 #undef RR_SB
+#undef RR_RD
 #undef RR_LOADB
 #undef RR_LOADA
 #undef RR_MM
 }
 
-template <bool A_KS, bool B_KS>
+template <bool A_KS, bool B_KS, int ABL = 0>
 static int launch256r(GroupArgs& ga, int flags, hipStream_t stream) {
   static std::atomic<unsigned long long> attr_done{0};
-  const int r = kbner_set_max_lds_once(attr_done, reinterpret_cast<const void*>(gemm256r_kernel<A_KS, B_KS>), PP_LDS_BYTES);
+  const int r = kbner_set_max_lds_once(attr_done, reinterpret_cast<const void*>(gemm256r_kernel<A_KS, B_KS, ABL>), PP_LDS_BYTES);
   if (r) return r;
   ga.pad_ = flags;
   const int grid = ga.total_tiles < ga.ncu ? ga.total_tiles : ga.ncu;
-  hipLaunchKernelGGL((gemm256r_kernel<A_KS, B_KS>), dim3(grid), dim3(512), PP_LDS_BYTES, stream, ga);
+  hipLaunchKernelGGL((gemm256r_kernel<A_KS, B_KS, ABL>), dim3(grid), dim3(512), PP_LDS_BYTES, stream, ga);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// The FINE-GRAINED ring loop (round 4, final form).  What the variants above taught: the two waves of a SIMD run IDENTICAL code
-// from the same barrier, so they stay in lockstep -- both issue their MFMA groups at the same time (sharing the pipe) and both
-// sit in their non-MFMA chunks (fragment reads, address arithmetic, DMA pieces: ~150 issue cycles per 8-MFMA group) at the same
-// time, when the matrix pipe has nothing to do: pipe busy ~2/3, which is the 1.55-1.65 us per K step every coarse-grained
-// variant lands on (two-stage 1.59-1.64, ping-pong 1.53-1.61, ring 1.57-1.65) against 1.08 us of MFMA issue on random data.
-// Here the non-MFMA work is cut into single instructions placed BETWEEN the MFMAs of a quad (one A fragment x four B
-// fragments): an MFMA leaves the pipe busy for 16 cycles (32 with the partner wave's), a fragment read or an address op costs
-// an issue slot of ~4, so lockstep no longer matters.  The one long instruction, an LDS-DMA piece (~50-60 cycles of issue), is
-// issued by group 0 (waves 0-3) after even quads and by group 1 (waves 4-7: the other wave of every SIMD) after odd quads.
-// Ring, cursors, waits, held last quad and epilogue as in gemm256r_kernel.
-// ABL (trace builds only): compile-time ablations for cycle accounting -- 1 no barrier in the K loop, 2 no fragment reads after a
-// tile's first K step, 4 no MFMAs (timing only, wrong results)
+// The INTERLEAVED ring loop (round 4, final form).  tools/micro/issue_probe.hip is the cost model behind it: next to 64 MFMAs
+// per wave and two waves per SIMD in lockstep (identical code from the same barrier -- the GEMM's situation), an instruction
+// that sits BETWEEN two MFMAs is free (40 scalar instructions +5 cycles, 24 fragment reads +44, 8 LDS-DMA pieces +64), while the
+// same instructions in chunks between 8-MFMA groups are not (+212 / +70 / +137): both waves are in their chunks at the same time
+// and the matrix pipe has nothing to issue.  The two-stage loop's shape (barrier, 8-piece DMA burst, 8 x (3 reads + scalar work,
+// 8 MFMAs)) costs 2861 cycles per K step in the probe and 2950 in the kernel; the same ingredients spread out cost 2150.
+// So: the ring of gemm256r_kernel (operand slots, running cursors, DMA wait in front of the pre-epilogue barrier, last group
+// held across the barrier), its 8-MFMA groups and their one-group-ahead fragment prefetch -- but every fragment read, every DMA
+// piece (own M0 write: two scalar instructions) and the cursor arithmetic is a statement placed after ONE MFMA, pinned with
+// sched_barrier; no branch inside a step.
 template <bool A_KS, bool B_KS, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void gemm256f_kernel(const GroupArgs ga) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1463,103 +1484,216 @@ __global__ __launch_bounds__(512, 2) void gemm256f_kernel(const GroupArgs ga) {
   const int lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid >> 2, wn = wid & 3;
-  const int grp = wm;
   const int total = ga.total_tiles;
   const int gstep = (int)gridDim.x;
-  const int flags = ga.pad_;
-  const bool nodma = (flags & PP_FLAG_NODMA) != 0;
-  const bool strong = (flags & PP_FLAG_STRONGWAIT) != 0;
-
   G2_CLK(0)
-  int lane_m = lane;
+
+  int lane_m = lane;   // opaque copy for the main loop's address arithmetic (see gemm256pp_kernel)
   asm volatile("" : "+v"(lane_m));
-  int a_id = blockIdx.x, a_t = 0, a_nt = 0, a_m0 = 0, a_ld = 0;
-  const bf16_t* a_P = nullptr;
-  bool a_ok = true;
-  int ia = 0;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void*)smem);
+  int a_id = blockIdx.x, a_left = 0;
+  const bf16_t* a_ptr = nullptr;
+  size_t a_stride = 0;
+  unsigned a_dst = lds0 + wid * 4096;
   unsigned va[4];
-  int b_id = blockIdx.x, b_t = 0, b_nt = 0, b_n0 = 0, b_ld = 0;
-  const bf16_t* b_P = nullptr;
-  bool b_ok = true;
-  int ib = 0;
+  int b_id = blockIdx.x, b_left = 0;
+  const bf16_t* b_ptr = nullptr;
+  size_t b_stride = 0;
+  unsigned b_dst = lds0 + PP_B_BASE + wid * 4096;
   unsigned vb[4];
-#define RF_ALOAD()                                   \
-  {                                                  \
-    GemmProblem gi;                                  \
-    int nn_;                                         \
-    pick_tile<256>(ga, a_id, total, gi, a_m0, nn_);  \
-    a_nt = gi.K / BK2;                               \
-    a_P = gi.A;                                      \
-    a_ld = gi.lda;                                   \
-    stage_voff<A_KS, false>(a_ld, wid, lane_m, va);  \
+#define RF_ALOAD()                                                                        \
+  {                                                                                       \
+    GemmProblem gi;                                                                       \
+    int m_, n_;                                                                           \
+    pick_tile<256>(ga, a_id, total, gi, m_, n_);                                          \
+    a_left = gi.K / BK2;                                                                  \
+    a_ptr = A_KS ? gi.A + m_ : gi.A + (size_t)m_ * gi.lda;                               \
+    a_stride = A_KS ? (size_t)BK2 * gi.lda : (size_t)BK2;                                 \
+    stage_voff<A_KS, false>(gi.lda, wid, lane_m, va);                                     \
   }
-#define RF_BLOAD()                                   \
-  {                                                  \
-    GemmProblem gi;                                  \
-    int mm_;                                         \
-    pick_tile<256>(ga, b_id, total, gi, mm_, b_n0);  \
-    b_nt = gi.K / BK2;                               \
-    b_P = gi.B;                                      \
-    b_ld = gi.ldb;                                   \
-    stage_voff<B_KS, true>(b_ld, wid, lane_m, vb);   \
+#define RF_BLOAD()                                                                        \
+  {                                                                                       \
+    GemmProblem gi;                                                                       \
+    int m_, n_;                                                                           \
+    pick_tile<256>(ga, b_id, total, gi, m_, n_);                                          \
+    b_left = gi.K / BK2;                                                                  \
+    b_ptr = B_KS ? gi.B + n_ : gi.B + (size_t)n_ * gi.ldb;                               \
+    b_stride = B_KS ? (size_t)BK2 * gi.ldb : (size_t)BK2;                                 \
+    stage_voff<B_KS, true>(gi.ldb, wid, lane_m, vb);                                      \
   }
-#define RF_AADV()                   \
-  {                                 \
-    if (++a_t == a_nt) {            \
-      a_t = 0;                      \
-      a_id += gstep;                \
-      if (a_id < total) RF_ALOAD()  \
-      else a_ok = false;            \
-    }                               \
-    ia = (ia == 2) ? 0 : ia + 1;    \
+  // the cheap half of a cursor step (fillers between MFMAs) and its rare tile crossing (behind the step's last MFMA)
+#define RF_AADV_PTR()                                                   \
+  {                                                                     \
+    a_ptr += a_stride;                                                  \
+    a_dst = (a_dst + TILE2_BYTES >= lds0 + PP_B_BASE) ? a_dst - 2 * TILE2_BYTES : a_dst + TILE2_BYTES; \
   }
-#define RF_BADV()                   \
-  {                                 \
-    if (++b_t == b_nt) {            \
-      b_t = 0;                      \
-      b_id += gstep;                \
-      if (b_id < total) RF_BLOAD()  \
-      else b_ok = false;            \
-    }                               \
-    ib ^= 1;                        \
+#define RF_BADV_PTR()                                                   \
+  {                                                                     \
+    b_ptr += b_stride;                                                  \
+    b_dst = (2 * (lds0 + PP_B_BASE + wid * 4096) + TILE2_BYTES) - b_dst; \
   }
-#define RF_ABASE() (A_KS ? a_P + (size_t)(a_t * BK2) * a_ld + a_m0 : a_P + (size_t)a_m0 * a_ld + a_t * BK2)
-#define RF_BBASE() (B_KS ? b_P + (size_t)(b_t * BK2) * b_ld + b_n0 : b_P + (size_t)b_n0 * b_ld + b_t * BK2)
-#define RF_ADST() __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void*)(smem + ia * TILE2_BYTES + wid * 4096))
-#define RF_BDST() __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void*)(smem + PP_B_BASE + ib * TILE2_BYTES + wid * 4096))
+#define RF_AADV_TILE()                                                  \
+  {                                                                     \
+    if (--a_left == 0) {                                                \
+      a_id += gstep;                                                    \
+      if (a_id < total) RF_ALOAD()                                      \
+      else {                                                            \
+        a_ptr -= a_stride; /* exhausted: keep re-reading the last stage (see RF_BODY) */ \
+        a_stride = 0;                                                   \
+        a_left = 0x7fffffff;                                            \
+      }                                                                 \
+    }                                                                   \
+  }
+#define RF_BADV_TILE()                                                  \
+  {                                                                     \
+    if (--b_left == 0) {                                                \
+      b_id += gstep;                                                    \
+      if (b_id < total) RF_BLOAD()                                      \
+      else {                                                            \
+        b_ptr -= b_stride;                                              \
+        b_stride = 0;                                                   \
+        b_left = 0x7fffffff;                                            \
+      }                                                                 \
+    }                                                                   \
+  }
 
   RF_ALOAD();
   RF_BLOAD();
-  {
-    const bf16_t* pa = RF_ABASE();
-    const unsigned da = RF_ADST();
-    glds16_pair<0>(pa, va[0], va[1], da);
-    glds16_pair<2>(pa, va[2], va[3], da);
-    RF_AADV();
-    const bf16_t* pb = RF_BBASE();
-    const unsigned db = RF_BDST();
-    glds16_pair<0>(pb, vb[0], vb[1], db);
-    glds16_pair<2>(pb, vb[2], vb[3], db);
-    RF_BADV();
-    if (a_ok) {
-      const bf16_t* pa1 = RF_ABASE();
-      const unsigned da1 = RF_ADST();
-      glds16_pair<0>(pa1, va[0], va[1], da1);
-      glds16_pair<2>(pa1, va[2], va[3], da1);
-      RF_AADV();
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-  }
-  pp_barrier();
+  glds16_quad(a_ptr, va[0], va[1], va[2], va[3], a_dst);
+  RF_AADV_PTR();
+  RF_AADV_TILE();
+  glds16_quad(b_ptr, vb[0], vb[1], vb[2], vb[3], b_dst);
+  RF_BADV_PTR();
+  RF_BADV_TILE();
+  glds16_quad(a_ptr, va[0], va[1], va[2], va[3], a_dst);
+  RF_AADV_PTR();
+  RF_AADV_TILE();
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  pp_barrier();   // stage 0 of the first tile is visible
 
   int id = blockIdx.x;
-  int ca = 0, cb = 0;
+  unsigned sa_off = 0, sb_off = PP_B_BASE;
 #define RF_SB() __builtin_amdgcn_sched_barrier(0)
-#define RF_FA(ks, mi) (((ABL & 2) && t > 0) ? af[0] : frag256<A_KS>(sa, wm * 128 + (mi) * 16, ks, lane_m))
-#define RF_FB(ks, ni) (((ABL & 2) && t > 0) ? bq[0][0] : fragB256<B_KS>(sb, wn * 64, ni, ks, lane_m))
-#define RF_MFMA(mi, ni, bfr, afr) if (!(ABL & 4)) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr, afr, acc[mi][ni], 0, 0, 0)
+#define RF_NOP (void)0
+  // Fragment addresses.  Row-major (KC) images: ONE address register per operand and k half for the whole step -- the row block
+  // (A: mi * 2 KiB, B: (ni >> 1) * 4 KiB + (ni & 1) * 512 B) is the ds_read's immediate offset and k half 1 is k half 0 with
+  // bit 6 flipped (the chunk swizzles only look at row bits the row block does not touch) -- made opaque so that hipcc keeps this
+  // form (left alone it hoists eight per-row-block registers out of the loop and adds the slot offset to each: two VALU
+  // instructions per read, each of which takes the matrix pipe's issue port)
+  typedef const s8v __attribute__((address_space(3))) lds_s8v;
+  unsigned laneA = 0, laneB = 0, pa0 = 0, pa1 = 0, pb0 = 0, pb1 = 0;
+  (void)pa1;
+#define RF_LANE_BASES()                                                                                          \
+  {                                                                                                              \
+    if (!A_KS) {                                                                                                 \
+      const int row = wm * 128 + (lane_m & 15);                                                                  \
+      laneA = lds0 + row * 128 + ((((lane_m >> 4)) ^ kc_swz(row)) << 4);                                         \
+    } else { /* k-strided image: k row r, 32-byte block (row block ^ swizzle): the row block mi enters by XOR, see fa_ */ \
+      const int p = lane_m & 15;                                                                                 \
+      const int r = (lane_m >> 4) * 8 + (p >> 2);                                                                \
+      laneA = lds0 + r * 512 + ((p & 3) << 3) + wm * 256 + (ks_swz(r) << 5);                                     \
+    }                                                                                                            \
+    if (!B_KS) {                                                                                                 \
+      const int j = lane_m & 15;                                                                                 \
+      const int row = wn * 64 + (j >> 2) * 8 + (j & 3);                                                          \
+      laneB = lds0 + row * 128 + ((((lane_m >> 4)) ^ kcb_swz(row)) << 4);                                        \
+    } else {                                                                                                     \
+      const int p = lane_m & 15;                                                                                 \
+      const int r = (lane_m >> 4) * 8 + (p >> 2);                                                                \
+      laneB = lds0 + r * 512 + (((wn * 4 + ((p & 3) >> 1)) ^ ks_swz(r)) << 5) + (((p & 3) & 1) << 4);            \
+    }                                                                                                            \
+  }
+#define RF_STEP_BASES()                                          \
+  {                                                              \
+    pa0 = laneA + sa_off;                                        \
+    asm volatile("" : "+v"(pa0));                                \
+    if (!A_KS) {                                                 \
+      pa1 = pa0 ^ 64u;                                           \
+      asm volatile("" : "+v"(pa1));                              \
+    }                                                            \
+    pb0 = laneB + sb_off;                                        \
+    asm volatile("" : "+v"(pb0));                                \
+    pb1 = pb0 ^ 64u;                                             \
+    asm volatile("" : "+v"(pb1));                                \
+  }
+  typedef s4v __attribute__((address_space(3))) lds_s4v;
+  auto tr2_ = [&](unsigned addr) -> bf16x8 {   // the two transposed 8-byte reads of a k-strided fragment (k rows r and r + 4)
+    const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(size_t)addr);
+    const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(size_t)(addr + 4u * 512u));
+    s8v v;
+    v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+    v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+    return __builtin_bit_cast(bf16x8, v);
+  };
+  auto fa_ = [&](int ks, int mi) -> bf16x8 {
+    if constexpr (!A_KS) {
+      const s8v v = *reinterpret_cast<lds_s8v*>((size_t)((ks ? pa1 : pa0) + (unsigned)mi * 2048u));
+      return __builtin_bit_cast(bf16x8, v);
+    } else {
+      // (block ^ swizzle) << 5 with block = 8 wm + mi: the low three bits of the block are mi, so the row block is an XOR on
+      // address bits 5-7 (one VALU instruction per fragment; the k half is an immediate: 32 k rows x 512 B)
+      return tr2_((pa0 ^ ((unsigned)mi << 5)) + (unsigned)ks * 16384u);
+    }
+  };
+  auto fb_ = [&](int ks, int ni) -> bf16x8 {
+    if constexpr (!B_KS) {
+      const s8v v = *reinterpret_cast<lds_s8v*>((size_t)((ks ? pb1 : pb0) + (unsigned)((ni >> 1) * 4096 + (ni & 1) * 512)));
+      return __builtin_bit_cast(bf16x8, v);
+    } else {
+      // column block (4 wn + 2 (ni >> 1) + ...) ^ swizzle: ni >> 1 flips address bit 6 (pb1), ni & 1 adds 8 bytes
+      return tr2_(((ni >> 1) ? pb1 : pb0) + (unsigned)ks * 16384u + (unsigned)(ni & 1) * 8u);
+    }
+  };
+#define RF_FA(ks, mi) fa_(ks, mi)
+#define RF_FB(ks, ni) fb_(ks, ni)
+#define RF_M(a, b, pr, j, ni) \
+  if (!(ABL & 4)) acc[2 * (pr) + (j)][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[ni], a[j], acc[2 * (pr) + (j)][ni], 0, 0, 0)
+  // one 8-MFMA group (A fragments a[0..1] x B fragments b[0..3] -> accumulator rows 2 pr, 2 pr + 1), one filler statement per MFMA
+#define RF_GROUP(a, b, pr, f0, f1, f2, f3, f4, f5, f6, f7)                 \
+  RF_M(a, b, pr, 0, 0); RF_SB(); f0; RF_SB();                              \
+  RF_M(a, b, pr, 0, 1); RF_SB(); f1; RF_SB();                              \
+  RF_M(a, b, pr, 0, 2); RF_SB(); f2; RF_SB();                              \
+  RF_M(a, b, pr, 0, 3); RF_SB(); f3; RF_SB();                              \
+  RF_M(a, b, pr, 1, 0); RF_SB(); f4; RF_SB();                              \
+  RF_M(a, b, pr, 1, 1); RF_SB(); f5; RF_SB();                              \
+  RF_M(a, b, pr, 1, 2); RF_SB(); f6; RF_SB();                              \
+  RF_M(a, b, pr, 1, 3); RF_SB(); f7; RF_SB();
+#define RF_PB(J) if (!(ABL & (8 | 16))) glds16_piece<J>(b_ptr, vb[J], b_dst)
+// RF_PBF: B(t+1)'s pieces in a tile's FIRST step (no held group in front of it); in the other steps they ride on the held group
+#define RF_PBF(FIRST, J) if (FIRST) RF_PB(J)
+#define RF_PA(J) if (!(ABL & (8 | 32))) glds16_piece<J>(a_ptr, va[J], a_dst)
+  // groups 0..6 of a K step (group 7 is held across the barrier), the DMA of the step -- B(t+1), which has to land within this
+  // step, right behind the barrier (on the held group; in a tile's first step at the head of group 0), A(t+2) in groups 0-3,
+  // one piece behind an MFMA --, the cursor steps, the DMA wait, the barrier, the slot rotation.  No branch: a cursor that
+  // has run out of tiles (the last two K steps of a workgroup's walk) keeps re-reading its last stage into the ring slot that
+  // would be next -- free by construction, and never the slot the epilogue uses as scratch -- so every step issues 4 + 4 pieces
+  // and the DMA wait is always vmcnt(4).
+#define RF_BODY(first_step)                                                                                                       \
+  {                                                                                                                              \
+    RF_GROUP(a0, b0, 0, a1[0] = RF_FA(0, 2), RF_PBF(first_step, 0), a1[1] = RF_FA(0, 3), RF_PBF(first_step, 1), RF_PBF(first_step, 2), RF_PBF(first_step, 3), RF_PA(0), RF_NOP)   \
+    RF_GROUP(a1, b0, 1, a0[0] = RF_FA(0, 4), RF_NOP, a0[1] = RF_FA(0, 5), RF_NOP, RF_PA(1), RF_NOP, RF_NOP, RF_NOP)              \
+    RF_GROUP(a0, b0, 2, a1[0] = RF_FA(0, 6), RF_NOP, a1[1] = RF_FA(0, 7), RF_NOP, RF_PA(2), RF_NOP, RF_NOP, RF_NOP)              \
+    RF_GROUP(a1, b0, 3, b1[0] = RF_FB(1, 0), a0[0] = RF_FA(1, 0), b1[1] = RF_FB(1, 1), b1[2] = RF_FB(1, 2), b1[3] = RF_FB(1, 3),   \
+             a0[1] = RF_FA(1, 1), RF_PA(3), RF_NOP)                                                                              \
+    RF_GROUP(a0, b1, 0, a1[0] = RF_FA(1, 2), RF_NOP, a1[1] = RF_FA(1, 3), RF_NOP, RF_NOP, RF_NOP, RF_NOP, RF_NOP)                \
+    RF_GROUP(a1, b1, 1, a0[0] = RF_FA(1, 4), RF_NOP, a0[1] = RF_FA(1, 5), RF_NOP, RF_NOP, RF_NOP, RF_NOP, RF_NOP)                \
+    RF_GROUP(a0, b1, 2, a1[0] = RF_FA(1, 6), RF_NOP, a1[1] = RF_FA(1, 7), RF_NOP, RF_BADV_PTR(), RF_AADV_PTR(), RF_NOP, RF_NOP)  \
+    RF_BADV_TILE();                                                                                                              \
+    RF_AADV_TILE();                                                                                                              \
+    /* B(t+1) (and the older A(t+1)) have landed: the only younger pieces in this wave's queue are A(t+2)'s four */               \
+    if (ABL & 64) {} /* ablation: no DMA wait at all */                                                                          \
+    else if (!(ABL & (8 | 16 | 32))) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                            \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                        \
+    /* (the builtin, not inline asm: hipcc must KNOW the LGKM queue is empty here -- the scalar loads of a cursor's tile crossing */ \
+    /* would otherwise leave it assuming mixed SMEM / LDS events and turn every later counted lgkmcnt into lgkmcnt(0)) */         \
+    __builtin_amdgcn_s_waitcnt(0xC07F);                                                                                          \
+    if (!(ABL & 1)) pp_barrier();                                                                                                \
+    sa_off = (sa_off == 2 * TILE2_BYTES) ? 0u : sa_off + TILE2_BYTES;                                                            \
+    sb_off = (2 * PP_B_BASE + TILE2_BYTES) - sb_off;                                                                             \
+    RF_STEP_BASES();                                                                                                             \
+  }
+  RF_LANE_BASES();
+  RF_STEP_BASES();
   for (;;) {
     int m0, n0, nt;
     {
@@ -1567,98 +1701,37 @@ __global__ __launch_bounds__(512, 2) void gemm256f_kernel(const GroupArgs ga) {
       pick_tile<256>(ga, id, total, gm, m0, n0);
       nt = gm.K / BK2;
     }
-    bf16x8 bq[2][4], af[2], afh;
-    const unsigned char* sa = smem + ca * TILE2_BYTES;
-    const unsigned char* sb = smem + PP_B_BASE + cb * TILE2_BYTES;
-    {
-      const int t = 0;
-      (void)t;
+    bf16x8 b0[4], b1[4], a0[2], a1[2];
+    // first fragments of the tile's first stage (visible since the barrier in front of the previous tile's epilogue)
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni) bq[0][ni] = RF_FB(0, ni);
-      af[0] = RF_FA(0, 0);
-    }
+    for (int ni = 0; ni < 4; ++ni) b0[ni] = RF_FB(0, ni);
+    a0[0] = RF_FA(0, 0);
+    a0[1] = RF_FA(0, 1);
     f4v acc[8][4];
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
     RF_SB();
-    for (int t = 0; t < nt; ++t) {
-      const bool isb = b_ok && !nodma, isa = a_ok && !nodma;
-      const bf16_t* pb = RF_BBASE();
-      const unsigned db = RF_BDST();
-      const bf16_t* pa = RF_ABASE();
-      const unsigned da = RF_ADST();
+    RF_BODY(true)
+    for (int t = 1; t < nt; ++t) {
+      // behind the barrier: request the first fragments of the new stage, then the group held back across the barrier
+      // (group 7 of the previous step), which covers their latency
+      b0[0] = RF_FB(0, 0);
+      a0[0] = RF_FA(0, 0);
       RF_SB();
-      // quads 0..14 (quad q = A fragment (k half q >> 3, row block q & 7) x the four B fragments of that k half)
-#pragma unroll
-      for (int q = 0; q < 15; ++q) {
-        const int ks = q >> 3, mi = q & 7;
-        RF_MFMA(mi, 0, bq[ks][0], af[q & 1]);
-        RF_SB();
-        // the A fragment of the next quad (quad 15's goes to the buffer that is held across the barrier)
-        if (q + 1 < 15) af[(q + 1) & 1] = RF_FA((q + 1) >> 3, (q + 1) & 7);
-        else afh = RF_FA(1, 7);
-        RF_SB();
-        RF_MFMA(mi, 1, bq[ks][1], af[q & 1]);
-        RF_SB();
-        // the B fragments of k half 1, one per quad 3..6
-        if (q >= 3 && q <= 6) bq[1][q - 3] = RF_FB(1, q - 3);
-        RF_SB();
-        RF_MFMA(mi, 2, bq[ks][2], af[q & 1]);
-        RF_SB();
-        // one LDS-DMA piece per two quads and wave; the two waves of a SIMD (groups 0 / 1) take alternate quads.
-        // B(t+1) first (it has this step to land), then A(t+2)
-        if ((q & 1) == grp) {
-          const int j = q >> 1;   // 0..7 (group 1: 0..6, its eighth piece follows quad 14 below)
-          if (j == 0 && isb) glds16_piece<0>(pb, vb[0], db);
-          if (j == 1 && isb) glds16_piece<1>(pb, vb[1], db);
-          if (j == 2 && isb) glds16_piece<2>(pb, vb[2], db);
-          if (j == 3 && isb) glds16_piece<3>(pb, vb[3], db);
-          if (j == 4 && isa) glds16_piece<0>(pa, va[0], da);
-          if (j == 5 && isa) glds16_piece<1>(pa, va[1], da);
-          if (j == 6 && isa) glds16_piece<2>(pa, va[2], da);
-          if (j == 7 && isa) glds16_piece<3>(pa, va[3], da);
-        }
-        RF_SB();
-        RF_MFMA(mi, 3, bq[ks][3], af[q & 1]);
-        RF_SB();
-      }
-      if (grp == 1 && isa) glds16_piece<3>(pa, va[3], da);
-      if (b_ok) RF_BADV();
-      if (a_ok) RF_AADV();
-      if (isa && !strong) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      // (the builtin, not inline asm: hipcc must KNOW the LGKM queue is empty here -- scalar loads of a cursor's tile crossing
-      // above would otherwise leave it assuming mixed SMEM / LDS events and turn every later counted lgkmcnt into lgkmcnt(0))
-      __builtin_amdgcn_s_waitcnt(0xC07F);
-      if (!(ABL & 1)) pp_barrier();
-      ca = (ca == 2) ? 0 : ca + 1;
-      cb ^= 1;
-      if (t + 1 < nt) {
-        sa = smem + ca * TILE2_BYTES;
-        sb = smem + PP_B_BASE + cb * TILE2_BYTES;
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) bq[0][ni] = RF_FB(0, ni);
-        af[0] = RF_FA(0, 0);
-        RF_SB();
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) RF_MFMA(7, ni, bq[1][ni], afh);   // quad 15, held across the barrier
-        RF_SB();
-      } else {
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) RF_MFMA(7, ni, bq[1][ni], afh);
-        RF_SB();
-      }
+      RF_GROUP(a1, b1, 3, b0[1] = RF_FB(0, 1), b0[2] = RF_FB(0, 2), b0[3] = RF_FB(0, 3), a0[1] = RF_FA(0, 1), RF_PB(0), RF_PB(1), RF_PB(2), RF_PB(3))
+      RF_BODY(false)
     }
+    RF_GROUP(a1, b1, 3, RF_NOP, RF_NOP, RF_NOP, RF_NOP, RF_NOP, RF_NOP, RF_NOP, RF_NOP)   // the last step's group 7
     GemmProblem g;
     {
       int mm, nn;
       pick_tile<256>(ga, id, total, g, mm, nn);
     }
     const int epi = g.epi;
-    const int last_a = (ca == 0) ? 2 : ca - 1;
-    unsigned char* scr = smem + last_a * TILE2_BYTES + wid * 4096;
+    // the A slot consumed last (sa_off already points at the next one)
+    unsigned char* scr = smem + ((sa_off == 0) ? 2 * TILE2_BYTES : sa_off - TILE2_BYTES) + wid * 4096;
     if (!B_KS) {
       switch (epi) {
         case 0: epilogue256<0, 8>(g, acc, m0, n0, wm, wn, lane, scr); break;
@@ -1678,24 +1751,34 @@ __global__ __launch_bounds__(512, 2) void gemm256f_kernel(const GroupArgs ga) {
     } else {
       epilogue256<-1, 8, true>(g, acc, m0, n0, wm, wn, lane, scr);
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // scratch reads done before this wave's next DMA lands there
     id += gstep;
-    if (id >= total) { G2_CLK(1) break; }
+    if (id >= total) break;
     lane_m = lane;
     asm volatile("" : "+v"(lane_m));
+    RF_LANE_BASES();
+    RF_STEP_BASES();
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the re-read pieces of an exhausted cursor may still be in flight)
+  G2_CLK(1)
 #undef RF_ALOAD
 #undef RF_BLOAD
-#undef RF_AADV
-#undef RF_BADV
-#undef RF_ABASE
-#undef RF_BBASE
-#undef RF_ADST
-#undef RF_BDST
+#undef RF_AADV_PTR
+#undef RF_BADV_PTR
+#undef RF_AADV_TILE
+#undef RF_BADV_TILE
 #undef RF_SB
+#undef RF_NOP
 #undef RF_FA
 #undef RF_FB
-#undef RF_MFMA
+#undef RF_M
+#undef RF_GROUP
+#undef RF_PB
+#undef RF_PA
+#undef RF_PBF
+#undef RF_BODY
+#undef RF_LANE_BASES
+#undef RF_STEP_BASES
 }
 
 template <bool A_KS, bool B_KS, int ABL = 0>
@@ -1798,7 +1881,7 @@ static int gemm_grouped_impl(int layout, int nprob, const kbner_gemm_problem* pr
 static int pick_tile_rows(int layout, int nprob, const kbner_gemm_problem* probs, bool dyn);
 
 int kbner_gemm_set_variant(int variant) {
-  KBNER_CHECK_ARG(variant >= 0 && variant < 32768);
+  KBNER_CHECK_ARG(variant >= 0 && variant < 65536);
   g_gemm_variant.store(variant, std::memory_order_relaxed);
   return 0;
 }
@@ -1879,15 +1962,14 @@ static int gemm_grouped_impl(int layout, int nprob, const kbner_gemm_problem* pr
   if (TM == 128) return layout == 0 ? launch256<false, false, false, 128>(ga, st) : launch256<false, true, false, 128>(ga, st);
   const int variant = g_gemm_variant.load(std::memory_order_relaxed);
 #ifdef G2_TRACE
-  if ((variant & PP_FLAG_FINE) && layout == 0 && (variant & 0x7000)) {   // cycle-accounting ablations, NT only
-    switch ((variant >> 12) & 7) {
+  if ((variant & PP_FLAG_FINE) && layout == 0 && (variant & 0xF000)) {   // cycle-accounting ablations, NT only
+    switch ((variant >> 12) & 15) {
       case 1: return launch256f<false, false, 1>(ga, variant, st);
-      case 2: return launch256f<false, false, 2>(ga, variant, st);
-      case 3: return launch256f<false, false, 3>(ga, variant, st);
-      case 4: return launch256f<false, false, 4>(ga, variant, st);
-      case 5: return launch256f<false, false, 5>(ga, variant, st);
-      case 6: return launch256f<false, false, 6>(ga, variant, st);
-      default: return launch256f<false, false, 7>(ga, variant, st);
+      case 2: return launch256f<false, false, 16>(ga, variant, st);
+      case 3: return launch256f<false, false, 32>(ga, variant, st);
+      case 4: return launch256f<false, false, 64>(ga, variant, st);
+      case 8: return launch256f<false, false, 8>(ga, variant, st);
+      default: return launch256f<false, false, 9>(ga, variant, st);
     }
   }
 #endif
