@@ -187,6 +187,38 @@ static __device__ __forceinline__ bf16x8 fragB256(const unsigned char* s, int c0
   }
 }
 
+// The two halves of pick_tile (below) for kernels that pick a tile ONCE and hand the record (problem, origin) on: which problem
+// a linear id falls into (no memory access), and the tile origin inside it.
+static __device__ __forceinline__ void pick_problem(const GroupArgs& ga, int id, int total, int& pi, int& wg) {
+  const int xcd = id & 7;
+  const int q8 = total >> 3, r8 = total & 7;
+  wg = ((xcd < r8) ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3);
+  pi = 0;
+#pragma unroll
+  for (int i = 1; i < G2_MAXP; ++i)
+    if (wg >= ga.tile_begin[i]) pi = i;
+}
+static __device__ __forceinline__ const GemmProblem* problem_ptr(int pi) {
+  return &((const GroupArgs*)__builtin_amdgcn_kernarg_segment_ptr())->p[pi];
+}
+// a wave-uniform pointer that the compiler computed with vector instructions (64-bit multiply-add), back in scalar registers:
+// the "s" operands of the LDS-DMA inline asm are not legalised by hipcc
+static __device__ __forceinline__ const bf16_t* uniform_ptr(const bf16_t* p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (const bf16_t*)(((unsigned long long)hi << 32) | lo);
+}
+static __device__ __forceinline__ void tile_origin(int tile, int M, int N, int& m0, int& n0) {
+  const int tiles_n = N / T2, tiles_m = M / T2;
+  const int group = 8 * tiles_n;
+  const int first_m = (tile / group) * 8;
+  const int gm = min(tiles_m - first_m, 8);
+  const int r = tile % group;
+  m0 = (first_m + r % gm) * T2;
+  n0 = (r / gm) * T2;
+}
+
 // linear id -> (problem, tile origin).  XCD-aware bijective remap (block b runs on XCD b % 8; persistent ids keep
 // id % 8): each XCD's private L2 sees a contiguous run of tiles, n fastest, so neighbours share the A panel.
 // The problem is picked with static indices only (a runtime-indexed kernarg array would go to scratch).
@@ -220,6 +252,18 @@ static __device__ __forceinline__ void pick_tile(const GroupArgs& ga, int id, in
   n0 = (r / gm) * T2;
 }
 
+// two consecutive 1-KiB LDS-DMA pieces under one M0 write (v1 carries the - 1 KiB of its immediate offset, see glds16x4)
+template <int J0>
+static __device__ __forceinline__ void glds16_pair(const void* sbase, unsigned v0, unsigned v1, unsigned dst) {
+  asm volatile(
+      "s_mov_b32 m0, %3\n\ts_nop 0\n\t"
+      "global_load_lds_dwordx4 %0, %2 offset:%4\n\t"
+      "global_load_lds_dwordx4 %1, %2 offset:%5"
+      :
+      : "v"(v0), "v"(v1), "s"(sbase), "s"(dst), "n"(J0 * 1024), "n"(J0 * 1024 + 1024)
+      : "memory", "m0");
+}
+
 // Epilogue of one 256x256 tile, instantiated per flag set (EPI_CT; -1 = generic runtime flags for uncommon
 // combinations).  With runtime flags every (row-fragment, column-half) step is a chain of ~10 scalar branches and its
 // own basic block: ~160 branches per tile cost more than the arithmetic they guard (3.6 us of a 32-us tile measured
@@ -227,9 +271,14 @@ static __device__ __forceinline__ void pick_tile(const GroupArgs& ga, int id, in
 // exposes a full memory latency.  Here the flags fold at compile time, the operand loads of row fragment mi+1 are
 // issued before fragment mi is processed, and sched_barriers keep the compiler from interleaving all eight fragments
 // (which spills).
-template <int EPI_CT, int MI = 8, bool DRAIN = false>
+// IN_DMA (the ring kernels, which have a second wave-private 4 KiB of LDS -- scr2 -- at tile ends): the residual / GELU' operand
+// tile reaches its lanes through LDS instead of 16-rows-x-64-B global loads in the MFMA layout, which the memory pipe retires at
+// a third of the full-line rate (tools/micro/store_pattern.hip; per-tile trace, round 4: bias 3.7 K cycles, bias + residual
+// 13.9 K).  Per 16-row fragment two LDS-DMA pieces fetch 16 x 128 B as full lines into one of two 2-KiB buffers, one fragment
+// ahead (the DMA needs no registers), chunk-swizzled like the operand tiles so that the MFMA-layout ds_read_b128 is conflict-free.
+template <int EPI_CT, int MI = 8, bool DRAIN = false, bool IN_DMA = false>
 static __device__ __forceinline__ void epilogue256(const GemmProblem& g, f4v (&acc)[MI][4], int m0, int n0, int wm, int wn,
-                                                   int lane, unsigned char* scr) {
+                                                   int lane, unsigned char* scr, unsigned char* scr2 = nullptr) {
   const int epi = EPI_CT >= 0 ? EPI_CT : g.epi;
   const float alpha = g.alpha;
   const int gq = lane >> 4;
@@ -269,17 +318,41 @@ static __device__ __forceinline__ void epilogue256(const GemmProblem& g, f4v (&a
   // (specialised forward epilogues only: on the dgrad layout the direct stores measured marginally better in situ)
   const bool lds_out = EPI_CT >= 0 && !(EPI_CT & (EPI_RMW32 | EPI_ATOMIC32 | EPI_STORE32));
   const int wr_row = lane & 15;
-  unsigned char* scr_w[2] = {scr + wr_row * 128 + (((0 * 4 + gq) ^ (wr_row & 7)) << 4),
-                             scr + wr_row * 128 + (((1 * 4 + gq) ^ (wr_row & 7)) << 4)};
+  const int wr_off[2] = {wr_row * 128 + (((0 * 4 + gq) ^ (wr_row & 7)) << 4), wr_row * 128 + (((1 * 4 + gq) ^ (wr_row & 7)) << 4)};
   const int rd_row = lane >> 3, rd_chunk = lane & 7;
-  const unsigned char* scr_r = scr + rd_row * 128 + ((rd_chunk ^ (rd_row & 7)) << 4);
+  const int rd_lds = rd_row * 128 + ((rd_chunk ^ (rd_row & 7)) << 4);
   const size_t rd_off = (size_t)(m0 + wm * (MI * 16) + rd_row) * 1;  // row index; scaled by the leading dimension at the store
   // operand tile (residual addend or saved pre-activation) of the row fragment about to be processed, one fragment ahead
   const bool has_in = (epi & (EPI_ADD | EPI_DGELU)) != 0;
   const bf16_t* inp = (epi & EPI_ADD) ? g.addend : g.aux;
   const int ldin = (epi & EPI_ADD) ? g.ldadd : g.ldaux;
   uint4 nxt_in[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
-  if (has_in) {
+  // IN_DMA state: the per-lane source offsets of a fragment's two pieces (row (lane >> 3) [+ 8], 16-byte chunk (lane & 7) ^
+  // swizzle), the running source pointer of the wave's 64-column strip, the lane's two read addresses in a buffer
+  unsigned dv0 = 0, dv1 = 0, drd0 = 0, drd1 = 0, dbuf = 0, dbuf2 = 0;
+  const bf16_t* dsrc = nullptr;
+  size_t dstep = 0;
+  // Four 2-KiB buffers (scr: 0, 1; scr2: 2, 3), fragment mi in buffer mi & 3: its operand rows land there, are read into
+  // registers, and the same buffer then stages the fragment's output transpose; fragment mi + 4's pieces are issued into it at the
+  // end of iteration mi, i.e. three iterations (~1600 cycles: an HBM round trip) before they are needed.
+  if (IN_DMA && has_in) {
+    static_assert(!IN_DMA || MI == 8, "the counted DMA waits below are written for 8 fragments");
+    const int drow = lane >> 3;
+    dv0 = (unsigned)(drow * ldin + (((lane & 7) ^ kc_swz(drow)) << 3)) * 2u;
+    dv1 = (unsigned)((drow + 8) * ldin + (((lane & 7) ^ kc_swz(drow + 8)) << 3)) * 2u - 1024u;
+    dsrc = uniform_ptr(inp + (size_t)(m0 + wm * (MI * 16)) * ldin + n0 + wn * 64);
+    dstep = (size_t)16 * ldin;
+    dbuf = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void*)scr);
+    dbuf2 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void*)scr2);
+    const int r = lane & 15;
+    drd0 = (unsigned)(r * 128 + (((0 * 4 + gq) ^ kc_swz(r)) << 4));
+    drd1 = (unsigned)(r * 128 + (((1 * 4 + gq) ^ kc_swz(r)) << 4));
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      glds16_pair<0>(dsrc, dv0, dv1, ((f & 2) ? dbuf2 : dbuf) + (unsigned)(f & 1) * 2048u);
+      dsrc += dstep;
+    }
+  } else if (has_in) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) nxt_in[q] = *reinterpret_cast<const uint4*>(inp + (size_t)mrow * ldin + ncol + q * 32);
   }
@@ -288,7 +361,19 @@ static __device__ __forceinline__ void epilogue256(const GemmProblem& g, f4v (&a
     const int m = mrow + mi * 16;
     const uint32_t rk = drop ? drop_rowkey(g.drop_seed, (uint32_t)m) : 0u;
     uint4 cur_in[2] = {nxt_in[0], nxt_in[1]};
-    if (has_in && mi + 1 < MI) {
+    unsigned char* fbuf = (IN_DMA && has_in) ? ((mi & 2) ? scr2 : scr) + (mi & 1) * 2048 : scr;   // this fragment's buffer (IN_DMA)
+    unsigned char* stage = fbuf;   // ... which also stages the output transpose
+    if (IN_DMA && has_in) {
+      // pieces / stores queued behind fragment mi's two pieces (in order): fragments mi+1.. of the first four, then per finished
+      // iteration its two stores and the two pieces it issued
+      constexpr int kYounger[8] = {6, 8, 10, 12, 12, 10, 8, 6};
+      if (kYounger[mi] == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else if (kYounger[mi] == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (kYounger[mi] == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      cur_in[0] = *reinterpret_cast<const uint4*>(fbuf + drd0);
+      cur_in[1] = *reinterpret_cast<const uint4*>(fbuf + drd1);
+    } else if (has_in && mi + 1 < MI) {
 #pragma unroll
       for (int q = 0; q < 2; ++q)
         nxt_in[q] = *reinterpret_cast<const uint4*>(inp + (size_t)(m + 16) * ldin + ncol + q * 32);
@@ -369,7 +454,7 @@ static __device__ __forceinline__ void epilogue256(const GemmProblem& g, f4v (&a
           dw[r] = pack2bf(dy[0], dy[1]);
         }
         du.x = dw[0]; du.y = dw[1]; du.z = dw[2]; du.w = dw[3];
-        if (lds_out) *reinterpret_cast<uint4*>(scr_w[q] + 2048) = du;
+        if (lds_out) *reinterpret_cast<uint4*>(stage + wr_off[q] + 2048) = du;
         else *reinterpret_cast<uint4*>(g.out2 + (size_t)m * g.ldout2 + n) = du;
       }
       uint4 o;
@@ -377,7 +462,7 @@ static __device__ __forceinline__ void epilogue256(const GemmProblem& g, f4v (&a
       o.y = pack2bf(v[2], v[3]);
       o.z = pack2bf(v[4], v[5]);
       o.w = pack2bf(v[6], v[7]);
-      if (lds_out) *reinterpret_cast<uint4*>(scr_w[q]) = o;
+      if (lds_out) *reinterpret_cast<uint4*>(stage + wr_off[q]) = o;
       else *reinterpret_cast<uint4*>(g.C + (size_t)m * g.ldc + n) = o;
       if (epi & EPI_COLSUM) {
 #pragma unroll
@@ -385,18 +470,25 @@ static __device__ __forceinline__ void epilogue256(const GemmProblem& g, f4v (&a
       }
     }
     if (lds_out) {
-      const uint4 h0 = *reinterpret_cast<const uint4*>(scr_r);
-      const uint4 h1 = *reinterpret_cast<const uint4*>(scr_r + 8 * 128);
+      const uint4 h0 = *reinterpret_cast<const uint4*>(stage + rd_lds);
+      const uint4 h1 = *reinterpret_cast<const uint4*>(stage + rd_lds + 8 * 128);
       bf16_t* d0 = g.C + (rd_off + mi * 16) * g.ldc + n0 + wn * 64 + rd_chunk * 8;
       *reinterpret_cast<uint4*>(d0) = h0;
       *reinterpret_cast<uint4*>(d0 + (size_t)8 * g.ldc) = h1;
       if (epi & EPI_GELU) {
-        const uint4 e0 = *reinterpret_cast<const uint4*>(scr_r + 2048);
-        const uint4 e1 = *reinterpret_cast<const uint4*>(scr_r + 2048 + 8 * 128);
+        const uint4 e0 = *reinterpret_cast<const uint4*>(stage + rd_lds + 2048);
+        const uint4 e1 = *reinterpret_cast<const uint4*>(stage + rd_lds + 2048 + 8 * 128);
         bf16_t* d2 = g.out2 + (rd_off + mi * 16) * g.ldout2 + n0 + wn * 64 + rd_chunk * 8;
         *reinterpret_cast<uint4*>(d2) = e0;
         *reinterpret_cast<uint4*>(d2 + (size_t)8 * g.ldout2) = e1;
       }
+    }
+    if (IN_DMA && has_in && mi + 4 < MI) {
+      // this fragment's buffer is done with (operand rows read, output rows staged and read back: the stores above carry them):
+      // fragment mi + 4's operand rows go there
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      glds16_pair<0>(dsrc, dv0, dv1, ((mi & 2) ? dbuf2 : dbuf) + (unsigned)(mi & 1) * 2048u);
+      dsrc += dstep;
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -982,16 +1074,6 @@ __global__ __launch_bounds__(512, 2) void gemm256pp_kernel(const GroupArgs ga) {
 // Group 1's last compute phase of a tile falls behind the first barrier of the next tile, so BOTH groups run the epilogue of
 // tile n after that barrier (concurrently), in front of their first memory phase of tile n + 1.  DMA balance: M0 carries two of
 // A(t+2)'s four pieces, M1 the other two and B(t+2) (whose slot is free once both groups have passed the mid-step barrier).
-template <int J0>
-static __device__ __forceinline__ void glds16_pair(const void* sbase, unsigned v0, unsigned v1, unsigned dst) {
-  asm volatile(
-      "s_mov_b32 m0, %3\n\ts_nop 0\n\t"
-      "global_load_lds_dwordx4 %0, %2 offset:%4\n\t"
-      "global_load_lds_dwordx4 %1, %2 offset:%5"
-      :
-      : "v"(v0), "v"(v1), "s"(sbase), "s"(dst), "n"(J0 * 1024), "n"(J0 * 1024 + 1024)
-      : "memory", "m0");
-}
 
 template <bool A_KS, bool B_KS>
 __global__ __launch_bounds__(512, 2) void gemm256rot_kernel(const GroupArgs ga) {
@@ -1491,35 +1573,47 @@ __global__ __launch_bounds__(512, 2) void gemm256f_kernel(const GroupArgs ga) {
   int lane_m = lane;   // opaque copy for the main loop's address arithmetic (see gemm256pp_kernel)
   asm volatile("" : "+v"(lane_m));
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void*)smem);
+  // A tile is picked ONCE, by the A cursor (the first to need it); the record (problem, origin) travels on to the B cursor and
+  // to the consumer through two one-deep stashes (a cursor crosses into its next tile exactly one K step after the cursor ahead
+  // of it; at the end of a step B advances before A, so B reads the stash before A overwrites it; pi < 0 = no more tiles)
+  int rab_pi = -1, rab_m = 0, rab_n = 0;   // A -> B
+  int rbc_pi = -1, rbc_m = 0, rbc_n = 0;   // B -> consumer
   int a_id = blockIdx.x, a_left = 0;
   const bf16_t* a_ptr = nullptr;
   size_t a_stride = 0;
   unsigned a_dst = lds0 + wid * 4096;
   unsigned va[4];
-  int b_id = blockIdx.x, b_left = 0;
+  int b_left = 0;
   const bf16_t* b_ptr = nullptr;
   size_t b_stride = 0;
   unsigned b_dst = lds0 + PP_B_BASE + wid * 4096;
   unsigned vb[4];
 #define RF_ALOAD()                                                                        \
   {                                                                                       \
-    GemmProblem gi;                                                                       \
-    int m_, n_;                                                                           \
-    pick_tile<256>(ga, a_id, total, gi, m_, n_);                                          \
-    a_left = gi.K / BK2;                                                                  \
-    a_ptr = A_KS ? gi.A + m_ : gi.A + (size_t)m_ * gi.lda;                               \
-    a_stride = A_KS ? (size_t)BK2 * gi.lda : (size_t)BK2;                                 \
-    stage_voff<A_KS, false>(gi.lda, wid, lane_m, va);                                     \
+    int pi_, wg_, m_, n_;                                                                 \
+    pick_problem(ga, a_id, total, pi_, wg_);                                              \
+    const GemmProblem* gp_ = problem_ptr(pi_);                                            \
+    tile_origin(wg_ - gp_->tile_begin, gp_->M, gp_->N, m_, n_);                           \
+    const int lda_ = gp_->lda;                                                            \
+    a_left = gp_->K / BK2;                                                                \
+    a_ptr = uniform_ptr(A_KS ? gp_->A + m_ : gp_->A + (size_t)m_ * lda_);                \
+    a_stride = A_KS ? (size_t)BK2 * lda_ : (size_t)BK2;                                   \
+    stage_voff<A_KS, false>(lda_, wid, lane_m, va);                                       \
+    rab_pi = pi_;                                                                         \
+    rab_m = m_;                                                                           \
+    rab_n = n_;                                                                           \
   }
 #define RF_BLOAD()                                                                        \
   {                                                                                       \
-    GemmProblem gi;                                                                       \
-    int m_, n_;                                                                           \
-    pick_tile<256>(ga, b_id, total, gi, m_, n_);                                          \
-    b_left = gi.K / BK2;                                                                  \
-    b_ptr = B_KS ? gi.B + n_ : gi.B + (size_t)n_ * gi.ldb;                               \
-    b_stride = B_KS ? (size_t)BK2 * gi.ldb : (size_t)BK2;                                 \
-    stage_voff<B_KS, true>(gi.ldb, wid, lane_m, vb);                                      \
+    const GemmProblem* gp_ = problem_ptr(rab_pi);                                         \
+    const int ldb_ = gp_->ldb;                                                            \
+    b_left = gp_->K / BK2;                                                                \
+    b_ptr = uniform_ptr(B_KS ? gp_->B + rab_n : gp_->B + (size_t)rab_n * ldb_);          \
+    b_stride = B_KS ? (size_t)BK2 * ldb_ : (size_t)BK2;                                   \
+    stage_voff<B_KS, true>(ldb_, wid, lane_m, vb);                                        \
+    rbc_pi = rab_pi;                                                                      \
+    rbc_m = rab_m;                                                                        \
+    rbc_n = rab_n;                                                                        \
   }
   // the cheap half of a cursor step (fillers between MFMAs) and its rare tile crossing (behind the step's last MFMA)
 #define RF_AADV_PTR()                                                   \
@@ -1541,24 +1635,26 @@ __global__ __launch_bounds__(512, 2) void gemm256f_kernel(const GroupArgs ga) {
         a_ptr -= a_stride; /* exhausted: keep re-reading the last stage (see RF_BODY) */ \
         a_stride = 0;                                                   \
         a_left = 0x7fffffff;                                            \
+        rab_pi = -1;                                                    \
       }                                                                 \
     }                                                                   \
   }
 #define RF_BADV_TILE()                                                  \
   {                                                                     \
     if (--b_left == 0) {                                                \
-      b_id += gstep;                                                    \
-      if (b_id < total) RF_BLOAD()                                      \
+      if (rab_pi >= 0) RF_BLOAD()                                       \
       else {                                                            \
         b_ptr -= b_stride;                                              \
         b_stride = 0;                                                   \
         b_left = 0x7fffffff;                                            \
+        rbc_pi = -1;                                                    \
       }                                                                 \
     }                                                                   \
   }
 
   RF_ALOAD();
   RF_BLOAD();
+  int c_pi = rab_pi, m0 = rab_m, n0 = rab_n;   // the consumer's tile
   glds16_quad(a_ptr, va[0], va[1], va[2], va[3], a_dst);
   RF_AADV_PTR();
   RF_AADV_TILE();
@@ -1571,8 +1667,9 @@ __global__ __launch_bounds__(512, 2) void gemm256f_kernel(const GroupArgs ga) {
   asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   pp_barrier();   // stage 0 of the first tile is visible
 
-  int id = blockIdx.x;
   unsigned sa_off = 0, sb_off = PP_B_BASE;
+  int tile_no = 0;
+  (void)tile_no;
 #define RF_SB() __builtin_amdgcn_sched_barrier(0)
 #define RF_NOP (void)0
   // Fragment addresses.  Row-major (KC) images: ONE address register per operand and k half for the whole step -- the row block
@@ -1646,18 +1743,21 @@ __global__ __launch_bounds__(512, 2) void gemm256f_kernel(const GroupArgs ga) {
   };
 #define RF_FA(ks, mi) fa_(ks, mi)
 #define RF_FB(ks, ni) fb_(ks, ni)
-#define RF_M(a, b, pr, j, ni) \
-  if (!(ABL & 4)) acc[2 * (pr) + (j)][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[ni], a[j], acc[2 * (pr) + (j)][ni], 0, 0, 0)
+  // (Z: the MFMA starts its accumulator -- the k half 0 groups of a tile's first step; saves zeroing 128 registers per tile)
+#define RF_M(a, b, pr, j, ni, Z)                                                                                        \
+  if (!(ABL & 4)) acc[2 * (pr) + (j)][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                                    \
+      b[ni], a[j], (Z) ? (f4v){0.0f, 0.0f, 0.0f, 0.0f} : acc[2 * (pr) + (j)][ni], 0, 0, 0)
   // one 8-MFMA group (A fragments a[0..1] x B fragments b[0..3] -> accumulator rows 2 pr, 2 pr + 1), one filler statement per MFMA
-#define RF_GROUP(a, b, pr, f0, f1, f2, f3, f4, f5, f6, f7)                 \
-  RF_M(a, b, pr, 0, 0); RF_SB(); f0; RF_SB();                              \
-  RF_M(a, b, pr, 0, 1); RF_SB(); f1; RF_SB();                              \
-  RF_M(a, b, pr, 0, 2); RF_SB(); f2; RF_SB();                              \
-  RF_M(a, b, pr, 0, 3); RF_SB(); f3; RF_SB();                              \
-  RF_M(a, b, pr, 1, 0); RF_SB(); f4; RF_SB();                              \
-  RF_M(a, b, pr, 1, 1); RF_SB(); f5; RF_SB();                              \
-  RF_M(a, b, pr, 1, 2); RF_SB(); f6; RF_SB();                              \
-  RF_M(a, b, pr, 1, 3); RF_SB(); f7; RF_SB();
+#define RF_GROUPZ(Z, a, b, pr, f0, f1, f2, f3, f4, f5, f6, f7)             \
+  RF_M(a, b, pr, 0, 0, Z); RF_SB(); f0; RF_SB();                              \
+  RF_M(a, b, pr, 0, 1, Z); RF_SB(); f1; RF_SB();                              \
+  RF_M(a, b, pr, 0, 2, Z); RF_SB(); f2; RF_SB();                              \
+  RF_M(a, b, pr, 0, 3, Z); RF_SB(); f3; RF_SB();                              \
+  RF_M(a, b, pr, 1, 0, Z); RF_SB(); f4; RF_SB();                              \
+  RF_M(a, b, pr, 1, 1, Z); RF_SB(); f5; RF_SB();                              \
+  RF_M(a, b, pr, 1, 2, Z); RF_SB(); f6; RF_SB();                              \
+  RF_M(a, b, pr, 1, 3, Z); RF_SB(); f7; RF_SB();
+#define RF_GROUP(a, b, pr, f0, f1, f2, f3, f4, f5, f6, f7) RF_GROUPZ(false, a, b, pr, f0, f1, f2, f3, f4, f5, f6, f7)
 #define RF_PB(J) if (!(ABL & (8 | 16))) glds16_piece<J>(b_ptr, vb[J], b_dst)
 // RF_PBF: B(t+1)'s pieces in a tile's FIRST step (no held group in front of it); in the other steps they ride on the held group
 #define RF_PBF(FIRST, J) if (FIRST) RF_PB(J)
@@ -1670,10 +1770,10 @@ __global__ __launch_bounds__(512, 2) void gemm256f_kernel(const GroupArgs ga) {
   // and the DMA wait is always vmcnt(4).
 #define RF_BODY(first_step)                                                                                                       \
   {                                                                                                                              \
-    RF_GROUP(a0, b0, 0, a1[0] = RF_FA(0, 2), RF_PBF(first_step, 0), a1[1] = RF_FA(0, 3), RF_PBF(first_step, 1), RF_PBF(first_step, 2), RF_PBF(first_step, 3), RF_PA(0), RF_NOP)   \
-    RF_GROUP(a1, b0, 1, a0[0] = RF_FA(0, 4), RF_NOP, a0[1] = RF_FA(0, 5), RF_NOP, RF_PA(1), RF_NOP, RF_NOP, RF_NOP)              \
-    RF_GROUP(a0, b0, 2, a1[0] = RF_FA(0, 6), RF_NOP, a1[1] = RF_FA(0, 7), RF_NOP, RF_PA(2), RF_NOP, RF_NOP, RF_NOP)              \
-    RF_GROUP(a1, b0, 3, b1[0] = RF_FB(1, 0), a0[0] = RF_FA(1, 0), b1[1] = RF_FB(1, 1), b1[2] = RF_FB(1, 2), b1[3] = RF_FB(1, 3),   \
+    RF_GROUPZ(first_step, a0, b0, 0, a1[0] = RF_FA(0, 2), RF_PBF(first_step, 0), a1[1] = RF_FA(0, 3), RF_PBF(first_step, 1), RF_PBF(first_step, 2), RF_PBF(first_step, 3), RF_PA(0), RF_NOP)   \
+    RF_GROUPZ(first_step, a1, b0, 1, a0[0] = RF_FA(0, 4), RF_NOP, a0[1] = RF_FA(0, 5), RF_NOP, RF_PA(1), RF_NOP, RF_NOP, RF_NOP)              \
+    RF_GROUPZ(first_step, a0, b0, 2, a1[0] = RF_FA(0, 6), RF_NOP, a1[1] = RF_FA(0, 7), RF_NOP, RF_PA(2), RF_NOP, RF_NOP, RF_NOP)              \
+    RF_GROUPZ(first_step, a1, b0, 3, b1[0] = RF_FB(1, 0), a0[0] = RF_FA(1, 0), b1[1] = RF_FB(1, 1), b1[2] = RF_FB(1, 2), b1[3] = RF_FB(1, 3),   \
              a0[1] = RF_FA(1, 1), RF_PA(3), RF_NOP)                                                                              \
     RF_GROUP(a0, b1, 0, a1[0] = RF_FA(1, 2), RF_NOP, a1[1] = RF_FA(1, 3), RF_NOP, RF_NOP, RF_NOP, RF_NOP, RF_NOP)                \
     RF_GROUP(a1, b1, 1, a0[0] = RF_FA(1, 4), RF_NOP, a0[1] = RF_FA(1, 5), RF_NOP, RF_NOP, RF_NOP, RF_NOP, RF_NOP)                \
@@ -1695,12 +1795,9 @@ __global__ __launch_bounds__(512, 2) void gemm256f_kernel(const GroupArgs ga) {
   RF_LANE_BASES();
   RF_STEP_BASES();
   for (;;) {
-    int m0, n0, nt;
-    {
-      GemmProblem gm;
-      pick_tile<256>(ga, id, total, gm, m0, n0);
-      nt = gm.K / BK2;
-    }
+    G2_T(0)
+    const int nt = problem_ptr(c_pi)->K / BK2;
+    int x_pi = -1, x_m = 0, x_n = 0;   // the consumer's next tile: read from the stash at the start of this tile's last K step
     bf16x8 b0[4], b1[4], a0[2], a1[2];
     // first fragments of the tile's first stage (visible since the barrier in front of the previous tile's epilogue)
 #pragma unroll
@@ -1708,11 +1805,14 @@ __global__ __launch_bounds__(512, 2) void gemm256f_kernel(const GroupArgs ga) {
     a0[0] = RF_FA(0, 0);
     a0[1] = RF_FA(0, 1);
     f4v acc[8][4];
-#pragma unroll
-    for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
     RF_SB();
+#define RF_TAKE_NEXT(last) \
+  if (last) {              \
+    x_pi = rbc_pi;         \
+    x_m = rbc_m;           \
+    x_n = rbc_n;           \
+  }
+    RF_TAKE_NEXT(nt == 1)
     RF_BODY(true)
     for (int t = 1; t < nt; ++t) {
       // behind the barrier: request the first fragments of the new stage, then the group held back across the barrier
@@ -1721,39 +1821,44 @@ __global__ __launch_bounds__(512, 2) void gemm256f_kernel(const GroupArgs ga) {
       a0[0] = RF_FA(0, 0);
       RF_SB();
       RF_GROUP(a1, b1, 3, b0[1] = RF_FB(0, 1), b0[2] = RF_FB(0, 2), b0[3] = RF_FB(0, 3), a0[1] = RF_FA(0, 1), RF_PB(0), RF_PB(1), RF_PB(2), RF_PB(3))
+      RF_TAKE_NEXT(t + 1 == nt)
       RF_BODY(false)
     }
     RF_GROUP(a1, b1, 3, RF_NOP, RF_NOP, RF_NOP, RF_NOP, RF_NOP, RF_NOP, RF_NOP, RF_NOP)   // the last step's group 7
-    GemmProblem g;
-    {
-      int mm, nn;
-      pick_tile<256>(ga, id, total, g, mm, nn);
-    }
+    G2_T(1)
+    const GemmProblem g = *problem_ptr(c_pi);
     const int epi = g.epi;
     // the A slot consumed last (sa_off already points at the next one)
     unsigned char* scr = smem + ((sa_off == 0) ? 2 * TILE2_BYTES : sa_off - TILE2_BYTES) + wid * 4096;
+    // ... and the B slot consumed last (free until this wave's own pieces of the next tile's B(1) go there, in its first step):
+    // a second 4 KiB per wave, for the epilogue's operand tile (epilogue256, IN_DMA)
+    unsigned char* scr2 = smem + ((2 * PP_B_BASE + TILE2_BYTES) - sb_off) + wid * 4096;
     if (!B_KS) {
       switch (epi) {
-        case 0: epilogue256<0, 8>(g, acc, m0, n0, wm, wn, lane, scr); break;
-        case EPI_BIAS: epilogue256<EPI_BIAS, 8>(g, acc, m0, n0, wm, wn, lane, scr); break;
-        case EPI_BIAS | EPI_GELU: epilogue256<(EPI_BIAS | EPI_GELU), 8>(g, acc, m0, n0, wm, wn, lane, scr); break;
-        case EPI_BIAS | EPI_GELU_FWD: epilogue256<(EPI_BIAS | EPI_GELU_FWD), 8>(g, acc, m0, n0, wm, wn, lane, scr); break;
-        case EPI_BIAS | EPI_ADD: epilogue256<(EPI_BIAS | EPI_ADD), 8>(g, acc, m0, n0, wm, wn, lane, scr); break;
-        case EPI_BIAS | EPI_ADD | EPI_DROP: epilogue256<(EPI_BIAS | EPI_ADD | EPI_DROP), 8>(g, acc, m0, n0, wm, wn, lane, scr); break;
-        default: epilogue256<-1, 8, true>(g, acc, m0, n0, wm, wn, lane, scr); break;
+        case 0: epilogue256<(0), 8, false, true>(g, acc, m0, n0, wm, wn, lane, scr, scr2); break;
+        case EPI_BIAS: epilogue256<(EPI_BIAS), 8, false, true>(g, acc, m0, n0, wm, wn, lane, scr, scr2); break;
+        case EPI_BIAS | EPI_GELU: epilogue256<(EPI_BIAS | EPI_GELU), 8, false, true>(g, acc, m0, n0, wm, wn, lane, scr, scr2); break;
+        case EPI_BIAS | EPI_GELU_FWD: epilogue256<(EPI_BIAS | EPI_GELU_FWD), 8, false, true>(g, acc, m0, n0, wm, wn, lane, scr, scr2); break;
+        case EPI_BIAS | EPI_ADD: epilogue256<(EPI_BIAS | EPI_ADD), 8, false, true>(g, acc, m0, n0, wm, wn, lane, scr, scr2); break;
+        case EPI_BIAS | EPI_ADD | EPI_DROP: epilogue256<(EPI_BIAS | EPI_ADD | EPI_DROP), 8, false, true>(g, acc, m0, n0, wm, wn, lane, scr, scr2); break;
+        default: epilogue256<-1, 8, true, true>(g, acc, m0, n0, wm, wn, lane, scr, scr2); break;
       }
     } else if (A_KS && epi == EPI_RMW32) {
-      epilogue256<EPI_RMW32, 8>(g, acc, m0, n0, wm, wn, lane, scr);
+      epilogue256<(EPI_RMW32), 8, false, true>(g, acc, m0, n0, wm, wn, lane, scr, scr2);
     } else if (!A_KS && epi == EPI_ADD) {
-      epilogue256<EPI_ADD, 8>(g, acc, m0, n0, wm, wn, lane, scr);
+      epilogue256<(EPI_ADD), 8, false, true>(g, acc, m0, n0, wm, wn, lane, scr, scr2);
     } else if (!A_KS && epi == 0) {
-      epilogue256<0, 8>(g, acc, m0, n0, wm, wn, lane, scr);
+      epilogue256<(0), 8, false, true>(g, acc, m0, n0, wm, wn, lane, scr, scr2);
     } else {
-      epilogue256<-1, 8, true>(g, acc, m0, n0, wm, wn, lane, scr);
+      epilogue256<-1, 8, true, true>(g, acc, m0, n0, wm, wn, lane, scr, scr2);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // scratch reads done before this wave's next DMA lands there
-    id += gstep;
-    if (id >= total) break;
+    G2_T(2)
+    ++tile_no;
+    if (x_pi < 0) break;
+    c_pi = x_pi;
+    m0 = x_m;
+    n0 = x_n;
     lane_m = lane;
     asm volatile("" : "+v"(lane_m));
     RF_LANE_BASES();
@@ -1773,10 +1878,12 @@ __global__ __launch_bounds__(512, 2) void gemm256f_kernel(const GroupArgs ga) {
 #undef RF_FB
 #undef RF_M
 #undef RF_GROUP
+#undef RF_GROUPZ
 #undef RF_PB
 #undef RF_PA
 #undef RF_PBF
 #undef RF_BODY
+#undef RF_TAKE_NEXT
 #undef RF_LANE_BASES
 #undef RF_STEP_BASES
 }

@@ -11,7 +11,13 @@ dev, BF = "cuda", torch.bfloat16
 M, N, K = 65536, 4096, 1024
 x = (torch.randn(M, K, device=dev) * 0.5).to(BF); W = (torch.randn(N, K, device=dev) * 0.5).to(BF)
 C = torch.empty(M, N, device=dev, dtype=BF); P = torch.empty(M, N, device=dev, dtype=BF); b = torch.randn(N, device=dev)
-for name, kw in (("plain", {}), ("bias+gelu", dict(bias=b, out2=P, epi=EPI_BIAS | EPI_GELU))):
+import os
+VAR = [int(v) for v in os.environ.get("TRACE_VARIANTS", "0,2048").split(",")]
+from kbner.lib import EPI_ADD
+add = (torch.randn(M, N, device=dev)).to(BF)
+for var in VAR:
+  ops.gemm_variant(var)
+  for name, kw in (("plain", {}), ("bias", dict(bias=b, epi=EPI_BIAS)), ("bias+add", dict(bias=b, addend=add, epi=EPI_BIAS | EPI_ADD)), ("bias+gelu", dict(bias=b, out2=P, epi=EPI_BIAS | EPI_GELU))):
     for _ in range(2):
         ops.gemm(GEMM_NT, x, W, M, N, K, C=C, **kw)
     torch.cuda.synchronize()
@@ -24,7 +30,7 @@ for name, kw in (("plain", {}), ("bias+gelu", dict(bias=b, out2=P, epi=EPI_BIAS 
     main = (t[:, :nt, 1] - t[:, :nt, 0]); epi = (t[:, :nt, 2] - t[:, :nt, 1])
     gap = t[:, 1:nt, 0] - t[:, :nt - 1, 2]
     # s_memtime / readcyclecounter ticks at 100 MHz on this part (constant clock): report microseconds
-    f = 2000.0
-    print("%-10s main-loop %.2f us (p10 %.2f p90 %.2f)   epilogue %.2f us (p10 %.2f p90 %.2f)   gap %.2f   tile %.2f us   rc=%d" % (
-        name, main.mean() / f, np.percentile(main, 10) / f, np.percentile(main, 90) / f, epi.mean() / f,
+    f = 1.0   # report shader cycles (s_memtime)
+    print("variant %4d %-10s main-loop %.0f cyc (p10 %.0f p90 %.0f)   epilogue %.0f cyc (p10 %.0f p90 %.0f)   gap %.0f   tile %.0f cyc   rc=%d" % (
+        var, name, main.mean() / f, np.percentile(main, 10) / f, np.percentile(main, 90) / f, epi.mean() / f,
         np.percentile(epi, 10) / f, np.percentile(epi, 90) / f, gap.mean() / f, (t[:, nt - 1, 2] - t[:, 0, 0]).mean() / f / nt, rc))
