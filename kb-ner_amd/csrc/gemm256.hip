@@ -361,6 +361,10 @@ static __device__ __forceinline__ void epilogue256(const GemmProblem& g, f4v (&a
     const int m = mrow + mi * 16;
     const uint32_t rk = drop ? drop_rowkey(g.drop_seed, (uint32_t)m) : 0u;
     uint4 cur_in[2] = {nxt_in[0], nxt_in[1]};
+    // (re-defined per fragment behind an opaque asm: hipcc otherwise hoists the alpha multiplies of ALL fragments to the top of the
+    // epilogue and keeps scaled and unscaled accumulators alive -- the GELU' x + column-sum variant spilled 270 bytes that way)
+    float alpha_f = alpha;
+    asm volatile("" : "+v"(alpha_f));
     unsigned char* fbuf = (IN_DMA && has_in) ? ((mi & 2) ? scr2 : scr) + (mi & 1) * 2048 : scr;   // this fragment's buffer (IN_DMA)
     unsigned char* stage = fbuf;   // ... which also stages the output transpose
     if (IN_DMA && has_in) {
@@ -385,8 +389,8 @@ static __device__ __forceinline__ void epilogue256(const GemmProblem& g, f4v (&a
       float v[8];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        v[r] = acc[mi][2 * q][r] * alpha;
-        v[4 + r] = acc[mi][2 * q + 1][r] * alpha;
+        v[r] = acc[mi][2 * q][r] * alpha_f;
+        v[4 + r] = acc[mi][2 * q + 1][r] * alpha_f;
       }
       if (epi & EPI_STORE32) {
         float4* c = reinterpret_cast<float4*>(g.C32 + (size_t)m * g.ldc32 + n);
@@ -466,7 +470,10 @@ static __device__ __forceinline__ void epilogue256(const GemmProblem& g, f4v (&a
       else *reinterpret_cast<uint4*>(g.C + (size_t)m * g.ldc + n) = o;
       if (epi & EPI_COLSUM) {
 #pragma unroll
-        for (int r = 0; r < 8; ++r) csum[q][r] += v[r];
+        for (int r = 0; r < 8; ++r) {
+#pragma clang fp contract(off)   // no FMA contraction with the multiply that produced v: the same sums in every variant
+          csum[q][r] = csum[q][r] + v[r];
+        }
       }
     }
     if (lds_out) {
@@ -1828,6 +1835,10 @@ __global__ __launch_bounds__(512, 2) void gemm256f_kernel(const GroupArgs ga) {
     G2_T(1)
     const GemmProblem g = *problem_ptr(c_pi);
     const int epi = g.epi;
+    // opaque lane id: the epilogue variants' lane constants are recomputed per tile -- hoisted out of the tile loop they are
+    // spilled across the main loop (one set per variant)
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
     // the A slot consumed last (sa_off already points at the next one)
     unsigned char* scr = smem + ((sa_off == 0) ? 2 * TILE2_BYTES : sa_off - TILE2_BYTES) + wid * 4096;
     // ... and the B slot consumed last (free until this wave's own pieces of the next tile's B(1) go there, in its first step):
@@ -1835,22 +1846,27 @@ __global__ __launch_bounds__(512, 2) void gemm256f_kernel(const GroupArgs ga) {
     unsigned char* scr2 = smem + ((2 * PP_B_BASE + TILE2_BYTES) - sb_off) + wid * 4096;
     if (!B_KS) {
       switch (epi) {
-        case 0: epilogue256<(0), 8, false, true>(g, acc, m0, n0, wm, wn, lane, scr, scr2); break;
-        case EPI_BIAS: epilogue256<(EPI_BIAS), 8, false, true>(g, acc, m0, n0, wm, wn, lane, scr, scr2); break;
-        case EPI_BIAS | EPI_GELU: epilogue256<(EPI_BIAS | EPI_GELU), 8, false, true>(g, acc, m0, n0, wm, wn, lane, scr, scr2); break;
-        case EPI_BIAS | EPI_GELU_FWD: epilogue256<(EPI_BIAS | EPI_GELU_FWD), 8, false, true>(g, acc, m0, n0, wm, wn, lane, scr, scr2); break;
-        case EPI_BIAS | EPI_ADD: epilogue256<(EPI_BIAS | EPI_ADD), 8, false, true>(g, acc, m0, n0, wm, wn, lane, scr, scr2); break;
-        case EPI_BIAS | EPI_ADD | EPI_DROP: epilogue256<(EPI_BIAS | EPI_ADD | EPI_DROP), 8, false, true>(g, acc, m0, n0, wm, wn, lane, scr, scr2); break;
-        default: epilogue256<-1, 8, true, true>(g, acc, m0, n0, wm, wn, lane, scr, scr2); break;
+        case 0: epilogue256<(0), 8, false, true>(g, acc, m0, n0, wm, wn, lane_e, scr, scr2); break;
+        case EPI_BIAS: epilogue256<(EPI_BIAS), 8, false, true>(g, acc, m0, n0, wm, wn, lane_e, scr, scr2); break;
+        case EPI_BIAS | EPI_GELU: epilogue256<(EPI_BIAS | EPI_GELU), 8, false, true>(g, acc, m0, n0, wm, wn, lane_e, scr, scr2); break;
+        case EPI_BIAS | EPI_GELU_FWD: epilogue256<(EPI_BIAS | EPI_GELU_FWD), 8, false, true>(g, acc, m0, n0, wm, wn, lane_e, scr, scr2); break;
+        case EPI_BIAS | EPI_ADD: epilogue256<(EPI_BIAS | EPI_ADD), 8, false, true>(g, acc, m0, n0, wm, wn, lane_e, scr, scr2); break;
+        case EPI_BIAS | EPI_ADD | EPI_DROP: epilogue256<(EPI_BIAS | EPI_ADD | EPI_DROP), 8, false, true>(g, acc, m0, n0, wm, wn, lane_e, scr, scr2); break;
+        default: epilogue256<-1, 8, true, true>(g, acc, m0, n0, wm, wn, lane_e, scr, scr2); break;
       }
     } else if (A_KS && epi == EPI_RMW32) {
-      epilogue256<(EPI_RMW32), 8, false, true>(g, acc, m0, n0, wm, wn, lane, scr, scr2);
+      epilogue256<(EPI_RMW32), 8, false, true>(g, acc, m0, n0, wm, wn, lane_e, scr, scr2);
     } else if (!A_KS && epi == EPI_ADD) {
-      epilogue256<(EPI_ADD), 8, false, true>(g, acc, m0, n0, wm, wn, lane, scr, scr2);
+      epilogue256<(EPI_ADD), 8, false, true>(g, acc, m0, n0, wm, wn, lane_e, scr, scr2);
     } else if (!A_KS && epi == 0) {
-      epilogue256<(0), 8, false, true>(g, acc, m0, n0, wm, wn, lane, scr, scr2);
+      epilogue256<(0), 8, false, true>(g, acc, m0, n0, wm, wn, lane_e, scr, scr2);
+    } else if (!A_KS && epi == (EPI_DGELU | EPI_COLSUM | EPI_COLSUM_WS)) {
+      // FFN-down dgrad: x GELU' + column sums (the two-stage kernel keeps this one generic: specialised there it spilled)
+      epilogue256<(EPI_DGELU | EPI_COLSUM | EPI_COLSUM_WS), 8, false, true>(g, acc, m0, n0, wm, wn, lane_e, scr, scr2);
+    } else if (!A_KS && epi == EPI_DGELU) {
+      epilogue256<(EPI_DGELU), 8, false, true>(g, acc, m0, n0, wm, wn, lane_e, scr, scr2);
     } else {
-      epilogue256<-1, 8, true, true>(g, acc, m0, n0, wm, wn, lane, scr, scr2);
+      epilogue256<-1, 8, true, true>(g, acc, m0, n0, wm, wn, lane_e, scr, scr2);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // scratch reads done before this wave's next DMA lands there
     G2_T(2)
