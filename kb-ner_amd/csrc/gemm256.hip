@@ -2085,6 +2085,12 @@ static int gemm_grouped_impl(int layout, int nprob, const kbner_gemm_problem* pr
   if (TM == 128) return layout == 0 ? launch256<false, false, false, 128>(ga, st) : launch256<false, true, false, 128>(ga, st);
   const int variant = g_gemm_variant.load(std::memory_order_relaxed);
 #ifdef G2_TRACE
+  if ((variant & PP_FLAG_FINE) && layout == 2 && (variant & 0xF000)) {   // cycle-accounting ablations, TN: no DMA wait / no DMA
+    switch ((variant >> 12) & 15) {
+      case 4: return launch256f<true, true, 64>(ga, variant, st);
+      default: return launch256f<true, true, 8>(ga, variant, st);
+    }
+  }
   if ((variant & PP_FLAG_FINE) && layout == 0 && (variant & 0xF000)) {   // cycle-accounting ablations, NT only
     switch ((variant >> 12) & 15) {
       case 1: return launch256f<false, false, 1>(ga, variant, st);
