@@ -8,6 +8,7 @@ Inputs are resident in HBM before the timed region.  Prints ONE JSON line on ran
 
   python bench.py --gpus 1 --steps 5 --warmup 2
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+  python bench.py --gpus N ...        (no launcher: re-executes itself under torch.distributed.run with N ranks)
 """
 import argparse
 import json
@@ -112,7 +113,43 @@ def main():
     ap.add_argument("--dropout", type=float, default=0.0,
                     help="train with this dropout probability at the encoder's three HF sites + WordDropout (default 0: "
                          "BASELINE.md's workload is 'dropout off', and so is the cpu_baseline leg)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="only check the launch: every rank joins a gloo group on the CPU, all-reduces its rank and rank 0 prints "
+                         "{launch_check, world, ranks_seen}; no GPU work (tests/test_bench_launch_cpu.py)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: become N ranks (one process per GPU) under torch.distributed.run on
+        # this node -- the same command line the driver uses -- and pass its exit code on.  (KBNER_BENCH_LAUNCH_DRYRUN: print the
+        # command instead; tests/test_bench_launch_cpu.py.)
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        if os.environ.get("KBNER_BENCH_LAUNCH_DRYRUN"):
+            print(json.dumps({"launch": cmd}))
+            return
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sys.exit(subprocess.call(cmd, env=env))
+
+    if args.launch_check:
+        import torch
+        import torch.distributed as dist
+        w, r = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+        seen = torch.zeros(w)
+        seen[r] = 1.0
+        if w > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo")
+            dist.all_reduce(seen)
+            dist.destroy_process_group()
+        if r == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": args.gpus, "world": w, "ranks_seen": int(seen.sum().item())}))
+        return
 
     import torch
     import torch.distributed as dist

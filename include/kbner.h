@@ -208,13 +208,12 @@ int kbner_colsum_rows_f32(float* ws, int rows, int N, float* out, void* stream);
  * Bit-identical outputs (each output tile is computed the same way whoever computes it).  New capability: the reference has no
  * data-parallel path (flair/trainers/finetune_trainer.py:466,699-700). */
 int kbner_gemm_bf16_grouped_dyn(int layout, int nprob, const kbner_gemm_problem* probs, int* sched, void* stream);
-/* Which main loop the 256-row static launches of the three calls above use (round 4; process-wide, atomic, A/B switch of
- * tools/gemm_bench*.py and tests): bit 0 = the ping-pong loop (gemm256pp_kernel: the two waves of a SIMD alternate between a
- * 32-MFMA compute phase and a DMA-issue / fragment-read phase, 3 + 2 slot operand ring), 0 = the two-stage loop of rounds 1-3;
- * bit 1 = s_setprio 1 around the compute phases, bit 2 = every DMA wait is vmcnt(0) (debugging), bit 3 = the compile-time-
- * specialised GELU' x + column-sum epilogue on the dgrad layout.  Bit-identical outputs in every setting (same MFMA order per
- * accumulator).  kbner_gemm_get_variant returns the current value.  This and the once-per-device flags are the library's only
- * mutable process state. */
+/* Which main loop the 256-row static launches of the three calls above use (round 4; process-wide, atomic; the A/B switch of
+ * tools/gemm_pp_lab.py / tools/ab_step.sh and of tests): 1 (default) = the interleaved ring loop (gemm256f_kernel: 3 + 2 operand
+ * slots, every fragment read / LDS-DMA piece / cursor operation between two MFMAs, last MFMA group held across the barrier),
+ * 0 = the two-stage loop of rounds 1-3 (which the 128-row tiles and the dynamic-tile launches always run).  Bit-identical
+ * outputs in both settings (same MFMA order per accumulator, same epilogue arithmetic).  kbner_gemm_get_variant returns the
+ * current value.  This and the once-per-device flags are the library's only mutable process state. */
 int kbner_gemm_set_variant(int variant);
 int kbner_gemm_get_variant(void);
 /* Split-K for small micro-batches (a few dozen output tiles, long K): the K range is cut into `splits` problems of ONE grouped

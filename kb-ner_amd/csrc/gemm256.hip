@@ -26,7 +26,7 @@
 
 #define G2_MAXP 16
 #ifndef KBNER_GEMM_VARIANT_DEFAULT
-#define KBNER_GEMM_VARIANT_DEFAULT 2048
+#define KBNER_GEMM_VARIANT_DEFAULT 1
 #endif
 
 struct GemmProblem {
@@ -759,40 +759,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GroupArgs ga) {
 
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// Round 4: the PING-PONG main loop.  Same tile (256 x 256 x 64, 8 waves of 128 x 64), same LDS images, fragment maps and
-// epilogues as gemm256_kernel; what changes is WHEN a wave does what.  In gemm256_kernel all 8 waves run the same phase at the
-// same time: after each K step's barrier every wave first queues its 8 LDS-DMA pieces (in-order VMEM issue: the 64 pieces of a
-// stage pass the CU's one address pipe at ~16+ cycles each, and a wave cannot issue its fragment reads before its last piece has
-// been accepted), then waits for the first fragments -- ~800-1000 cycles per K step in which no SIMD has an MFMA to issue
-// (measured: 1.55 us per step against 1.03 us of MFMA issue).  Here the two waves of a SIMD (wave w and w + 4: group 0 = waves
-// 0-3 = the tile's upper 128 rows, group 1 = waves 4-7) run HALF A PHASE APART: while one group issues 32 back-to-back MFMAs on
-// fragments it already holds in registers (a "compute" phase: one K = 32 half step of its 128 x 64 sub-tile), the other group
-// does everything that is not an MFMA (a "memory" phase: DMA issue for a later stage, the 8-16 fragment reads of its next
-// compute phase, address arithmetic, the counted waits).  An s_barrier ends every phase and flips the roles, so the matrix pipe
-// of a SIMD always has exactly one wave feeding it and the LDS / VMEM issue of the other wave runs under it.
-//
-// Ring instead of two stages: fragments are held in registers, so a stage's LDS slot is free as soon as both groups have READ it.
-// 160 KiB = 3 A slots + 2 B slots of 32 KiB.  Stage t's B fragments (both k halves) are read in the first memory phase of the
-// stage, which frees B's slot two phases early; per stage and wave: M0 = issue A(t+2), read A(k half 0) + B(both halves);
-// C0 = 32 MFMAs; M1 = issue B(t+2), read A(k half 1); C1 = 32 MFMAs.  A(t+2) has 7-8 phases (two K steps) to land, B(t+2) 5-6
-// -- against one K step in the two-stage loop, whose period was the HBM flight of a stage (tools/micro/dma_mix.hip).
-// The stage counter runs on across tiles (persistent walk): the next tile's first two stages are in flight during the epilogue.
-// The epilogue's per-wave transpose scratch is the wave's own 4 KiB of the A slot the tile consumed last (that slot's next DMA
-// -- stage 2 of the next tile, the wave's own pieces -- is issued by the same wave after its epilogue).
-// Group 1 runs one phase behind group 0: one extra leading barrier at kernel start, one extra trailing barrier for group 0.
-// At a tile boundary group 0 runs its epilogue AFTER the barrier that ends its last compute phase and group 1 BEFORE the
-// barrier that ends the phase after its last compute phase: both epilogues sit in the same barrier interval and overlap.
+// Round 4: the ring main loop (gemm256f_kernel below).  LDS = 3 A slots + 2 B slots of 32 KiB (one K = 64 operand tile each).
 #define PP_B_BASE (3 * TILE2_BYTES)
 #define PP_LDS_BYTES (5 * TILE2_BYTES)
-#define PP_FLAG_PRIO 2        // s_setprio 1 around the compute phases
-#define PP_FLAG_STRONGWAIT 4  // debugging: every DMA wait is vmcnt(0)
-#define PP_FLAG_SPEC584 8     // NN: the compile-time-specialised GELU' x + column-sum epilogue (spills ~60 registers) instead of the generic one
-#define PP_FLAG_NODMA 16      // ablation (timing only, wrong results): no LDS-DMA inside the K loop
-#define PP_FLAG_NOMFMA 32     // ablation (timing only, wrong results): no MFMAs
-#define PP_FLAG_NOREADS 128   // ablation (timing only): fragment reads only in the first K step of a tile
-#define PP_FLAG_FINE 2048     // the fine-grained ring loop (gemm256f_kernel)
-#define PP_FLAG_RING 256      // the ring loop (gemm256r_kernel)
-#define PP_FLAG_ROT 64        // the rotated two-barrier loop (gemm256rot_kernel)
 
 static __device__ __forceinline__ void pp_barrier() {
   asm volatile("" ::: "memory");
@@ -802,7 +771,8 @@ static __device__ __forceinline__ void pp_barrier() {
   asm volatile("" ::: "memory");
 }
 
-// the per-lane source offsets of a wave's four 1-KiB pieces of an operand tile (stage256's arithmetic, kept apart from the issue)
+// the per-lane source offsets of a wave's four 1-KiB pieces of an operand tile (stage256's arithmetic, kept apart from the issue;
+// piece j's offset already carries the - j KiB of its instruction's immediate offset, see glds16x4)
 template <bool KS, bool ISB>
 static __device__ __forceinline__ void stage_voff(int ld, int wid, int lane, unsigned (&voff)[4]) {
 #pragma unroll
@@ -819,7 +789,7 @@ static __device__ __forceinline__ void stage_voff(int ld, int wid, int lane, uns
     }
   }
 }
-// piece J of the four (voff already carries the - J KiB of glds16x4's addressing)
+// piece J of the four, with its own M0 write (two scalar instructions: free between two MFMAs)
 template <int J>
 static __device__ __forceinline__ void glds16_piece(const void* sbase, unsigned voff, unsigned dst) {
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3"
@@ -827,495 +797,8 @@ static __device__ __forceinline__ void glds16_piece(const void* sbase, unsigned 
                : "v"(voff), "s"(sbase), "s"(dst), "n"(J * 1024)
                : "memory", "m0");
 }
-
-template <bool A_KS, bool B_KS, int MODE>
-__global__ __launch_bounds__(512, 2) void gemm256pp_kernel(const GroupArgs ga) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grp = wid >> 2;
-  const int wm = grp, wn = wid & 3;
-  const int total = ga.total_tiles;
-  const int gstep = (int)gridDim.x;
-  const int flags = ga.pad_;
-  const bool prio = (flags & PP_FLAG_PRIO) != 0;
-  const bool strong = (flags & PP_FLAG_STRONGWAIT) != 0;
-  const bool spec584 = (flags & PP_FLAG_SPEC584) != 0;
-  const bool nodma = (flags & PP_FLAG_NODMA) != 0;
-  const bool nomfma = (flags & PP_FLAG_NOMFMA) != 0;
-  const bool noreads = (flags & PP_FLAG_NOREADS) != 0;
-  G2_CLK(0)
-
-  // ---- issue cursor: the (tile, K stage) the next DMA belongs to; runs two stages ahead of the consumer, across tiles
-  int i_id = blockIdx.x, i_t = 0, i_nt = 0, i_m0 = 0, i_n0 = 0, i_lda = 0, i_ldb = 0;
-  const bf16_t* i_A = nullptr;
-  const bf16_t* i_B = nullptr;
-  bool i_valid = true;
-  int ia = 0, ib = 0;   // ring slots of the next issue
-#define PP_ILOAD()                                      \
-  {                                                     \
-    GemmProblem gi;                                     \
-    pick_tile<256>(ga, i_id, total, gi, i_m0, i_n0);    \
-    i_nt = gi.K / BK2;                                  \
-    i_A = gi.A;                                         \
-    i_B = gi.B;                                         \
-    i_lda = gi.lda;                                     \
-    i_ldb = gi.ldb;                                     \
-  }
-#define PP_ISSUE_A()                                                                                   \
-  {                                                                                                    \
-    stage256<A_KS, false, 256>(i_A, i_lda, i_m0, i_t * BK2, smem + ia * TILE2_BYTES, wid, lane_m);      \
-    ia = (ia == 2) ? 0 : ia + 1;                                                                       \
-  }
-#define PP_ISSUE_B()                                                                                         \
-  {                                                                                                          \
-    stage256<B_KS, true>(i_B, i_ldb, i_n0, i_t * BK2, smem + PP_B_BASE + ib * TILE2_BYTES, wid, lane_m);      \
-    ib ^= 1;                                                                                                 \
-  }
-#define PP_IADV()                 \
-  {                               \
-    if (++i_t == i_nt) {          \
-      i_t = 0;                    \
-      i_id += gstep;              \
-      if (i_id < total) PP_ILOAD() \
-      else i_valid = false;       \
-    }                             \
-  }
-#define PP_WAIT(issued, n)                                                                  \
-  {                                                                                         \
-    if ((issued) && !strong) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory");          \
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                   \
-  }
-
-  // lane_m: the main loop's copy of the lane id, made opaque again at every tile start so that hipcc RECOMPUTES the ~25 lane-
-  // constant fragment / DMA address registers after an epilogue instead of spilling them across it (the NN layout's scratch
-  // reloads at tile start left compiler-tracked loads pending into the K loop, i.e. vmcnt(0) waits in front of the DMA)
-  int lane_m = lane;
-  asm volatile("" : "+v"(lane_m));
-  PP_ILOAD();
-  PP_ISSUE_A();
-  PP_ISSUE_B();
-  PP_IADV();
-  {
-    const bool two = i_valid;
-    if (two) {
-      PP_ISSUE_A();
-      PP_ISSUE_B();
-      PP_IADV();
-    }
-    PP_WAIT(two, 8);
-  }
-  pp_barrier();                  // stage 0 of the first tile is visible to everybody
-  if (grp == 1) pp_barrier();    // group 1 starts one phase late
-
-  int id = blockIdx.x;
-  int ca = 0, cb = 0;            // ring slots of the stage being consumed
-  for (;;) {
-    int m0, n0, nt;
-    {
-      GemmProblem gm;
-      pick_tile<256>(ga, id, total, gm, m0, n0);
-      nt = gm.K / BK2;
-    }
-    f4v acc[8][4];
-#pragma unroll
-    for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
-    lane_m = lane;
-    asm volatile("" : "+v"(lane_m));
-
-    for (int t = 0; t < nt; ++t) {
-      const unsigned char* sa = smem + ca * TILE2_BYTES;
-      const unsigned char* sb = smem + PP_B_BASE + cb * TILE2_BYTES;
-      const bool iss = i_valid && !nodma;
-      const bool adv = i_valid;
-      bf16x8 a[8], b0[4], b1[4];
-      // MODE 1: what the compute phase needs to issue the four pieces of an operand tile
-      unsigned pv[4] = {0u, 0u, 0u, 0u};
-      const bf16_t* pbase = nullptr;
-      unsigned pdst = 0u;
-      // ---- M0: A(t+2) -> the slot stage t-1 used; fragments of k half 0 and all of B
-      if (MODE == 0) {
-        if (iss) PP_ISSUE_A();
-      } else if (iss) {
-        stage_voff<A_KS, false>(i_lda, wid, lane_m, pv);
-        pbase = A_KS ? i_A + (size_t)(i_t * BK2) * i_lda + i_m0 : i_A + (size_t)i_m0 * i_lda + i_t * BK2;
-        pdst = (unsigned)(size_t)(lds_void*)(smem + ia * TILE2_BYTES + wid * 4096);
-        ia = (ia == 2) ? 0 : ia + 1;
-      }
-      if (!noreads || t == 0) {
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) b0[ni] = fragB256<B_KS>(sb, wn * 64, ni, 0, lane_m);
-#pragma unroll
-      for (int mi = 0; mi < 8; ++mi) a[mi] = frag256<A_KS>(sa, wm * 128 + mi * 16, 0, lane_m);
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) b1[ni] = fragB256<B_KS>(sb, wn * 64, ni, 1, lane_m);
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      pp_barrier();
-      // ---- C0
-      if (prio) __builtin_amdgcn_s_setprio(1);
-      if (!nomfma) {
-#pragma unroll
-        for (int mi = 0; mi < 8; ++mi) {
-#pragma unroll
-          for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[ni], a[mi], acc[mi][ni], 0, 0, 0);
-          if (MODE == 1 && (mi & 1)) {
-            __builtin_amdgcn_sched_barrier(0);
-            if (iss) {
-              if (mi == 1) glds16_piece<0>(pbase, pv[0], pdst);
-              if (mi == 3) glds16_piece<1>(pbase, pv[1], pdst);
-              if (mi == 5) glds16_piece<2>(pbase, pv[2], pdst);
-              if (mi == 7) glds16_piece<3>(pbase, pv[3], pdst);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
-      }
-      if (prio) __builtin_amdgcn_s_setprio(0);
-      pp_barrier();
-      // ---- M1: B(t+2) -> the slot stage t used (both groups have read all of it); fragments of k half 1
-      if (MODE == 0) {
-        if (iss) PP_ISSUE_B();
-      } else if (iss) {
-        stage_voff<B_KS, true>(i_ldb, wid, lane_m, pv);
-        pbase = B_KS ? i_B + (size_t)(i_t * BK2) * i_ldb + i_n0 : i_B + (size_t)i_n0 * i_ldb + i_t * BK2;
-        pdst = (unsigned)(size_t)(lds_void*)(smem + PP_B_BASE + ib * TILE2_BYTES + wid * 4096);
-        ib ^= 1;
-      }
-      if (!noreads) {
-#pragma unroll
-      for (int mi = 0; mi < 8; ++mi) a[mi] = frag256<A_KS>(sa, wm * 128 + mi * 16, 1, lane_m);
-      }
-      if (adv) PP_IADV();
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      // this wave's pieces of stage t+1 have landed.  Younger in its queue: MODE 0 A(t+2), B(t+2); MODE 1 (group 1 issues
-      // B(t+2) in the compute phase that follows) A(t+2) only
-      if (grp == 1) {
-        if (MODE == 0) PP_WAIT(iss, 8) else PP_WAIT(iss, 4)
-      }
-      pp_barrier();
-      // ---- C1
-      if (prio) __builtin_amdgcn_s_setprio(1);
-      if (!nomfma) {
-#pragma unroll
-        for (int mi = 0; mi < 8; ++mi) {
-#pragma unroll
-          for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[ni], a[mi], acc[mi][ni], 0, 0, 0);
-          if (MODE == 1 && (mi & 1)) {
-            __builtin_amdgcn_sched_barrier(0);
-            if (iss) {
-              if (mi == 1) glds16_piece<0>(pbase, pv[0], pdst);
-              if (mi == 3) glds16_piece<1>(pbase, pv[1], pdst);
-              if (mi == 5) glds16_piece<2>(pbase, pv[2], pdst);
-              if (mi == 7) glds16_piece<3>(pbase, pv[3], pdst);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
-      }
-      if (prio) __builtin_amdgcn_s_setprio(0);
-      if (grp == 0) PP_WAIT(iss, 8);
-      ca = (ca == 2) ? 0 : ca + 1;
-      cb ^= 1;
-      if (t + 1 < nt) pp_barrier();
-    }
-
-    if (grp == 0) pp_barrier();
-    GemmProblem g;
-    {
-      int mm, nn;
-      pick_tile<256>(ga, id, total, g, mm, nn);
-    }
-    const int epi = g.epi;
-    const int last_a = (ca == 0) ? 2 : ca - 1;
-    unsigned char* scr = smem + last_a * TILE2_BYTES + wid * 4096;
-    if (!B_KS) {
-      switch (epi) {
-        case 0: epilogue256<0, 8>(g, acc, m0, n0, wm, wn, lane, scr); break;
-        case EPI_BIAS: epilogue256<EPI_BIAS, 8>(g, acc, m0, n0, wm, wn, lane, scr); break;
-        case EPI_BIAS | EPI_GELU: epilogue256<(EPI_BIAS | EPI_GELU), 8>(g, acc, m0, n0, wm, wn, lane, scr); break;
-        case EPI_BIAS | EPI_GELU_FWD: epilogue256<(EPI_BIAS | EPI_GELU_FWD), 8>(g, acc, m0, n0, wm, wn, lane, scr); break;
-        case EPI_BIAS | EPI_ADD: epilogue256<(EPI_BIAS | EPI_ADD), 8>(g, acc, m0, n0, wm, wn, lane, scr); break;
-        case EPI_BIAS | EPI_ADD | EPI_DROP: epilogue256<(EPI_BIAS | EPI_ADD | EPI_DROP), 8>(g, acc, m0, n0, wm, wn, lane, scr); break;
-        default: epilogue256<-1, 8, true>(g, acc, m0, n0, wm, wn, lane, scr); break;
-      }
-    } else if (A_KS && epi == EPI_RMW32) {
-      epilogue256<EPI_RMW32, 8>(g, acc, m0, n0, wm, wn, lane, scr);
-    } else if (!A_KS && epi == EPI_ADD) {
-      epilogue256<EPI_ADD, 8>(g, acc, m0, n0, wm, wn, lane, scr);
-    } else if (!A_KS && epi == 0) {
-      epilogue256<0, 8>(g, acc, m0, n0, wm, wn, lane, scr);
-    } else if (!A_KS && spec584 && epi == (EPI_DGELU | EPI_COLSUM | EPI_COLSUM_WS)) {
-      epilogue256<(EPI_DGELU | EPI_COLSUM | EPI_COLSUM_WS), 8>(g, acc, m0, n0, wm, wn, lane, scr);
-    } else {
-      epilogue256<-1, 8, true>(g, acc, m0, n0, wm, wn, lane, scr);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the scratch reads are done before this wave's next DMA lands there
-    if (grp == 1) pp_barrier();
-    id += gstep;
-    if (id >= total) break;
-  }
-  if (grp == 0) pp_barrier();   // pairs with group 1's last trailing barrier
-  G2_CLK(1)
-#undef PP_ILOAD
-#undef PP_ISSUE_A
-#undef PP_ISSUE_B
-#undef PP_IADV
-#undef PP_WAIT
-}
-
-// ---------------------------------------------------------------------------------------------------------------------------
-// The ROTATED ping-pong loop (what the measurements of the four-barrier version above led to; tools/gemm_pp_lab.py,
-// profiles/round4_pp_lab_phase_ablation.txt: per K step of an 8192^3 NT problem the two-stage loop takes 1.59 us, the four-
-// barrier ping-pong 1.53, its memory phases alone 1.05, its phases with neither DMA nor MFMA 0.69 -- i.e. ~140 cycles per
-// barrier interval are rendezvous, and its first memory phase (16 fragment reads + 4 DMA pieces, ~640 cycles) is longer than a
-// 32-MFMA compute phase (~544)).  Same ring, same phases, but only TWO barriers per K step, and the two groups run the phases of
-// an interval in OPPOSITE ORDER instead of meeting at a barrier after every phase:
-//     group 0:  b  M0(t) C0(t)        b  M1(t) C1(t)
-//     group 1:  b  C1(t-1) M0(t)      b  C0(t) M1(t)
-// After a barrier group 1 issues 32 MFMAs on fragments it already holds while group 0 issues DMA and reads; then the roles
-// swap without a rendezvous (if a memory phase runs long the partner's MFMAs simply start later; the matrix pipe arbitrates).
-// Group 1's last compute phase of a tile falls behind the first barrier of the next tile, so BOTH groups run the epilogue of
-// tile n after that barrier (concurrently), in front of their first memory phase of tile n + 1.  DMA balance: M0 carries two of
-// A(t+2)'s four pieces, M1 the other two and B(t+2) (whose slot is free once both groups have passed the mid-step barrier).
-
-template <bool A_KS, bool B_KS>
-__global__ __launch_bounds__(512, 2) void gemm256rot_kernel(const GroupArgs ga) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grp = wid >> 2;
-  const int wm = grp, wn = wid & 3;
-  const int total = ga.total_tiles;
-  const int gstep = (int)gridDim.x;
-  const int flags = ga.pad_;
-  const bool prio = (flags & PP_FLAG_PRIO) != 0;
-  const bool strong = (flags & PP_FLAG_STRONGWAIT) != 0;
-  const bool nodma = (flags & PP_FLAG_NODMA) != 0;
-  const bool nomfma = (flags & PP_FLAG_NOMFMA) != 0;
-  const bool noreads = (flags & PP_FLAG_NOREADS) != 0;
-  G2_CLK(0)
-
-  int i_id = blockIdx.x, i_t = 0, i_nt = 0, i_m0 = 0, i_n0 = 0, i_lda = 0, i_ldb = 0;
-  const bf16_t* i_A = nullptr;
-  const bf16_t* i_B = nullptr;
-  bool i_valid = true;
-  int ia = 0, ib = 0;
-#define PR_ILOAD()                                      \
-  {                                                     \
-    GemmProblem gi;                                     \
-    pick_tile<256>(ga, i_id, total, gi, i_m0, i_n0);    \
-    i_nt = gi.K / BK2;                                  \
-    i_A = gi.A;                                         \
-    i_B = gi.B;                                         \
-    i_lda = gi.lda;                                     \
-    i_ldb = gi.ldb;                                     \
-  }
-#define PR_IADV()                 \
-  {                               \
-    if (++i_t == i_nt) {          \
-      i_t = 0;                    \
-      i_id += gstep;              \
-      if (i_id < total) PR_ILOAD() \
-      else i_valid = false;       \
-    }                             \
-  }
-#define PR_WAIT(issued, n)                                                                  \
-  {                                                                                         \
-    if ((issued) && !strong) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory");          \
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                   \
-  }
-#define PR_MMA(bfr)                                                                                                        \
-  {                                                                                                                        \
-    if (prio) __builtin_amdgcn_s_setprio(1);                                                                               \
-    if (!nomfma) {                                                                                                         \
-      _Pragma("unroll") for (int mi = 0; mi < 8; ++mi) _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) acc[mi][ni] =       \
-          __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], a[mi], acc[mi][ni], 0, 0, 0);                                     \
-    }                                                                                                                      \
-    if (prio) __builtin_amdgcn_s_setprio(0);                                                                               \
-    __builtin_amdgcn_sched_barrier(0);                                                                                     \
-  }
-
-  int lane_m = lane;
-  asm volatile("" : "+v"(lane_m));
-  PR_ILOAD();
-  for (int s0 = 0; s0 < 2; ++s0) {   // stages 0 and 1 of this workgroup's walk
-    if (i_valid) {
-      stage256<A_KS, false, 256>(i_A, i_lda, i_m0, i_t * BK2, smem + ia * TILE2_BYTES, wid, lane_m);
-      stage256<B_KS, true>(i_B, i_ldb, i_n0, i_t * BK2, smem + PP_B_BASE + ib * TILE2_BYTES, wid, lane_m);
-      ia = ia + 1;
-      ib ^= 1;
-      PR_IADV();
-      if (s0 == 0) {
-        const bool two = i_valid;
-        if (!two) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      } else {
-        PR_WAIT(true, 8);
-      }
-    }
-  }
-
-  int id = blockIdx.x;
-  int ca = 0, cb = 0;
-  bool started = false;
-  int p_id = 0, p_m0 = 0, p_n0 = 0, p_last_a = 0;   // the tile whose epilogue is due
-  f4v acc[8][4];
-  bf16x8 a[8], b0[4], b1[4];
-#pragma unroll
-  for (int mi = 0; mi < 8; ++mi) a[mi] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-  for (int ni = 0; ni < 4; ++ni) b1[ni] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-  for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
-
-  for (;;) {
-    const bool have = id < total;
-    int m0 = 0, n0 = 0, nt = 1;
-    if (have) {
-      GemmProblem gm;
-      pick_tile<256>(ga, id, total, gm, m0, n0);
-      nt = gm.K / BK2;
-    }
-    pp_barrier();   // b(0,0) of this tile: its stage 0 is visible; the slot of the previous stage's A is free
-    if (grp == 1 && started) PR_MMA(b1);   // C1 of the previous tile's last K step
-    if (started) {
-    int lane_e = lane;   // opaque: the epilogue's lane constants are recomputed per tile, not kept live across the K loop
-    asm volatile("" : "+v"(lane_e));
-    GemmProblem g;
-    {
-      int mm, nn;
-      pick_tile<256>(ga, p_id, total, g, mm, nn);
-    }
-    const int epi = g.epi;
-    unsigned char* scr = smem + p_last_a * TILE2_BYTES + wid * 4096;
-    if (!B_KS) {
-      switch (epi) {
-        case 0: epilogue256<0, 8>(g, acc, p_m0, p_n0, wm, wn, lane_e, scr); break;
-        case EPI_BIAS: epilogue256<EPI_BIAS, 8>(g, acc, p_m0, p_n0, wm, wn, lane_e, scr); break;
-        case EPI_BIAS | EPI_GELU: epilogue256<(EPI_BIAS | EPI_GELU), 8>(g, acc, p_m0, p_n0, wm, wn, lane_e, scr); break;
-        case EPI_BIAS | EPI_GELU_FWD: epilogue256<(EPI_BIAS | EPI_GELU_FWD), 8>(g, acc, p_m0, p_n0, wm, wn, lane_e, scr); break;
-        case EPI_BIAS | EPI_ADD: epilogue256<(EPI_BIAS | EPI_ADD), 8>(g, acc, p_m0, p_n0, wm, wn, lane_e, scr); break;
-        case EPI_BIAS | EPI_ADD | EPI_DROP: epilogue256<(EPI_BIAS | EPI_ADD | EPI_DROP), 8>(g, acc, p_m0, p_n0, wm, wn, lane_e, scr); break;
-        default: epilogue256<-1, 8, true>(g, acc, p_m0, p_n0, wm, wn, lane_e, scr); break;
-      }
-    } else if (A_KS && epi == EPI_RMW32) {
-      epilogue256<EPI_RMW32, 8>(g, acc, p_m0, p_n0, wm, wn, lane_e, scr);
-    } else if (!A_KS && epi == EPI_ADD) {
-      epilogue256<EPI_ADD, 8>(g, acc, p_m0, p_n0, wm, wn, lane_e, scr);
-    } else if (!A_KS && epi == 0) {
-      epilogue256<0, 8>(g, acc, p_m0, p_n0, wm, wn, lane_e, scr);
-    } else {
-      epilogue256<-1, 8, true>(g, acc, p_m0, p_n0, wm, wn, lane_e, scr);
-    }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // scratch reads done before this wave's next DMA lands there
-    }
-    if (!have) break;
-#pragma unroll
-    for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
-    lane_m = lane;
-    asm volatile("" : "+v"(lane_m));
-    for (int t = 0; t < nt; ++t) {
-      if (t > 0) {
-        pp_barrier();   // b(t,0): stage t is visible; the slot of A(t-1) is free
-        if (grp == 1) PR_MMA(b1);   // C1 of the previous K step
-      }
-      const unsigned char* sa = smem + ca * TILE2_BYTES;
-      const unsigned char* sb = smem + PP_B_BASE + cb * TILE2_BYTES;
-      const bool iss = i_valid && !nodma;
-      const bool adv = i_valid;
-      // ---- M0: two pieces of A(t+2); fragments of k half 0 and all of B
-      unsigned pv[4] = {0u, 0u, 0u, 0u};
-      const bf16_t* pbase = nullptr;
-      unsigned pdst = 0u;
-      if (iss) {
-        stage_voff<A_KS, false>(i_lda, wid, lane_m, pv);
-        pbase = A_KS ? i_A + (size_t)(i_t * BK2) * i_lda + i_m0 : i_A + (size_t)i_m0 * i_lda + i_t * BK2;
-        pdst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void*)(smem + ia * TILE2_BYTES + wid * 4096));
-        glds16_pair<0>(pbase, pv[0], pv[1], pdst);
-      }
-      if (!noreads || t == 0) {
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) b0[ni] = fragB256<B_KS>(sb, wn * 64, ni, 0, lane_m);
-#pragma unroll
-      for (int mi = 0; mi < 8; ++mi) a[mi] = frag256<A_KS>(sa, wm * 128 + mi * 16, 0, lane_m);
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) b1[ni] = fragB256<B_KS>(sb, wn * 64, ni, 1, lane_m);
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      if (grp == 0) PR_MMA(b0);   // C0
-      pp_barrier();   // b(t,1): both groups have read all of B(t)
-      if (grp == 1) PR_MMA(b0);   // C0
-      // ---- M1: the other two pieces of A(t+2), B(t+2); fragments of k half 1
-      if (iss) {
-        int lane_p = lane_m;   // opaque: the two offsets are recomputed here instead of staying live across the compute phase
-        asm volatile("" : "+v"(lane_p));
-        stage_voff<A_KS, false>(i_lda, wid, lane_p, pv);
-        glds16_pair<2>(pbase, pv[2], pv[3], pdst);
-        ia = (ia == 2) ? 0 : ia + 1;
-        stage256<B_KS, true>(i_B, i_ldb, i_n0, i_t * BK2, smem + PP_B_BASE + ib * TILE2_BYTES, wid, lane_m);
-        ib ^= 1;
-      }
-      if (!noreads) {
-#pragma unroll
-      for (int mi = 0; mi < 8; ++mi) a[mi] = frag256<A_KS>(sa, wm * 128 + mi * 16, 1, lane_m);
-      }
-      if (adv) PR_IADV();
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      if (grp == 0) PR_MMA(b1);   // C1 (group 1: after the next barrier)
-      PR_WAIT(iss, 8);            // this wave's pieces of stage t+1 have landed (younger: A(t+2), B(t+2))
-      ca = (ca == 2) ? 0 : ca + 1;
-      cb ^= 1;
-      started = true;
-    }
-    p_id = id;
-    p_m0 = m0;
-    p_n0 = n0;
-    p_last_a = (ca == 0) ? 2 : ca - 1;
-    id += gstep;
-  }
-  G2_CLK(1)
-#undef PR_ILOAD
-#undef PR_IADV
-#undef PR_WAIT
-#undef PR_MMA
-}
-
-// ---------------------------------------------------------------------------------------------------------------------------
-// The RING loop (round 4).  Cycle accounting (tools/gemm_clk.sh, profiles/round4_gemm_cycle_accounting.txt: s_memtime against
-// s_memrealtime inside the kernels) says every main loop tried takes 2900-3060 shader cycles per K step against 2100 of MFMA
-// pipe time per SIMD, whatever the wall clock does (the chip runs these kernels at 1.7-1.8 GHz on random data and 2.3 on zeros:
-// wall-time A/Bs mostly measure power).  An MFMA blocks its wave's issue for its 16.4 cycles and every other instruction for
-// ~4-5, so the two waves of a SIMD only keep the pipe busy if neither stalls: the two-stage loop of rounds 1-3 (93 non-MFMA
-// instructions per wave and step) loses ~800 cycles per step to what happens at its barrier -- all eight waves queue their 8
-// LDS-DMA pieces right behind it (~50 cycles of issue each, both waves of every SIMD at the same time) and then wait out the
-// latency of the new stage's first fragment reads --, and the ping-pong / fine-grained variants above spend what they win there
-// on extra scalar work (branches, cursor arithmetic: 200 non-MFMA instructions per step = 1100 cycles per wave).
-// This loop keeps the two-stage loop's instruction stream (identical code in all 8 waves, 8-MFMA groups with the next group's
-// fragments read one group ahead, one barrier per K step) and changes what happens around the barrier:
-//   * operand RING (3 A slots + 2 B slots of 32 KiB): the DMA of a step is no longer tied to its barrier.  A wave's four pieces of
-//     B(t+1) and of A(t+2) go out as two bursts in the middle of step t, at DIFFERENT points for the two waves of a SIMD (group
-//     0 = waves 0-3 after MFMA groups 0 and 2, group 1 = waves 4-7 after groups 2 and 4), so the partner wave has the matrix
-//     pipe to itself meanwhile; A has two steps to land, B (the L2-resident weight in the forward / dgrad layouts) most of one;
-//   * the LAST MFMA group of a step is held back across the barrier: behind the barrier a wave first requests the first six
-//     fragments of the new stage, then issues the 8 held MFMAs, which cover that LDS latency;
-//   * the DMA wait sits in front of the barrier that precedes the EPILOGUE too, so no epilogue store is ever queued in front of a
-//     load that has to be waited for (no `pend` bookkeeping), and that barrier frees the A slot consumed last, whose wave-private
-//     4 KiB are the epilogue's transpose scratch (the slot's next DMA, A(2) of the next tile, is the wave's own pieces);
-//   * running pointers instead of per-step address arithmetic: ~35 scalar instructions per step.
-// ABL (trace builds): compile-time ablations for cycle accounting: 1 no barrier, 2 fragment reads only in a tile's first step,
-// 4 no MFMAs, 8 no in-loop DMA (timing only, wrong results).
+// all four pieces under one M0 write (prologue)
 static __device__ __forceinline__ void glds16_quad(const void* sbase, unsigned v0, unsigned v1, unsigned v2, unsigned v3, unsigned dst) {
-  // v_j already carries the - j KiB of the immediate offsets (stage_voff)
   asm volatile(
       "s_mov_b32 m0, %5\n\ts_nop 0\n\t"
       "global_load_lds_dwordx4 %0, %4\n\t"
@@ -1325,234 +808,6 @@ static __device__ __forceinline__ void glds16_quad(const void* sbase, unsigned v
       :
       : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(sbase), "s"(dst)
       : "memory", "m0");
-}
-
-template <bool A_KS, bool B_KS, int ABL = 0>
-__global__ __launch_bounds__(512, 2) void gemm256r_kernel(const GroupArgs ga) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wid >> 2, wn = wid & 3;
-  const int grp = wm;
-  const int total = ga.total_tiles;
-  const int gstep = (int)gridDim.x;
-  G2_CLK(0)
-
-  int lane_m = lane;   // opaque copy for the main loop's address arithmetic (see gemm256pp_kernel)
-  asm volatile("" : "+v"(lane_m));
-  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void*)smem);
-  // ---- two issue cursors running ahead of the consumer across tiles (A by two K stages, B by one): a running source pointer,
-  // the steps left in the cursor's tile, the LDS address of the wave's four pieces in the next ring slot
-  int a_id = blockIdx.x, a_left = 0;
-  const bf16_t* a_ptr = nullptr;
-  size_t a_stride = 0;
-  bool a_ok = true;
-  unsigned a_dst = lds0 + wid * 4096;
-  unsigned va[4];
-  int b_id = blockIdx.x, b_left = 0;
-  const bf16_t* b_ptr = nullptr;
-  size_t b_stride = 0;
-  bool b_ok = true;
-  unsigned b_dst = lds0 + PP_B_BASE + wid * 4096;
-  unsigned vb[4];
-#define RR_ALOAD()                                                                        \
-  {                                                                                       \
-    GemmProblem gi;                                                                       \
-    int m_, n_;                                                                           \
-    pick_tile<256>(ga, a_id, total, gi, m_, n_);                                          \
-    a_left = gi.K / BK2;                                                                  \
-    a_ptr = A_KS ? gi.A + m_ : gi.A + (size_t)m_ * gi.lda;                               \
-    a_stride = A_KS ? (size_t)BK2 * gi.lda : (size_t)BK2;                                 \
-    stage_voff<A_KS, false>(gi.lda, wid, lane_m, va);                                     \
-  }
-#define RR_BLOAD()                                                                        \
-  {                                                                                       \
-    GemmProblem gi;                                                                       \
-    int m_, n_;                                                                           \
-    pick_tile<256>(ga, b_id, total, gi, m_, n_);                                          \
-    b_left = gi.K / BK2;                                                                  \
-    b_ptr = B_KS ? gi.B + n_ : gi.B + (size_t)n_ * gi.ldb;                               \
-    b_stride = B_KS ? (size_t)BK2 * gi.ldb : (size_t)BK2;                                 \
-    stage_voff<B_KS, true>(gi.ldb, wid, lane_m, vb);                                      \
-  }
-#define RR_AADV()                                                       \
-  {                                                                     \
-    a_ptr += a_stride;                                                  \
-    a_dst = (a_dst + TILE2_BYTES >= lds0 + PP_B_BASE) ? a_dst - 2 * TILE2_BYTES : a_dst + TILE2_BYTES; \
-    if (--a_left == 0) {                                                \
-      a_id += gstep;                                                    \
-      if (a_id < total) RR_ALOAD()                                      \
-      else a_ok = false;                                                \
-    }                                                                   \
-  }
-#define RR_BADV()                                                       \
-  {                                                                     \
-    b_ptr += b_stride;                                                  \
-    b_dst = (2 * (lds0 + PP_B_BASE + wid * 4096) + TILE2_BYTES) - b_dst; \
-    if (--b_left == 0) {                                                \
-      b_id += gstep;                                                    \
-      if (b_id < total) RR_BLOAD()                                      \
-      else b_ok = false;                                                \
-    }                                                                   \
-  }
-#define RR_ABURST() glds16_quad(a_ptr, va[0], va[1], va[2], va[3], a_dst)
-#define RR_BBURST() glds16_quad(b_ptr, vb[0], vb[1], vb[2], vb[3], b_dst)
-
-  RR_ALOAD();
-  RR_BLOAD();
-  RR_ABURST();
-  RR_AADV();
-  RR_BBURST();
-  RR_BADV();
-  if (a_ok) {
-    RR_ABURST();
-    RR_AADV();
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  pp_barrier();   // stage 0 of the first tile is visible
-
-  int id = blockIdx.x;
-  unsigned sa_off = 0, sb_off = PP_B_BASE;   // ring slots of the stage being consumed (byte offsets into smem)
-#define RR_SB() __builtin_amdgcn_sched_barrier(0)
-#define RR_RD (!(ABL & 2) || t == 0)
-#define RR_LOADB(dst, ks) \
-  if (RR_RD) _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) dst[ni] = fragB256<B_KS>(smem + sb_off, wn * 64, ni, ks, lane_m)
-#define RR_LOADA(dst, ks, pr)                                                            \
-  if (RR_RD) {                                                                           \
-    dst[0] = frag256<A_KS>(smem + sa_off, wm * 128 + (2 * (pr)) * 16, ks, lane_m);       \
-    dst[1] = frag256<A_KS>(smem + sa_off, wm * 128 + (2 * (pr) + 1) * 16, ks, lane_m);   \
-  }
-#define RR_MM(a, b, pr)                                                                                                              \
-  if (!(ABL & 4)) _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) acc[2 * (pr) + j][ni] = \
-      __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[ni], a[j], acc[2 * (pr) + j][ni], 0, 0, 0)
-  for (;;) {
-    int m0, n0, nt;
-    {
-      GemmProblem gm;
-      pick_tile<256>(ga, id, total, gm, m0, n0);
-      nt = gm.K / BK2;
-    }
-    bf16x8 b0[4], b1[4], a0[2], a1[2];
-    if (ABL & 2) {
-      a1[0] = a1[1] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) b1[ni] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-    }
-    {
-      const int t = 0;
-      (void)t;
-      RR_LOADB(b0, 0);
-      RR_LOADA(a0, 0, 0);
-    }
-    f4v acc[8][4];
-#pragma unroll
-    for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
-    RR_SB();
-    for (int t = 0; t < nt; ++t) {
-      const bool isb = b_ok && !(ABL & (8 | 16)), isa = a_ok && !(ABL & (8 | 32));   // 16 / 32: no B / no A bursts
-      // DMA bursts at eight positions of the step, two waves (of different SIMDs) per position: the CU's one address pipe takes
-      // ~16 cycles per 1-KiB piece, so four waves bursting together each wait ~50 cycles per piece, two waves ~20
-      const int wp = wid >> 1;
-      RR_LOADA(a1, 0, 1); RR_SB(); RR_MM(a0, b0, 0); RR_SB();
-      if (wp == 0 && isb) RR_BBURST();
-      RR_LOADA(a0, 0, 2); RR_SB(); RR_MM(a1, b0, 1); RR_SB();
-      if (wp == 1 && isb) RR_BBURST();
-      RR_LOADA(a1, 0, 3); RR_SB(); RR_MM(a0, b0, 2); RR_SB();
-      if (wp == 2 && isb) RR_BBURST();
-      RR_LOADB(b1, 1);
-      RR_LOADA(a0, 1, 0); RR_SB(); RR_MM(a1, b0, 3); RR_SB();
-      if (wp == 3 && isb) RR_BBURST();
-      RR_LOADA(a1, 1, 1); RR_SB(); RR_MM(a0, b1, 0); RR_SB();
-      if (wp == 0 && isa) RR_ABURST();
-      RR_LOADA(a0, 1, 2); RR_SB(); RR_MM(a1, b1, 1); RR_SB();
-      if (wp == 1 && isa) RR_ABURST();
-      RR_LOADA(a1, 1, 3); RR_SB(); RR_MM(a0, b1, 2); RR_SB();
-      if (wp == 2 && isa) RR_ABURST();
-      if (wp == 3 && isa) RR_ABURST();
-      if (b_ok) RR_BADV();
-      if (a_ok) RR_AADV();
-      // B(t+1) (and the older A(t+1)) have landed: the only younger pieces in this wave's queue are A(t+2)'s four
-      if (isa) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      // (the builtin, not inline asm: hipcc must KNOW the LGKM queue is empty here -- the scalar loads of a cursor's tile crossing
-      // would otherwise leave it assuming mixed SMEM / LDS events and turn every later counted lgkmcnt into lgkmcnt(0))
-      __builtin_amdgcn_s_waitcnt(0xC07F);
-      if (!(ABL & 1)) pp_barrier();
-      sa_off = (sa_off == 2 * TILE2_BYTES) ? 0u : sa_off + TILE2_BYTES;
-      sb_off = (2 * PP_B_BASE + TILE2_BYTES) - sb_off;
-      if (t + 1 < nt) {
-        RR_LOADB(b0, 0);
-        RR_LOADA(a0, 0, 0);
-        RR_SB();
-        RR_MM(a1, b1, 3);   // the group held back across the barrier: covers the latency of the six reads just issued
-        RR_SB();           // (written out in both branches so that hipcc counts lgkmcnt(6) here instead of merging to lgkmcnt(0))
-      } else {
-        RR_MM(a1, b1, 3);
-        RR_SB();
-      }
-    }
-    GemmProblem g;
-    {
-      int mm, nn;
-      pick_tile<256>(ga, id, total, g, mm, nn);
-    }
-    const int epi = g.epi;
-    // the A slot consumed last (sa_off already points at the next one)
-    unsigned char* scr = smem + ((sa_off == 0) ? 2 * TILE2_BYTES : sa_off - TILE2_BYTES) + wid * 4096;
-    if (!B_KS) {
-      switch (epi) {
-        case 0: epilogue256<0, 8>(g, acc, m0, n0, wm, wn, lane, scr); break;
-        case EPI_BIAS: epilogue256<EPI_BIAS, 8>(g, acc, m0, n0, wm, wn, lane, scr); break;
-        case EPI_BIAS | EPI_GELU: epilogue256<(EPI_BIAS | EPI_GELU), 8>(g, acc, m0, n0, wm, wn, lane, scr); break;
-        case EPI_BIAS | EPI_GELU_FWD: epilogue256<(EPI_BIAS | EPI_GELU_FWD), 8>(g, acc, m0, n0, wm, wn, lane, scr); break;
-        case EPI_BIAS | EPI_ADD: epilogue256<(EPI_BIAS | EPI_ADD), 8>(g, acc, m0, n0, wm, wn, lane, scr); break;
-        case EPI_BIAS | EPI_ADD | EPI_DROP: epilogue256<(EPI_BIAS | EPI_ADD | EPI_DROP), 8>(g, acc, m0, n0, wm, wn, lane, scr); break;
-        default: epilogue256<-1, 8, true>(g, acc, m0, n0, wm, wn, lane, scr); break;
-      }
-    } else if (A_KS && epi == EPI_RMW32) {
-      epilogue256<EPI_RMW32, 8>(g, acc, m0, n0, wm, wn, lane, scr);
-    } else if (!A_KS && epi == EPI_ADD) {
-      epilogue256<EPI_ADD, 8>(g, acc, m0, n0, wm, wn, lane, scr);
-    } else if (!A_KS && epi == 0) {
-      epilogue256<0, 8>(g, acc, m0, n0, wm, wn, lane, scr);
-    } else {
-      epilogue256<-1, 8, true>(g, acc, m0, n0, wm, wn, lane, scr);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // scratch reads done before this wave's next DMA lands there
-    id += gstep;
-    if (id >= total) break;
-    lane_m = lane;
-    asm volatile("" : "+v"(lane_m));
-  }
-  G2_CLK(1)
-#undef RR_ALOAD
-#undef RR_BLOAD
-#undef RR_AADV
-#undef RR_BADV
-#undef RR_ABURST
-#undef RR_BBURST
-#undef RR_SB
-#undef RR_RD
-#undef RR_LOADB
-#undef RR_LOADA
-#undef RR_MM
-}
-
-template <bool A_KS, bool B_KS, int ABL = 0>
-static int launch256r(GroupArgs& ga, int flags, hipStream_t stream) {
-  static std::atomic<unsigned long long> attr_done{0};
-  const int r = kbner_set_max_lds_once(attr_done, reinterpret_cast<const void*>(gemm256r_kernel<A_KS, B_KS, ABL>), PP_LDS_BYTES);
-  if (r) return r;
-  ga.pad_ = flags;
-  const int grid = ga.total_tiles < ga.ncu ? ga.total_tiles : ga.ncu;
-  hipLaunchKernelGGL((gemm256r_kernel<A_KS, B_KS, ABL>), dim3(grid), dim3(512), PP_LDS_BYTES, stream, ga);
-  hipError_t e = hipGetLastError();
-  return e == hipSuccess ? 0 : -(int)e;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -1905,44 +1160,20 @@ __global__ __launch_bounds__(512, 2) void gemm256f_kernel(const GroupArgs ga) {
 }
 
 template <bool A_KS, bool B_KS, int ABL = 0>
-static int launch256f(GroupArgs& ga, int flags, hipStream_t stream) {
+static int launch256f(const GroupArgs& ga, hipStream_t stream) {
   static std::atomic<unsigned long long> attr_done{0};
   const int r = kbner_set_max_lds_once(attr_done, reinterpret_cast<const void*>(gemm256f_kernel<A_KS, B_KS, ABL>), PP_LDS_BYTES);
   if (r) return r;
-  ga.pad_ = flags;
   const int grid = ga.total_tiles < ga.ncu ? ga.total_tiles : ga.ncu;
   hipLaunchKernelGGL((gemm256f_kernel<A_KS, B_KS, ABL>), dim3(grid), dim3(512), PP_LDS_BYTES, stream, ga);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }
 
-// which main loop the 256-row static launches use: bit 0 = ping-pong (gemm256pp_kernel), bits 1.. = its PP_FLAG_* options.
-// Process-wide, atomic; set through kbner_gemm_set_variant (include/kbner.h).
+// which main loop the 256-row static launches use: 1 = the interleaved ring loop (gemm256f_kernel, default), 0 = the two-stage loop
+// of rounds 1-3 (gemm256_kernel; also what the 128-row and the dynamic-tile launches run).  Process-wide, atomic; set through
+// kbner_gemm_set_variant (include/kbner.h).  Trace builds (-DG2_TRACE) read compile-time ablations of the ring loop from bits 12-15.
 static std::atomic<int> g_gemm_variant{KBNER_GEMM_VARIANT_DEFAULT};
-
-template <bool A_KS, bool B_KS>
-static int launch256rot(GroupArgs& ga, int flags, hipStream_t stream) {
-  static std::atomic<unsigned long long> attr_done{0};
-  const int r = kbner_set_max_lds_once(attr_done, reinterpret_cast<const void*>(gemm256rot_kernel<A_KS, B_KS>), PP_LDS_BYTES);
-  if (r) return r;
-  ga.pad_ = flags;
-  const int grid = ga.total_tiles < ga.ncu ? ga.total_tiles : ga.ncu;
-  hipLaunchKernelGGL((gemm256rot_kernel<A_KS, B_KS>), dim3(grid), dim3(512), PP_LDS_BYTES, stream, ga);
-  hipError_t e = hipGetLastError();
-  return e == hipSuccess ? 0 : -(int)e;
-}
-
-template <bool A_KS, bool B_KS, int MODE>
-static int launch256pp(GroupArgs& ga, int flags, hipStream_t stream) {
-  static std::atomic<unsigned long long> attr_done{0};
-  const int r = kbner_set_max_lds_once(attr_done, reinterpret_cast<const void*>(gemm256pp_kernel<A_KS, B_KS, MODE>), PP_LDS_BYTES);
-  if (r) return r;
-  ga.pad_ = flags;
-  const int grid = ga.total_tiles < ga.ncu ? ga.total_tiles : ga.ncu;
-  hipLaunchKernelGGL((gemm256pp_kernel<A_KS, B_KS, MODE>), dim3(grid), dim3(512), PP_LDS_BYTES, stream, ga);
-  hipError_t e = hipGetLastError();
-  return e == hipSuccess ? 0 : -(int)e;
-}
 
 template <bool A_KS, bool B_KS, bool DYN, int TM = 256>
 static int launch256(const GroupArgs& ga, hipStream_t stream) {
@@ -2004,7 +1235,7 @@ static int gemm_grouped_impl(int layout, int nprob, const kbner_gemm_problem* pr
 static int pick_tile_rows(int layout, int nprob, const kbner_gemm_problem* probs, bool dyn);
 
 int kbner_gemm_set_variant(int variant) {
-  KBNER_CHECK_ARG(variant >= 0 && variant < 65536);
+  KBNER_CHECK_ARG(variant >= 0 && variant < 65536);   // (bits 12-15: trace-build ablations)
   g_gemm_variant.store(variant, std::memory_order_relaxed);
   return 0;
 }
@@ -2085,49 +1316,28 @@ static int gemm_grouped_impl(int layout, int nprob, const kbner_gemm_problem* pr
   if (TM == 128) return layout == 0 ? launch256<false, false, false, 128>(ga, st) : launch256<false, true, false, 128>(ga, st);
   const int variant = g_gemm_variant.load(std::memory_order_relaxed);
 #ifdef G2_TRACE
-  if ((variant & PP_FLAG_FINE) && layout == 2 && (variant & 0xF000)) {   // cycle-accounting ablations, TN: no DMA wait / no DMA
+  if ((variant & 1) && layout == 2 && (variant & 0xF000)) {   // cycle-accounting ablations, TN: no DMA wait / no DMA
     switch ((variant >> 12) & 15) {
-      case 4: return launch256f<true, true, 64>(ga, variant, st);
-      default: return launch256f<true, true, 8>(ga, variant, st);
+      case 4: return launch256f<true, true, 64>(ga, st);
+      default: return launch256f<true, true, 8>(ga, st);
     }
   }
-  if ((variant & PP_FLAG_FINE) && layout == 0 && (variant & 0xF000)) {   // cycle-accounting ablations, NT only
+  if ((variant & 1) && layout == 0 && (variant & 0xF000)) {   // cycle-accounting ablations, NT
     switch ((variant >> 12) & 15) {
-      case 1: return launch256f<false, false, 1>(ga, variant, st);
-      case 2: return launch256f<false, false, 16>(ga, variant, st);
-      case 3: return launch256f<false, false, 32>(ga, variant, st);
-      case 4: return launch256f<false, false, 64>(ga, variant, st);
-      case 8: return launch256f<false, false, 8>(ga, variant, st);
-      default: return launch256f<false, false, 9>(ga, variant, st);
+      case 1: return launch256f<false, false, 1>(ga, st);
+      case 2: return launch256f<false, false, 16>(ga, st);
+      case 3: return launch256f<false, false, 32>(ga, st);
+      case 4: return launch256f<false, false, 64>(ga, st);
+      case 8: return launch256f<false, false, 8>(ga, st);
+      default: return launch256f<false, false, 9>(ga, st);
     }
   }
 #endif
-  if (variant & PP_FLAG_FINE) {
-    switch (layout) {
-      case 0: return launch256f<false, false>(ga, variant, st);
-      case 1: return launch256f<false, true>(ga, variant, st);
-      default: return launch256f<true, true>(ga, variant, st);
-    }
-  }
-  if (variant & PP_FLAG_RING) {
-    switch (layout) {
-      case 0: return launch256r<false, false>(ga, variant, st);
-      case 1: return launch256r<false, true>(ga, variant, st);
-      default: return launch256r<true, true>(ga, variant, st);
-    }
-  }
-  if ((variant & 1) && (variant & PP_FLAG_ROT)) {
-    switch (layout) {
-      case 0: return launch256rot<false, false>(ga, variant, st);
-      case 1: return launch256rot<false, true>(ga, variant, st);
-      default: return launch256rot<true, true>(ga, variant, st);
-    }
-  }
   if (variant & 1) {
     switch (layout) {
-      case 0: return launch256pp<false, false, 0>(ga, variant, st);
-      case 1: return launch256pp<false, true, 0>(ga, variant, st);
-      default: return launch256pp<true, true, 0>(ga, variant, st);
+      case 0: return launch256f<false, false>(ga, st);
+      case 1: return launch256f<false, true>(ga, st);
+      default: return launch256f<true, true>(ga, st);
     }
   }
   switch (layout) {

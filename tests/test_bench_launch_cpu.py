@@ -1,0 +1,46 @@
+"""CPU: `python bench.py --gpus N` with no launcher in the environment starts N ranks itself (torch.distributed.run on 127.0.0.1,
+one process per GPU) -- VERDICT round 3, "the flag is a trap".  The ranks here only join a gloo group (--launch-check): no GPU."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _env():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    return env
+
+
+def test_gpus_flag_builds_the_torchrun_command():
+    env = _env()
+    env["KBNER_BENCH_LAUNCH_DRYRUN"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1"], env=env,
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    cmd = json.loads(out.stdout.strip().splitlines()[-1])["launch"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "8"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    tail = cmd[cmd.index(os.path.join(ROOT, "bench.py")) + 1:]
+    assert tail == ["--gpus", "8", "--steps", "3", "--warmup", "1"]
+
+
+def test_gpus_flag_without_launcher_runs_n_ranks_over_gloo():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], env=_env(),
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout          # rank 0 alone prints
+    d = json.loads(lines[0])
+    assert d == {"launch_check": True, "n_gpus": 2, "world": 2, "ranks_seen": 2}
+
+
+def test_with_world_size_in_the_environment_it_does_not_relaunch():
+    env = _env()
+    env.update({"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--launch-check"], env=env,
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert json.loads(out.stdout.strip().splitlines()[-1])["world"] == 1

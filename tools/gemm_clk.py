@@ -12,7 +12,7 @@ dev, BF = "cuda", torch.bfloat16
 lib = L.load()
 lib.kbner_debug_read_clk.argtypes = [ctypes.c_void_p]
 import os
-VARIANTS = [int(v) for v in os.environ.get("CLK_VARIANTS", "0,2048,2064").split(",")]
+VARIANTS = [int(v) for v in os.environ.get("CLK_VARIANTS", "0,1").split(",")]
 SHAPES = os.environ.get("CLK_SHAPES", "8192,8192,8192,random;8192,8192,8192,zeros")
 for (M, N, K, data) in [(int(x.split(",")[0]), int(x.split(",")[1]), int(x.split(",")[2]), x.split(",")[3]) for x in SHAPES.split(";")]:
     A = (torch.randn(M, K, device=dev) * 0.5).to(BF) if data == "random" else torch.zeros(M, K, device=dev, dtype=BF)
