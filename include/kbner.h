@@ -10,9 +10,10 @@
  *   - return 0 on success, -22 (EINVAL) on a bad argument, -(hipError_t) on a launch failure; never throw/exit
  *   - every pointer is a DEVICE pointer owned by the caller (torch) and kept alive until the stream drains
  *   - `stream` is a hipStream_t (NULL = default stream); work is enqueued asynchronously on it
- *   - no device allocation: callers pass workspaces.  The only mutable process state is a set of once-per-device flags (a
- *     kernel's dynamic-LDS limit has been raised on device d; the CU count of device d), kept in atomics: entry points may be
- *     called from several host threads and on several devices
+ *   - no device allocation: callers pass workspaces.  Mutable process state, all of it in atomics (entry points may be called
+ *     from several host threads and on several devices): once-per-device flags (a kernel's dynamic-LDS limit has been raised on
+ *     device d; the CU count of device d), the GEMM main-loop switch (kbner_gemm_set_variant) and the attention A/B switch read
+ *     once from the KBNER_ATTN environment variable (csrc/attention.hip; experiments only)
  *   - bf16 tensors are raw uint16_t storage, row-major; fp32 statistics / optimizer state / CRF
  */
 #ifndef KBNER_H
@@ -213,7 +214,7 @@ int kbner_gemm_bf16_grouped_dyn(int layout, int nprob, const kbner_gemm_problem*
  * slots, every fragment read / LDS-DMA piece / cursor operation between two MFMAs, last MFMA group held across the barrier),
  * 0 = the two-stage loop of rounds 1-3 (which the 128-row tiles and the dynamic-tile launches always run).  Bit-identical
  * outputs in both settings (same MFMA order per accumulator, same epilogue arithmetic).  kbner_gemm_get_variant returns the
- * current value.  This and the once-per-device flags are the library's only mutable process state. */
+ * current value. */
 int kbner_gemm_set_variant(int variant);
 int kbner_gemm_get_variant(void);
 /* Split-K for small micro-batches (a few dozen output tiles, long K): the K range is cut into `splits` problems of ONE grouped

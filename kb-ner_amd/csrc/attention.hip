@@ -1226,13 +1226,17 @@ int kbner_attn_fwd3(const bf16_t* qkv, const float* maskbias, bf16_t* ctx, float
 // KBNER_ATTN: 2 (default) = the round-2 kernels; 3 = the round-3 streaming forward (attention3.hip) where it applies, 4 = forced
 // (tests of small cases).  The streaming kernel is correct on every shape of tools/micro/attn_lab but not faster yet (282-300 us
 // against 270 us per B=128 forward in the lab), so it stays opt-in.
+// (an atomic: two host threads may make their first call at the same time; both then store the same value.  With
+// kbner_gemm_set_variant and the once-per-device flags this is all of the library's mutable process state.)
 static int attn_variant() {
-  static int v = -1;
-  if (v < 0) {
+  static std::atomic<int> v{-1};
+  int r = v.load(std::memory_order_relaxed);
+  if (r < 0) {
     const char* e = getenv("KBNER_ATTN");
-    v = e ? atoi(e) : 2;
+    r = e ? atoi(e) : 2;
+    v.store(r, std::memory_order_relaxed);
   }
-  return v;
+  return r;
 }
 
 extern "C" {

@@ -22,7 +22,7 @@ typedef uint16_t bf16_t;  // raw bfloat16 storage
 
 // One-off per-DEVICE host-side initialisation (a kernel's dynamic-LDS limit, a device's CU count): a bit per device ordinal in an
 // atomic mask, so a second device gets its own call and two host threads racing here both make the same idempotent call.  This
-// is the only mutable process state of the library (include/kbner.h, conventions).
+// is, with the two A/B switches listed there, the mutable process state of the library (include/kbner.h, conventions).
 #include <atomic>
 static inline int kbner_device_ordinal() {
   int dev = 0;

@@ -117,8 +117,17 @@ class ConfigParser:
             config = Params.from_file(self.config[self.target][corpus]["train_config"])
             teacher = self.create_model(config, pretrained=True)
             teacher.targets = {corpus}
+            self._as_frozen_teacher(teacher)
             teachers.append(teacher)
         return teachers
+
+    @staticmethod
+    def _as_frozen_teacher(teacher):
+        """a teacher only ever labels the training set (forward passes): its gradient buffer -- as large as its parameters -- is
+        given back at once (the reference moves its teachers to the CPU after labelling, finetune_trainer.py:633-636)"""
+        drop = getattr(teacher, "drop_gradients", None)
+        if drop is not None:
+            drop()
 
     def create_teachers_list(self, is_professor=False):
         """config_parser.py:255-274 (`is_teacher_list: true`): `<target>.teachers` maps a teacher's YAML to the ':'-joined corpora
@@ -133,6 +142,7 @@ class ConfigParser:
                 continue
             teacher = self.create_model(Params.from_file(filename), pretrained=True)
             teacher.targets = corpus_target
+            self._as_frozen_teacher(teacher)
             teachers.append(teacher)
         return teachers
 

@@ -177,6 +177,19 @@ class SequenceTagger(flair.nn.Model):
         self._emb.model.source = self.engine
         self._emb.model._state_dict = None  # the arena is the single owner of the weights now
 
+    def drop_gradients(self):
+        """forward-only from now on (teachers of a distillation run): the arena's gradient buffer and embedding-row flags are freed"""
+        eng = getattr(self, "engine", None)
+        if eng is not None and getattr(eng, "arena", None) is not None:
+            eng.arena.g = None
+            eng.arena.emb_flags = None
+
+    def release_device_memory(self):
+        """drop the engine (parameter arena, bf16 shadow, activation buffers): the tagger cannot run afterwards"""
+        self.engine = None
+        if getattr(self, "_emb", None) is not None and getattr(self._emb, "model", None) is not None:
+            self._emb.model.source = None
+
     # ------------------------------------------------------------------ config 5: frozen stack + BiLSTM (inference)
     def _build_stack(self):
         """BiLSTM(sum of embedding widths -> hidden_size, bidirectional) + linear(2 * hidden -> T) + transitions, initialised
@@ -565,14 +578,16 @@ class SequenceTagger(flair.nn.Model):
             return False
         return torch.from_numpy(tags)
 
-    def multi_view_plan(self, sentences):
+    def multi_view_plan(self, sentences, with_flag=False):
         """-> indices of the sentences that take part in the distillation term of this (micro-)batch: those with an `orig_sent`
-        whose own tags contain S-X (:2023); [] when check_multi_view is False (the batch is then a plain NLL batch)"""
+        whose own tags contain S-X (:2023); [] when check_multi_view is False (the batch is then a plain NLL batch).
+        with_flag: -> (is a multi-view batch, indices) from ONE walk over the batch's tags (the trainer's group weights need both)"""
         tags = self.check_multi_view(sentences)
         if tags is False:
-            return []
+            return (False, []) if with_flag else []
         x = self.tag_dictionary.get_idx_for_item("S-X")
-        return [b for b, s in enumerate(sentences) if hasattr(s, "orig_sent") and bool((tags[b, :len(s)] == x).any())]
+        sel = [b for b, s in enumerate(sentences) if hasattr(s, "orig_sent") and bool((tags[b, :len(s)] == x).any())]
+        return (True, sel) if with_flag else sel
 
     def touched_word_ids(self, sentences):
         """the word-embedding rows a list of sentences looks up (host integers): what the data-parallel gradient exchange
@@ -689,6 +704,7 @@ class SequenceTagger(flair.nn.Model):
         env["x_id"] = env["items"].index("S-X") if "S-X" in env["items"] else None
         env["unk_id"] = env["items"].index("<unk>") if "<unk>" in env["items"] else None
         t0 = time.time()
+        failure = None
         try:
             pending = None
             for index, batch in enumerate(data_loader):
@@ -703,6 +719,10 @@ class SequenceTagger(flair.nn.Model):
             if pending is not None:
                 eval_loss += self._eval_finish(pending[0], pending[1], env)
                 store_embeddings(pending[0], embeddings_storage_mode)
+        except BaseException as e:   # (also KeyboardInterrupt) a sharded evaluation must still reach the collective below, or the
+            if shard is None:        # other ranks block in it forever; the failure is re-raised -- on every rank -- after it
+                raise
+            failure = e
         finally:
             if outfile is not None:
                 outfile.close()
@@ -712,10 +732,15 @@ class SequenceTagger(flair.nn.Model):
             log.info("decode speed: %.2f sents/sec", rate)
         if shard is not None:
             from kbner import dp
-            parts = dp.all_gather_object((metric.counts(), eval_loss, batch_no))
+            parts = dp.all_gather_object((metric.counts(), eval_loss, batch_no, None if failure is None else repr(failure)))
+            if failure is not None:
+                raise failure
+            failed = [(r, p[3]) for r, p in enumerate(parts) if p[3] is not None]
+            if failed:
+                raise RuntimeError("evaluate(): rank(s) %s failed" % failed)
             metric = Metric("Evaluation")
             eval_loss, batch_no = 0.0, 0
-            for counts, loss_sum, nb in parts:   # rank order: the same sums on every rank
+            for counts, loss_sum, nb, _ in parts:   # rank order: the same sums on every rank
                 metric.merge_counts(counts)
                 eval_loss += loss_sum
                 batch_no += nb

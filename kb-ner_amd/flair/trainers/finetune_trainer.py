@@ -134,10 +134,9 @@ class ModelFinetuner:
         G = len(group)
         wts, idx, kw, base = [], [], [], 0
         for bt in group:
-            sel = self.model.multi_view_plan(bt) if multi_view_rate is not None else []
             # the reference scales the NLL whenever check_multi_view returns the tag tensor (finetune_trainer.py:909-914) -- some
             # sentence has an orig_sent AND an S-X tag occurs anywhere in the batch -- even if no single sentence has both
-            mv_batch = multi_view_rate is not None and self.model.check_multi_view(bt) is not False
+            mv_batch, sel = self.model.multi_view_plan(bt, with_flag=True) if multi_view_rate is not None else (False, [])
             f = (1.0 - multi_view_rate) if mv_batch else 1.0
             wts += [f / (G * len(bt))] * len(bt)
             if sel:
@@ -273,6 +272,12 @@ class ModelFinetuner:
             # finetune_trainer.py:597-636: every training sentence gets its teacher targets, then the teachers are released
             train_data = self.assign_pretrained_teacher_targets(train_sets, self.teachers, best_k=best_k,
                                                                 mini_batch_size=mini_batch_size)
+            # release the teachers: their engines' device arenas (fp32 parameters, bf16 shadow -- ~3.4 GB for an XLM-R-large-sized
+            # teacher) go back to the allocator once no reference is left (train.py drops its own list after building the trainer)
+            for t in self.teachers:
+                release = getattr(t, "release_device_memory", None)
+                if release is not None:
+                    release()
             self.teachers = []
             if torch.cuda.is_available():
                 torch.cuda.empty_cache()
@@ -370,7 +375,9 @@ class ModelFinetuner:
                 rem = len(mine) - n_full
                 losses, scaled, seen, micro = [], [], 0, 0   # scaled: loss / average_factor, what the reference accumulates
                 t_ep = t_log = time.time()
-                fuse = bool(fuse_accumulation) and accum > 1
+                # (teacher annealing gives every micro-batch its own interpolation, finetune_trainer.py:885: a fused group would train
+                # all of them with the last one's -- the group is then run micro-batch by micro-batch)
+                fuse = bool(fuse_accumulation) and accum > 1 and not (self.distill_mode and self.teacher_annealing)
                 group = []
                 for local_no, bi in enumerate(mine):
                     batch = loader[bi]
@@ -445,17 +452,20 @@ class ModelFinetuner:
                     f1s, dls = [], []
                     for name, dl in zip(getattr(self.corpus, "targets", ["dev"]), dev_loaders):
                         res, dl_loss = self.model.evaluate(dl, embeddings_storage_mode=embeddings_storage_mode, shard=shard)
-                        log.info("%s DEV : loss %.4f - f1 %.4f - macro %.4f", name, dl_loss, res.main_score, res.macro_score)
+                        if is_main:
+                            log.info("%s DEV : loss %.4f - f1 %.4f - macro %.4f", name, dl_loss, res.main_score, res.macro_score)
                         # dataset-level macro average over the dev sets, in PERCENT (:1108-1126)
                         f1s.append((res.macro_score if select_model_by_macro else res.main_score) * 100)
                         dls.append(dl_loss)
                     score = sum(f1s) / len(f1s)
-                    log.info("Dataset-Level Macro Average: %.2f\tDataset-Level Macro avg loss: %.2f", score, sum(dls) / len(dls))
+                    if is_main:
+                        log.info("Dataset-Level Macro Average: %.2f\tDataset-Level Macro avg loss: %.2f", score, sum(dls) / len(dls))
                     dev_score_history.append(score)
                     dev_loss_history.append(sum(dls) / len(dls))
                 for name, tl in zip(getattr(self.corpus, "targets", ["test"]), test_loaders):
                     res, tl_loss = self.model.evaluate(tl, embeddings_storage_mode=embeddings_storage_mode, shard=shard)
-                    log.info("%s TEST: loss %.4f - f1 %.4f", name, tl_loss, res.main_score)
+                    if is_main:
+                        log.info("%s TEST: loss %.4f - f1 %.4f", name, tl_loss, res.main_score)
                 if is_main:
                     with open(loss_txt, "a") as f:
                         f.write("%d\t%s\t%.3e\t%.6f\t%s\t%s\t_\n" % (epoch + 1, time.strftime("%H:%M:%S"), learning_rate * opt.lr_lambda(),

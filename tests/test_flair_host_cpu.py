@@ -298,8 +298,11 @@ def test_multi_view_pairing_and_weights_host_logic():
     class Model:
         multi_view_training = True
 
-        def multi_view_plan(self, batch):   # paired sentences that have context
-            return [i for i, s in enumerate(batch) if hasattr(s, "orig_sent") and not getattr(s, "no_x", False)]
+        def multi_view_plan(self, batch, with_flag=False):   # paired sentences that have context (+ the batch-level rule, one walk)
+            sel = [i for i, s in enumerate(batch) if hasattr(s, "orig_sent") and not getattr(s, "no_x", False)]
+            if self.check_multi_view(batch) is False:
+                sel = []
+            return (self.check_multi_view(batch) is not False, sel) if with_flag else sel
 
         def check_multi_view(self, batch):  # reference rule: some sentence is paired AND some S-X tag occurs in the batch
             if not any(hasattr(s, "orig_sent") for s in batch):

@@ -74,6 +74,7 @@ def main():
         # train.py:98-127 of the reference: `is_teacher_list: true` -> <target>.teachers, else one teacher per corpus
         teachers = cp.create_teachers_list() if cp.config.get("is_teacher_list") else cp.create_teachers()
         trainer = flair.trainers.ModelFinetuner(student, teachers, corpus, config=cp.config, professors=[], **tcfg)
+        del teachers   # the trainer holds the only reference: it drops the teachers (and their device arenas) once the targets exist
     else:
         if inference:
             tcfg["distill_mode"] = False     # no teachers are built for --test / --parse (train.py:122-123)
