@@ -224,13 +224,18 @@ int kbner_splitk_finish(const float* ws, int splits, const float* bias, const kb
                         int M, int N, uint32_t drop_seed, uint32_t drop_thresh, void* stream);
 
 /* ---------------- fused self-attention (transformers BertSelfAttention), head_dim 64, S<=512 ---------------- */
-/* drop_*: attention-probability dropout, element (i,j) = (bh*S + query, bh*S + key) with bh = b*A + head */
-int kbner_attn_fwd(const kbner_bf16* qkv, const float* maskbias, kbner_bf16* ctx, float* lse, int B, int S, int H, int A,
-                   uint32_t drop_seed, uint32_t drop_thresh, void* stream);
+/* drop_*: attention-probability dropout, element (i,j) = (bh*S + query, bh*S + key) with bh = b*A + head.
+ * ctx_lo (nullable), B*S*H bytes: the forward also stores the rounding residual O - bf16(O), one e5m2 byte per element in a
+ * layout private to the two calls, and the backward, given the same buffer, takes the softmax-backward correction
+ * D = rowdot(dO, O) from bf16 O + residual instead of the bf16 O alone.  Where the value rows of a head are nearly parallel,
+ * dS = P (dP - D) cancels and the 2^-9 rounding of O is amplified (16 % of a query.weight gradient at L = 24 on random
+ * weights; 2.6 % with the residual: DESIGN.md section 3). */
+int kbner_attn_fwd(const kbner_bf16* qkv, const float* maskbias, kbner_bf16* ctx, uint8_t* ctx_lo, float* lse, int B, int S, int H,
+                   int A, uint32_t drop_seed, uint32_t drop_thresh, void* stream);
 /* dbias_qkv f32[3H] (nullable): += column sums of dqkv, i.e. the fused QKV projection's bias gradient */
-int kbner_attn_bwd(const kbner_bf16* qkv, const kbner_bf16* ctx, const kbner_bf16* dctx, const float* maskbias,
-                   const float* lse, float* Dws, kbner_bf16* dqkv, int B, int S, int H, int A, uint32_t drop_seed,
-                   uint32_t drop_thresh, float* dbias_qkv, void* stream);
+int kbner_attn_bwd(const kbner_bf16* qkv, const kbner_bf16* ctx, const uint8_t* ctx_lo, const kbner_bf16* dctx,
+                   const float* maskbias, const float* lse, float* Dws, kbner_bf16* dqkv, int B, int S, int H, int A,
+                   uint32_t drop_seed, uint32_t drop_thresh, float* dbias_qkv, void* stream);
 
 /* ---------------- LSTM recurrence (inference): BiLSTM tagger head + FlairEmbeddings character LMs ---------------- */
 /* One time step of torch.nn.LSTM's recurrent half for a whole batch and `ndir` directions / models

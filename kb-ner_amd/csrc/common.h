@@ -202,6 +202,17 @@ static __device__ __forceinline__ f2v unpack2bf(uint32_t w) {
   return (f2v){__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)};
 }
 
+// bf16 pair; what the rounding dropped goes, scaled by 2^14, into one half (hi_half) of `res` as two e5m2 bytes
+// (v_cvt_pk_bf8_f32, round to nearest even; OCP e5m2 on gfx950)
+#define KBNER_RES8_SCALE 16384.0f
+static __device__ __forceinline__ uint32_t pack2bf_res8(float lo, float hi, uint32_t& res, bool hi_half) {
+  const uint32_t w = pack2bf(lo, hi);
+  const f2v r = unpack2bf(w);
+  res = hi_half ? (uint32_t)__builtin_amdgcn_cvt_pk_bf8_f32((lo - r[0]) * KBNER_RES8_SCALE, (hi - r[1]) * KBNER_RES8_SCALE, (int)res, true)
+                : (uint32_t)__builtin_amdgcn_cvt_pk_bf8_f32((lo - r[0]) * KBNER_RES8_SCALE, (hi - r[1]) * KBNER_RES8_SCALE, 0, false);
+  return w;
+}
+
 static __device__ __forceinline__ float gelu_f(float x) {
   float cdf, e;
   gelu_parts(x, cdf, e);

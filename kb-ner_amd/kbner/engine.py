@@ -12,6 +12,8 @@ Data layout in HBM (sized for 288 GB: everything stays resident, nothing is reco
 """
 import math
 
+import os
+
 import torch
 
 from . import lib as L_
@@ -189,6 +191,7 @@ class _Acts:
         self.x = [z(Mp, H) for _ in range(L + 1)]
         self.qkv = [z(Mp, 3 * H) for _ in range(L)]
         self.ctx = [z(Mp, H) for _ in range(L)]
+        self.ctx_lo = [None] * L   # O - bf16(O) in bytes, allocated by the first training forward (Engine.ATTN_RESIDUAL)
         self.lse = [z(B, A, S, dt=F32) for _ in range(L)]
         self.h1 = [z(Mp, H) for _ in range(L)]
         self.x1 = [z(Mp, H) for _ in range(L)]
@@ -330,6 +333,9 @@ class Tagger:
         if self.arena.offsets[name] < self.arena.n_shadow:
             self.arena.refresh_shadow()
 
+    # the attention forward also keeps O - bf16(O) (one byte per element and layer) and the backward takes its softmax
+    # correction D from the pair: include/kbner.h kbner_attn_bwd.  KBNER_ATTN_RESIDUAL=0: D from the bf16 O alone (round 3).
+    ATTN_RESIDUAL = os.environ.get("KBNER_ATTN_RESIDUAL", "1") != "0"
     ACTS_BUDGET_BYTES = 120 << 30  # resident activation sets (one per (B, S) shape), least-recently-used first out
 
     def acts(self, B, S):
@@ -340,9 +346,9 @@ class Tagger:
             self._acts[key] = self._acts.pop(key)  # move to the most-recent end
             return self._acts[key]
         cfg = self.cfg
-        per_row = 2 * (cfg.num_hidden_layers * (8 * cfg.hidden_size + 2 * cfg.intermediate_size) + 16 * cfg.hidden_size
+        per_row = 2 * (cfg.num_hidden_layers * (8.5 * cfg.hidden_size + 2 * cfg.intermediate_size) + 16 * cfg.hidden_size
                        + 4 * cfg.intermediate_size)
-        need = _round_up(B * S, 256) * per_row
+        need = int(_round_up(B * S, 256) * per_row)
         while self._acts and sum(a.nbytes for a in self._acts.values()) + need > self.ACTS_BUDGET_BYTES:
             self._acts.pop(next(iter(self._acts)))
         ac = _Acts(self.cfg, B, S, self.device)
@@ -389,7 +395,10 @@ class Tagger:
             x = ac.x[l]
             d_att, d_o, d_f = d_layers[l]
             ops.gemm(GEMM_NT, x, a.bf(p + "qkv.weight"), Mp, 3 * H, H, C=ac.qkv[l], bias=a.param(p + "qkv.bias"), epi=EPI_BIAS, occupancy=True)
-            ops.attn_fwd(ac.qkv[l], maskbias, ac.ctx[l], ac.lse[l], B, S, H, A, drop=d_att)
+            if need_grad and self.ATTN_RESIDUAL and ac.ctx_lo[l] is None:
+                ac.ctx_lo[l] = torch.empty((Mp * H,), dtype=torch.uint8, device=self.device)   # what the backward reads is written
+            ops.attn_fwd(ac.qkv[l], maskbias, ac.ctx[l], ac.lse[l], B, S, H, A, drop=d_att,
+                         ctx_lo=ac.ctx_lo[l] if need_grad and self.ATTN_RESIDUAL else None)
             ops.gemm(GEMM_NT, ac.ctx[l], a.bf(p + "o.weight"), Mp, H, H, C=ac.h1[l], bias=a.param(p + "o.bias"), addend=x,
                      epi=EPI_BIAS | EPI_ADD, drop=d_o, occupancy=True)
             ops.ln_fwd(ac.h1[l], a.param(p + "ln1.g"), a.param(p + "ln1.b"), eps, ac.x1[l], ac.st1[l][0], ac.st1[l][1])
@@ -456,7 +465,7 @@ class Tagger:
             ops.gemm(GEMM_NN, dh1m, a.bf(p + "o.weight"), Mp, H, H, C=ac.dctx, occupancy=True)
             # attention core (+ d qkv.bias = column sums of dqkv, accumulated inside the kernels)
             ops.attn_bwd(ac.qkv[l], ac.ctx[l], ac.dctx, maskbias, ac.lse[l], ac.dws, dqkv, B, S, H, A, drop=d_att,
-                         dbias=a.grad(p + "qkv.bias"))
+                         dbias=a.grad(p + "qkv.bias"), ctx_lo=ac.ctx_lo[l] if self.ATTN_RESIDUAL else None)
             # QKV projection
             self._long_k_gemm(GEMM_NN, dqkv, a.bf(p + "qkv.weight"), Mp, H, 3 * H, ac.dx, ac, addend=dh1)
             # weight gradients dW += dY^T X are deferred and launched for WGRAD_GROUP layers at once

@@ -57,8 +57,8 @@ SIGNATURES = {
     "kbner_gemm_set_variant": (c_int, [c_int]),
     "kbner_gemm_get_variant": (c_int, []),
     "kbner_splitk_finish": (c_int, [P, c_int, P, P, c_int, P, c_int, c_int, c_int, U32, U32, P]),
-    "kbner_attn_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, U32, U32, P]),
-    "kbner_attn_bwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, U32, U32, P, P]),
+    "kbner_attn_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, U32, U32, P]),
+    "kbner_attn_bwd": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, U32, U32, P, P]),
     "kbner_lstm_step": (c_int, [P, c_int, P, P, P, P, P, P, c_int, c_int, P, c_int, c_int, c_int, P]),
     "kbner_lstm_seq": (c_int, [P, c_int, P, P, P, P, P, c_int, P, P, c_int, c_int, c_int, c_int, P]),
     "kbner_sqnorm_ws_floats": (c_int, []),

@@ -436,13 +436,14 @@ def gemm_splitk(layout, A, B, M, N, K, splits, ws, C, bias=None, addend=None, dr
 
 
 # ---------------------------------------------------------------- attention
-def attn_fwd(qkv, maskbias, ctx, lse, B, S, H, A, drop=NO_DROP):
-    L.call("kbner_attn_fwd", ptr(qkv), ptr(maskbias), ptr(ctx), ptr(lse), B, S, H, A, drop[0], drop[1], stream_ptr())
+def attn_fwd(qkv, maskbias, ctx, lse, B, S, H, A, drop=NO_DROP, ctx_lo=None):
+    """ctx_lo uint8 [B*S*H] (optional): receives the residual O - bf16(O) for attn_bwd's D (include/kbner.h)"""
+    L.call("kbner_attn_fwd", ptr(qkv), ptr(maskbias), ptr(ctx), ptr(ctx_lo), ptr(lse), B, S, H, A, drop[0], drop[1], stream_ptr())
 
 
-def attn_bwd(qkv, ctx, dctx, maskbias, lse, dws, dqkv, B, S, H, A, drop=NO_DROP, dbias=None):
+def attn_bwd(qkv, ctx, dctx, maskbias, lse, dws, dqkv, B, S, H, A, drop=NO_DROP, dbias=None, ctx_lo=None):
     """dbias f32[3H] (optional): accumulates the column sums of dqkv (= d qkv.bias) inside the kernels"""
-    L.call("kbner_attn_bwd", ptr(qkv), ptr(ctx), ptr(dctx), ptr(maskbias), ptr(lse), ptr(dws), ptr(dqkv), B, S, H, A,
+    L.call("kbner_attn_bwd", ptr(qkv), ptr(ctx), ptr(ctx_lo), ptr(dctx), ptr(maskbias), ptr(lse), ptr(dws), ptr(dqkv), B, S, H, A,
            drop[0], drop[1], ptr(dbias), stream_ptr())
 
 

@@ -103,7 +103,66 @@ def position_ids_from_input_ids(input_ids, pad_id):
     return torch.cumsum(m, dim=1) * m + pad_id
 
 
-def encoder_forward(params, cfg, input_ids, attention_mask, return_all=False, masks=None):
+class _RoundBf16(torch.autograd.Function):
+    """value AND the gradient flowing back through it rounded to bfloat16 (round-to-nearest-even): a tensor the HIP path keeps
+    in bf16 in both directions (activation forward, its dY backward)"""
+
+    @staticmethod
+    def forward(ctx, t):
+        return t.to(torch.bfloat16).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(torch.float32)
+
+
+def round_bf16(t):
+    return _RoundBf16.apply(t)
+
+
+def round_bf16_weight(w):
+    """the bf16 shadow of an fp32 master weight: rounded value forward, fp32 gradient (straight through) backward"""
+    return w + (w.to(torch.bfloat16).to(torch.float32) - w).detach()
+
+
+class _AttnCoreFlash(torch.autograd.Function):
+    """softmax(Q K^T / sqrt(d) + ext) (* dropout multiplier) . V with the BACKWARD the HIP kernels run (csrc/attention.hip
+    attn_bwd_dq2 / attn_bwd_dkv2, the FlashAttention-2 recomputation): P recomputed in fp32, the softmax-backward correction
+    taken as D = rowdot(dO, O) from the STORED bf16 O (instead of sum_j P dP), dS and P rounded to bf16 for the dQ / dK / dV
+    products.  o_split: how O is stored for D -- False = bf16 (round 3), True = bf16 + the e5m2 byte of the residual * 2^14
+    (round 4, kbner_attn_fwd's ctx_lo)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, ext, mult, o_split):
+        d = q.shape[-1]
+        p = torch.softmax(torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(d) + ext, dim=-1)
+        pm = p if mult is None else p * mult
+        pb = pm.to(torch.bfloat16).to(torch.float32)
+        o = torch.matmul(pb, v)
+        ctx.save_for_backward(q, k, v, p, pb, o, mult if mult is not None else torch.tensor(0.0))
+        ctx.has_mult, ctx.o_split = mult is not None, o_split
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, p, pb, o, mult = ctx.saved_tensors
+        d = q.shape[-1]
+        rb = lambda t: t.to(torch.bfloat16).to(torch.float32)   # noqa: E731
+        o_st = rb(o)
+        if ctx.o_split:
+            o_st = o_st + ((o - o_st) * 16384.0).to(torch.float8_e5m2).to(torch.float32) / 16384.0
+        dd = (do * o_st).sum(-1, keepdim=True)
+        dp = torch.matmul(do, v.transpose(-1, -2))
+        if ctx.has_mult:
+            dp = dp * mult
+        ds = rb(p * (dp - dd))
+        dq = torch.matmul(ds, k) / math.sqrt(d)
+        dk = torch.matmul(ds.transpose(-1, -2), q) / math.sqrt(d)
+        dv = torch.matmul(pb.transpose(-1, -2), do)
+        return dq, dk, dv, None, None, None
+
+
+def encoder_forward(params, cfg, input_ids, attention_mask, return_all=False, masks=None, bf16_points=False):
     """input_ids int64[B,S], attention_mask {0,1}[B,S] -> last hidden state f32[B,S,H]
     (== hidden_states[-1], the only layer the path uses: `layers: '-1'`).
 
@@ -113,6 +172,12 @@ def encoder_forward(params, cfg, input_ids, attention_mask, return_all=False, ma
     HIP kernels regenerate from their seeds: "emb" [B,S,H], ("attn", i) [B,A,S,S], ("o", i) / ("ffn", i) [B,S,H]."""
     masks = masks or {}
     mul = lambda t, key: t * masks[key] if key in masks else t  # noqa: E731
+    # bf16_points (tests/selftest.py check_step(bf16_oracle=True): attribution of the HIP path's gradient error): round to bf16
+    # wherever the HIP path stores bf16 -- GEMM weights (shadow), every activation tensor between kernels (and, through autograd,
+    # the gradient that comes back through it), the attention probabilities fed to P.V -- and nowhere else (fp32 accumulation,
+    # fp32 LayerNorm statistics, fp32 softmax as in the kernels)
+    r = round_bf16 if bf16_points else (lambda t: t)
+    rw = round_bf16_weight if bf16_points else (lambda w: w)
     H, A = cfg.hidden_size, cfg.num_attention_heads
     d = H // A
     B, S = input_ids.shape
@@ -122,26 +187,30 @@ def encoder_forward(params, cfg, input_ids, attention_mask, return_all=False, ma
          + params["embeddings.position_embeddings.weight"][pos]
          + params["embeddings.token_type_embeddings.weight"][0])
     x = F.layer_norm(x, (H,), params["embeddings.LayerNorm.weight"], params["embeddings.LayerNorm.bias"], eps)
-    x = mul(x, "emb")
+    x = r(mul(x, "emb"))
     ext = (1.0 - attention_mask.to(x.dtype))[:, None, None, :] * -10000.0
     hs = [x]
     for i in range(cfg.num_hidden_layers):
         p = "encoder.layer.%d." % i
-        q = F.linear(x, params[p + "attention.self.query.weight"], params[p + "attention.self.query.bias"])
-        k = F.linear(x, params[p + "attention.self.key.weight"], params[p + "attention.self.key.bias"])
-        v = F.linear(x, params[p + "attention.self.value.weight"], params[p + "attention.self.value.bias"])
+        q = r(F.linear(x, rw(params[p + "attention.self.query.weight"]), params[p + "attention.self.query.bias"]))
+        k = r(F.linear(x, rw(params[p + "attention.self.key.weight"]), params[p + "attention.self.key.bias"]))
+        v = r(F.linear(x, rw(params[p + "attention.self.value.weight"]), params[p + "attention.self.value.bias"]))
         q = q.view(B, S, A, d).transpose(1, 2)
         k = k.view(B, S, A, d).transpose(1, 2)
         v = v.view(B, S, A, d).transpose(1, 2)
-        sc = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(d) + ext
-        pr = mul(torch.softmax(sc, dim=-1), ("attn", i))
-        c = torch.matmul(pr, v).transpose(1, 2).reshape(B, S, H)
-        o = mul(F.linear(c, params[p + "attention.output.dense.weight"], params[p + "attention.output.dense.bias"]), ("o", i))
-        x = F.layer_norm(o + x, (H,), params[p + "attention.output.LayerNorm.weight"],
-                         params[p + "attention.output.LayerNorm.bias"], eps)
-        h = F.gelu(F.linear(x, params[p + "intermediate.dense.weight"], params[p + "intermediate.dense.bias"]))
-        o = mul(F.linear(h, params[p + "output.dense.weight"], params[p + "output.dense.bias"]), ("ffn", i))
-        x = F.layer_norm(o + x, (H,), params[p + "output.LayerNorm.weight"], params[p + "output.LayerNorm.bias"], eps)
+        if bf16_points in ("flash", "flash_split"):    # + the backward formulas of the attention kernels (see _AttnCoreFlash)
+            c = _AttnCoreFlash.apply(q, k, v, ext, masks.get(("attn", i)), bf16_points == "flash_split")
+            c = r(c.transpose(1, 2).reshape(B, S, H))
+        else:
+            sc = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(d) + ext
+            pr = r(mul(torch.softmax(sc, dim=-1), ("attn", i)))
+            c = r(torch.matmul(pr, v).transpose(1, 2).reshape(B, S, H))
+        o = mul(F.linear(c, rw(params[p + "attention.output.dense.weight"]), params[p + "attention.output.dense.bias"]), ("o", i))
+        x = r(F.layer_norm(r(o + x), (H,), params[p + "attention.output.LayerNorm.weight"],
+                           params[p + "attention.output.LayerNorm.bias"], eps))
+        h = r(F.gelu(r(F.linear(x, rw(params[p + "intermediate.dense.weight"]), params[p + "intermediate.dense.bias"]))))
+        o = mul(F.linear(h, rw(params[p + "output.dense.weight"]), params[p + "output.dense.bias"]), ("ffn", i))
+        x = r(F.layer_norm(r(o + x), (H,), params[p + "output.LayerNorm.weight"], params[p + "output.LayerNorm.bias"], eps))
         hs.append(x)
     if return_all:
         return x, hs

@@ -43,13 +43,15 @@ def crf_nll_torch(feats, tags, lens, trans, start, stop):
     return logz - (ts + emis)
 
 
-def tagger_forward_loss(params, cfg, batch, start, stop, x_idx, masks=None, word_keep=None):
+def tagger_forward_loss(params, cfg, batch, start, stop, x_idx, masks=None, word_keep=None, bf16_points=False):
     """batch: dict(input_ids[B,S], attention_mask[B,S], first_idx[B,n], tags[B,n], lengths[B]).
     params additionally holds 'linear.weight' [T,H], 'linear.bias' [T], 'transitions' [T,T].
     masks: explicit encoder dropout multipliers (encoder_forward); word_keep: bool[n], flair.nn.WordDropout's per-POSITION
     mask (flair/nn.py:176-183: one Bernoulli per token position shared by the whole batch, no rescale)."""
-    hidden = enc.encoder_forward(params, cfg, batch["input_ids"], batch["attention_mask"], masks=masks)
+    hidden = enc.encoder_forward(params, cfg, batch["input_ids"], batch["attention_mask"], masks=masks, bf16_points=bf16_points)
     pooled = enc.gather_first_subtoken(hidden, batch["first_idx"], batch.get("first_row"))
+    if bf16_points:   # the pooled rows are a bf16 tensor on the HIP path; the head runs in fp32
+        pooled = enc.round_bf16(pooled)
     if word_keep is not None:
         pooled = pooled * word_keep.to(pooled.dtype)[None, :, None]
     emis = F.linear(pooled, params["linear.weight"], params["linear.bias"])

@@ -167,10 +167,17 @@ def attn_reference(qkv, maskbias, B, S, H, A, dctx=None, pmask=None):
     return ctx.detach(), lse.detach(), x.grad
 
 
-def check_attention(B, S, A, seed=0, ragged=True, drop_p=0.0):
+def check_attention(B, S, A, seed=0, ragged=True, drop_p=0.0, residual=False, collapse=0.0):
+    """residual: the forward also stores O - bf16(O) and the backward takes D from the pair (include/kbner.h kbner_attn_bwd).
+    collapse > 0: the K and V rows of a head are one common row + collapse * noise (what deep layers of a freshly initialised
+    encoder look like): dS = P (dP - D) cancels and the rounding of a bf16 O is amplified into dQ."""
     H = A * 64
     g = torch.Generator(device="cpu").manual_seed(seed)
-    qkv = (torch.randn(B * S, 3 * H, generator=g)).to(BF16)
+    qkv = torch.randn(B * S, 3 * H, generator=g)
+    if collapse:
+        common = torch.randn(1, 2 * H, generator=g)
+        qkv[:, H:] = common + collapse * qkv[:, H:]
+    qkv = qkv.to(BF16)
     dctx = (torch.randn(B * S, H, generator=g)).to(BF16)
     am = torch.ones(B, S)
     if ragged:
@@ -183,11 +190,12 @@ def check_attention(B, S, A, seed=0, ragged=True, drop_p=0.0):
     qd, dd, mbd = qkv.to(DEV), dctx.to(DEV), mb.to(DEV)
     ctx = torch.zeros(B * S, H, dtype=BF16, device=DEV)
     lse = torch.zeros(B, A, S, dtype=F32, device=DEV)
-    ops.attn_fwd(qd, mbd, ctx, lse, B, S, H, A, drop=drop)
+    ctx_lo = torch.zeros(B * S * H, dtype=torch.uint8, device=DEV) if residual else None
+    ops.attn_fwd(qd, mbd, ctx, lse, B, S, H, A, drop=drop, ctx_lo=ctx_lo)
     dws = torch.zeros(B, A, S, dtype=F32, device=DEV)
     dqkv = torch.zeros(B * S, 3 * H, dtype=BF16, device=DEV)
     dbias = torch.zeros(3 * H, dtype=F32, device=DEV)
-    ops.attn_bwd(qd, ctx, dd, mbd, lse, dws, dqkv, B, S, H, A, drop=drop, dbias=dbias)
+    ops.attn_bwd(qd, ctx, dd, mbd, lse, dws, dqkv, B, S, H, A, drop=drop, dbias=dbias, ctx_lo=ctx_lo)
     torch.cuda.synchronize()
     dq = dqkv.cpu().float()
     bias_ref = dqkv_ref.sum(0)
@@ -356,9 +364,13 @@ def check_dropout_mask(p=0.1, Z=3, M=512, N=512, seed=12345):
             "adj_row_corr": corr(keep[:, 1:], keep[:, :-1]), "adj_col_corr": corr(keep[:, :, 1:], keep[:, :, :-1])}
 
 
-def check_step(dropout=False, H=128, A=2, F_=256, L=2, S=64, V=512, std=0.08):
+def check_step(dropout=False, H=128, A=2, F_=256, L=2, S=64, V=512, std=0.08, bf16_oracle=False):
     """One micro-batch fwd+bwd on the HIP path vs the oracle's autograd (fp32 CPU).  dropout=True: training mode with
-    p=0.1 at every encoder site + WordDropout 0.1; the oracle is fed the very masks the kernels generated."""
+    p=0.1 at every encoder site + WordDropout 0.1; the oracle is fed the very masks the kernels generated.
+    bf16_oracle=True (attribution of the gradient error): a SECOND oracle pass rounds to bf16 at the
+    points where the HIP path stores bf16 (oracle/encoder.py bf16_points); the result then also carries, per gradient tensor,
+    HIP vs that rounded oracle and rounded oracle vs fp32 oracle -- if the kernels are right, the first is small and the second
+    reproduces the HIP-vs-fp32 distance."""
     from oracle import encoder as oenc
     from oracle import train_step as ots
     cfg, tg, b, (start, stop, x_idx) = tiny_setup(H=H, A=A, F_=F_, L=L, S=S, V=V, std=std)
@@ -418,6 +430,34 @@ def check_step(dropout=False, H=128, A=2, F_=256, L=2, S=64, V=512, std=0.08):
     res["grad_worst_rel"], res["grad_worst_name"], res["grad_min_cos"] = worst, worst_name, coss
     for k in ("linear.weight", "linear.bias", "transitions"):
         res["grad_" + k] = rel_l2(tg.arena.grad(k).cpu(), params[k].grad)
+    # bf16_oracle: True = one pass with bf16_points=True; a tuple of modes (True | "flash" | "flash_split") = one pass each
+    for mode in ((bf16_oracle if isinstance(bf16_oracle, (tuple, list)) else (bf16_oracle,)) if bf16_oracle else ()):
+        tag = "bf16_oracle" if mode is True else "%s_oracle" % mode
+        p16 = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
+        l16, _ = ots.tagger_forward_loss(p16, ocfg, ob, start, stop, x_idx, masks=masks, word_keep=word_keep, bf16_points=mode)
+        l16.backward()
+        res["loss_rel_vs_" + tag] = abs(float(loss) - float(l16.detach())) / abs(float(l16.detach()))
+        t16, w_hip, w_rnd, per_layer = [], (0.0, "", 1.0), (0.0, "", 1.0), {}
+        for hf, (mine, sl) in nm.items():
+            go, g16 = params[hf].grad, p16[hf].grad
+            if go is None or g16 is None or hf.endswith("key.bias") or float(go.abs().max()) < 1e-7 * gscale:
+                continue
+            gh = tg.arena.grad(mine)
+            gh = (gh[sl[0]:sl[1]] if sl is not None else gh).cpu()
+            e_h16, c_h16 = rel_l2(gh, g16), cosine(gh, g16)          # HIP vs the rounding oracle
+            e_16o, c_16o = rel_l2(g16, go), cosine(g16, go)          # what the rounding alone does to the fp32 gradient
+            t16.append((e_h16, c_h16, e_16o, c_16o, hf))
+            if e_h16 > w_hip[0]:
+                w_hip = (e_h16, hf, c_h16)
+            if e_16o > w_rnd[0]:
+                w_rnd = (e_16o, hf, c_16o)
+            if hf.endswith("attention.self.query.weight"):
+                per_layer[int(hf.split(".")[2])] = (round(rel_l2(gh, go), 4), round(e_h16, 4), round(e_16o, 4))
+        res["grad_worst_rel_vs_" + tag], res["grad_worst_name_vs_" + tag], res["grad_cos_vs_" + tag] = w_hip
+        res["grad_min_cos_vs_" + tag] = min(t[1] for t in t16)
+        res[tag + "_vs_fp32_worst_rel"], res[tag + "_vs_fp32_worst_name"], _ = w_rnd
+        # per layer, query.weight: (HIP vs fp32 oracle, HIP vs this oracle, this oracle vs fp32 oracle) relative L2
+        res["query_weight_rel_by_layer_" + tag] = [per_layer[k] for k in sorted(per_layer)]
     # Viterbi on the HIP emissions == oracle Viterbi on the SAME emissions (bit-exact indices)
     from oracle import crf as ocrf
     lens = torch.from_numpy(b["lengths"]).to(DEV)

@@ -236,14 +236,23 @@ def test_full_size_step_vs_oracle():
     """BASELINE size for real: XLM-R-large dimensions (L24/H1024/A16/F4096, V=250002), two ragged 512-token sentences, one
     forward + backward on the HIP path vs the oracle's fp32 autograd on the host CPU (~1 min)."""
     import selftest as st
-    r = st.check_step(H=1024, A=16, F_=4096, L=24, S=512, V=250002, std=0.02)
-    # thresholds = 3x the observed error (round 3, identical on two boxes and on the round-2 tree: loss 4.0e-4, emissions 1.22e-2;
-    # worst gradient cosine 0.9826 / rel 0.188 on encoder.layer.23.attention.self.query.weight)
+    r = st.check_step(H=1024, A=16, F_=4096, L=24, S=512, V=250002, std=0.02, bf16_oracle=(True, "flash"))
+    print("full-size step:", {k: v for k, v in r.items() if k != "grad_table_top"})
+    # Round 3 measured loss 4.0e-4, emissions 1.22e-2 and a worst gradient of cosine 0.9826 / rel 0.16-0.19 (layer 23's
+    # query.weight, growing with depth from 0.013 at layer 0).  Round 4 attributed it with two more oracle passes:
+    #   * bf16_points=True rounds to bf16 wherever the HIP path stores bf16 -- and stays at 0.026 from the fp32 oracle: storage
+    #     rounding is NOT the cause;
+    #   * bf16_points="flash" additionally runs the attention backward the way the kernels do (D = rowdot(dO, bf16 O)) -- and
+    #     lands at 0.17 from the fp32 oracle with the same growth over the layers: the cause is the cancellation in
+    #     dS = P (dP - D) on nearly parallel value rows, which amplifies the rounding of O (include/kbner.h kbner_attn_bwd).
+    # The forward now keeps the residual of O in one byte per element and the HIP gradient is at 0.026 / cosine 0.9997 from the
+    # fp32 oracle, which is the distance of the storage-rounding oracle itself.  Thresholds: 3x the observed values.
     assert r["loss_rel"] < 1.2e-3, r
     assert r["emissions_rel"] < 3.7e-2, r
-    assert r["grad_min_cos"] > 0.98 and r["grad_worst_rel"] < 0.2, r
-    assert r["grad_linear.weight"] < 5e-2 and r["grad_transitions"] < 5e-2, r
-    assert r["viterbi_equal"], r
+    assert r["grad_min_cos"] > 0.999 and r["grad_worst_rel"] < 0.078, r
+    assert r["grad_worst_rel_vs_bf16_oracle"] < 0.09 and r["grad_min_cos_vs_bf16_oracle"] > 0.9985, r
+    # the attribution itself: the flash-backward oracle reproduces round 3's distance (within 2x), the storage oracle does not
+    assert 0.08 < r["flash_oracle_vs_fp32_worst_rel"] < 0.34 and r["bf16_oracle_vs_fp32_worst_rel"] < 0.06, r
 
 
 def test_accumulation_fusion_is_the_same_gradient(workdir):

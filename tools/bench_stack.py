@@ -65,6 +65,10 @@ def measure(encoders=3, lms=4, reps=3, lm_hidden=2048):
         em = torch.randn(B, nn, T, device=dev)
         tv = timed(lambda: ops.crf_viterbi(em, trans, lens, start, stop), 20)
         results.append({"metric": "cfg5 encoder fwd (XLM-R-large, 512 sub-tokens) + linear + Viterbi", "B": B, "n": nn,
+                        "n_requested": n_,
+                        "note": (None if nn == n_ else "BASELINE.md's point is (B=%d, n'=%d); the synthetic 512-sub-token generator yields at "
+                                 "most %d word tokens per sentence (<s>, </s> and multi-piece words take the rest), so n' = %d is timed" %
+                                 (B, n_, n_tok, nn)),
                         "sentences_per_s": round(B / dt, 1), "ms": round(dt * 1e3, 3), "viterbi_alone_us": round(tv * 1e6, 1),
                         "viterbi_alone_sentences_per_s": round(B / tv)})
     # ---- the whole stack at B = 32, n' = 20 real tokens (sentences chunked at <EOS>), ~6 characters per token

@@ -1,7 +1,7 @@
 // Attention lab: a torch-free executable that checks the attention kernels of libkbner_hip.so against naive fp32 GPU
 // references and times them (HIP events), so one short gpurun call can A/B several kernel variants.
 //   build: hipcc --offload-arch=gfx950 -O2 -std=c++17 -I kb-ner_amd/csrc -I include tools/micro/attn_lab.hip \
-//            kb-ner_amd/kbner/libkbner_hip.so -Wl,-rpath,'$ORIGIN/../../kb-ner_amd/kbner' -o tools/micro/attn_lab
+//            -Lkb-ner_amd/kbner -lkbner_hip -Wl,-rpath,'$ORIGIN/../../kb-ner_amd/kbner' -o tools/micro/attn_lab
 //   run:   tools/micro/attn_lab [Bcheck] [Btime] [S] [reps]         (env KBNER_ATTN selects the library's variant)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -13,9 +13,9 @@
 
 typedef uint16_t bf16_t;
 extern "C" {
-int kbner_attn_fwd(const bf16_t* qkv, const float* maskbias, bf16_t* ctx, float* lse, int B, int S, int H, int A, uint32_t drop_seed,
+int kbner_attn_fwd(const bf16_t* qkv, const float* maskbias, bf16_t* ctx, bf16_t* ctx_lo, float* lse, int B, int S, int H, int A, uint32_t drop_seed,
                    uint32_t drop_thresh, void* stream);
-int kbner_attn_bwd(const bf16_t* qkv, const bf16_t* ctx, const bf16_t* dctx, const float* maskbias, const float* lse, float* Dws,
+int kbner_attn_bwd(const bf16_t* qkv, const bf16_t* ctx, const bf16_t* ctx_lo, const bf16_t* dctx, const float* maskbias, const float* lse, float* Dws,
                    bf16_t* dqkv, int B, int S, int H, int A, uint32_t drop_seed, uint32_t drop_thresh, float* dbias_qkv, void* stream);
 int kbner_dropout_mask(float* out, int Z, int M, int N, uint32_t seed, uint32_t thresh, void* stream);
 }
@@ -160,7 +160,7 @@ static float grand() {   // ~N(0,1): sum of 4 uniforms
 }
 
 struct Bufs {
-  bf16_t *qkv, *dctx, *ctx, *dqkv;
+  bf16_t *qkv, *dctx, *ctx, *ctx_lo, *dqkv;   // ctx_lo: LAB_RESIDUAL=1 allocates it (null = D from the bf16 O alone)
   float *mb, *lse, *dws, *dbias;
 };
 
@@ -213,6 +213,8 @@ int main(int argc, char** argv) {
     Bufs d;
     const size_t nq = (size_t)B * S * 3 * H, nc = (size_t)B * S * H, nl = (size_t)B * A * S, np = nl * S;
     CK(hipMalloc(&d.qkv, nq * 2)); CK(hipMalloc(&d.dctx, nc * 2)); CK(hipMalloc(&d.ctx, nc * 2)); CK(hipMalloc(&d.dqkv, nq * 2));
+    d.ctx_lo = nullptr;
+    if (getenv("LAB_RESIDUAL")) CK(hipMalloc(&d.ctx_lo, nc * 2));
     CK(hipMalloc(&d.mb, (size_t)B * S * 4)); CK(hipMalloc(&d.lse, nl * 4)); CK(hipMalloc(&d.dws, nl * 4)); CK(hipMalloc(&d.dbias, 3 * H * 4));
     CK(hipMemcpy(d.qkv, qkv.data(), nq * 2, hipMemcpyHostToDevice));
     CK(hipMemcpy(d.dctx, dctx.data(), nc * 2, hipMemcpyHostToDevice));
@@ -229,7 +231,7 @@ int main(int argc, char** argv) {
     }
     hipLaunchKernelGGL(ref_probs, dim3(S, A, B), dim3(256), S * 4, 0, d.qkv, d.mb, P, lref, S, H, A);
     hipLaunchKernelGGL(ref_pv, dim3(S, A, B), dim3(64), 0, 0, d.qkv, P, DM, Oref, S, H, A);
-    int r1 = kbner_attn_fwd(d.qkv, d.mb, d.ctx, d.lse, B, S, H, A, dseed, dthr, nullptr);
+    int r1 = kbner_attn_fwd(d.qkv, d.mb, d.ctx, d.ctx_lo, d.lse, B, S, H, A, dseed, dthr, nullptr);
     CK(hipDeviceSynchronize());
     std::vector<float> o_ref(nc), l_ref(nl), l_got(nl), o_got(nc);
     std::vector<bf16_t> o_bf(nc);
@@ -251,7 +253,7 @@ int main(int argc, char** argv) {
     if (do_bwd) {
       hipLaunchKernelGGL(ref_ds, dim3(S, A, B), dim3(256), S * 4, 0, d.qkv, d.dctx, P, DM, dSr, PD, S, H, A);
       hipLaunchKernelGGL(ref_dqkv, dim3(S, A, B), dim3(64), 0, 0, d.qkv, d.dctx, dSr, PD, dref, S, H, A);
-      int r2 = kbner_attn_bwd(d.qkv, d.ctx, d.dctx, d.mb, d.lse, d.dws, d.dqkv, B, S, H, A, dseed, dthr, d.dbias, nullptr);
+      int r2 = kbner_attn_bwd(d.qkv, d.ctx, d.ctx_lo, d.dctx, d.mb, d.lse, d.dws, d.dqkv, B, S, H, A, dseed, dthr, d.dbias, nullptr);
       CK(hipDeviceSynchronize());
       std::vector<float> g_ref(nq), g_got(nq), db(3 * H);
       std::vector<bf16_t> g_bf(nq);
@@ -275,7 +277,7 @@ int main(int argc, char** argv) {
     printf(" %s\n", rc ? "FAIL-SO-FAR" : "ok");
     hipFree(P); hipFree(Oref); hipFree(lref); hipFree(dSr); hipFree(PD); hipFree(dref);
     if (DM) hipFree(DM);
-    hipFree(d.qkv); hipFree(d.dctx); hipFree(d.ctx); hipFree(d.dqkv); hipFree(d.mb); hipFree(d.lse); hipFree(d.dws); hipFree(d.dbias);
+    hipFree(d.qkv); hipFree(d.dctx); hipFree(d.ctx); hipFree(d.ctx_lo); hipFree(d.dqkv); hipFree(d.mb); hipFree(d.lse); hipFree(d.dws); hipFree(d.dbias);
   }
   // ---------------- timing ----------------
   if (Bt > 0) {
@@ -291,6 +293,8 @@ int main(int argc, char** argv) {
     Bufs d;
     const size_t nq = (size_t)B * S * 3 * H, nc = (size_t)B * S * H, nl = (size_t)B * A * S;
     CK(hipMalloc(&d.qkv, nq * 2)); CK(hipMalloc(&d.dctx, nc * 2)); CK(hipMalloc(&d.ctx, nc * 2)); CK(hipMalloc(&d.dqkv, nq * 2));
+    d.ctx_lo = nullptr;
+    if (getenv("LAB_RESIDUAL")) CK(hipMalloc(&d.ctx_lo, nc * 2));
     CK(hipMalloc(&d.mb, (size_t)B * S * 4)); CK(hipMalloc(&d.lse, nl * 4)); CK(hipMalloc(&d.dws, nl * 4)); CK(hipMalloc(&d.dbias, 3 * H * 4));
     CK(hipMemcpy(d.qkv, qkv.data(), nq * 2, hipMemcpyHostToDevice));
     CK(hipMemcpy(d.dctx, dctx.data(), nc * 2, hipMemcpyHostToDevice));
@@ -301,10 +305,10 @@ int main(int argc, char** argv) {
     const double f = 4.0 * S * S * 64 * A * B;
     for (int drop = 0; drop < 2; ++drop) {
       const uint32_t thr = drop ? 429496730u : 0u;
-      for (int i = 0; i < 3; ++i) kbner_attn_fwd(d.qkv, d.mb, d.ctx, d.lse, B, S, H, A, 1u, thr, nullptr);
+      for (int i = 0; i < 3; ++i) kbner_attn_fwd(d.qkv, d.mb, d.ctx, d.ctx_lo, d.lse, B, S, H, A, 1u, thr, nullptr);
       CK(hipDeviceSynchronize());
       CK(hipEventRecord(e0));
-      for (int i = 0; i < reps; ++i) kbner_attn_fwd(d.qkv, d.mb, d.ctx, d.lse, B, S, H, A, 1u, thr, nullptr);
+      for (int i = 0; i < reps; ++i) kbner_attn_fwd(d.qkv, d.mb, d.ctx, d.ctx_lo, d.lse, B, S, H, A, 1u, thr, nullptr);
       CK(hipEventRecord(e1));
       CK(hipEventSynchronize(e1));
       float ms;
@@ -312,10 +316,10 @@ int main(int argc, char** argv) {
       ms /= reps;
       printf("time B=%d S=%d drop=%d  fwd %8.1f us  %7.1f TFLOP/s", B, S, drop, ms * 1e3, f / ms / 1e9);
       if (do_bwd) {
-        for (int i = 0; i < 3; ++i) kbner_attn_bwd(d.qkv, d.ctx, d.dctx, d.mb, d.lse, d.dws, d.dqkv, B, S, H, A, 1u, thr, d.dbias, nullptr);
+        for (int i = 0; i < 3; ++i) kbner_attn_bwd(d.qkv, d.ctx, d.ctx_lo, d.dctx, d.mb, d.lse, d.dws, d.dqkv, B, S, H, A, 1u, thr, d.dbias, nullptr);
         CK(hipDeviceSynchronize());
         CK(hipEventRecord(e0));
-        for (int i = 0; i < reps; ++i) kbner_attn_bwd(d.qkv, d.ctx, d.dctx, d.mb, d.lse, d.dws, d.dqkv, B, S, H, A, 1u, thr, d.dbias, nullptr);
+        for (int i = 0; i < reps; ++i) kbner_attn_bwd(d.qkv, d.ctx, d.ctx_lo, d.dctx, d.mb, d.lse, d.dws, d.dqkv, B, S, H, A, 1u, thr, d.dbias, nullptr);
         CK(hipEventRecord(e1));
         CK(hipEventSynchronize(e1));
         CK(hipEventElapsedTime(&ms, e0, e1));

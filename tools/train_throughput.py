@@ -67,14 +67,49 @@ def evaluate_rate(sentences=512, batch=32, model="large"):
     dl = ColumnDataLoader(list(cc.train), batch, sentence_level_batch=True)
     dl.assign_tags("ner", td)
     tagger.eval()
+    # the host half of evaluate is small-tensor / numpy work: a wide intra-op pool (the CPU leg of bench.py leaves 32 threads set,
+    # a GPU box may report 256 logical CPUs under a 16-CPU quota) only adds wake-up latency to it
+    prev_threads = torch.get_num_threads()
+    torch.set_num_threads(max(1, min(4, prev_threads)))
     tagger.evaluate(dl)
     torch.cuda.synchronize()
+    # host / device split per batch: the device half of batch k (enqueue) runs while the host half of batch k - 1 (finish: wait,
+    # labels, spans, metric) is computed; the wall time per batch is ~max(device, host)
+    enq_host, fin_host, gpu_ms, evs = [], [], [], []
+    orig_enq, orig_fin = tagger._eval_enqueue, tagger._eval_finish
+
+    def enq(*a, **k):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t = time.perf_counter()
+        e0.record()
+        r = orig_enq(*a, **k)
+        e1.record()
+        enq_host.append(time.perf_counter() - t)
+        evs.append((e0, e1))
+        return r
+
+    def fin(*a, **k):
+        t = time.perf_counter()
+        r = orig_fin(*a, **k)
+        fin_host.append(time.perf_counter() - t)
+        return r
+
+    tagger._eval_enqueue, tagger._eval_finish = enq, fin
     t0 = time.perf_counter()
     tagger.evaluate(dl)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    tagger._eval_enqueue, tagger._eval_finish = orig_enq, orig_fin
+    gpu_ms = [a.elapsed_time(b) for a, b in evs]
+    torch.set_num_threads(prev_threads)
     shutil.rmtree(d, ignore_errors=True)
+    nb = max(1, len(evs))
     return {"value": round(sentences / dt, 1), "unit": "sentences/sec", "sentences": sentences, "batch": batch,
+            "per_batch_ms": {"wall": round(1e3 * dt / nb, 2), "device": round(float(np.mean(gpu_ms)), 2),
+                             "host_enqueue": round(1e3 * float(np.mean(enq_host)), 2),
+                             "host_finish_incl_wait": round(1e3 * float(np.mean(fin_host)), 2),
+                             "host_other (tokenise, batch)": round(1e3 * (dt - sum(enq_host) - sum(fin_host)) / nb, 2)},
+            "host_threads": max(1, min(4, prev_threads)),
             "sub_tokens_per_sentence": round(float(np.mean(sub)), 1),
             "what": "FastSequenceTagger.evaluate end to end (host tokenisation + batching + XLM-R-%s-sized encoder forward + emissions "
                     "+ CRF NLL + Viterbi + labels + span metric), second pass over the corpus" % model}
