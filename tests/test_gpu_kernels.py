@@ -103,6 +103,22 @@ def test_attention(st, B, S, A, ragged):
     assert r["dbias"] < 2e-2, r                        # qkv bias gradient accumulated inside the backward kernels
 
 
+def test_gemm_variants_bit_identical():
+    """the interleaved-ring main loop (gemm256f_kernel, variant 1 = default) against the two-stage loop of rounds 1-3 (variant 0) on
+    every engine epilogue: one tile, several tiles per CU (ring wrap across tiles), K = 64 (one stage per tile), K = 128 / 192 / 320
+    (ring phases 2, 0, 2 mod 3 at the tile boundary).  Same MFMA order per output element, so the results must be EQUAL, fp32
+    column sums included.  Own process (tools/gemm_pp_lab.py switches the library's variant)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "gemm_pp_lab.py"), "--skip-bench", "--variants", "0,1"], cwd=root,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = r.stdout.decode()
+    assert r.returncode == 0, out[-2000:]
+    assert "MISMATCH" not in out and "bit-identity vs variant 0: OK" in out, out[-2000:]
+    assert out.count("checked M=") == 7, out[-2000:]
+
+
 @pytest.mark.parametrize("B,S,A", [(2, 128, 2), (32, 512, 8)])
 def test_attention_residual_context(st, B, S, A):
     """kbner_attn_fwd / _bwd with ctx_lo (the engine's training default): on ordinary inputs nothing changes beyond rounding, and where the K / V rows of a head are nearly parallel -- dS = P (dP - D) cancels --
