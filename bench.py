@@ -311,12 +311,13 @@ def main():
         cands = sorted(f for f in (os.listdir(pdir) if os.path.isdir(pdir) else []) if f.endswith("_hbm_traffic.json"))
         tpath = os.path.join(pdir, cands[-1]) if cands else ""
         if args.model == "large" and B == 128 and S == 512 and tpath:
-            ks = [v for k, v in json.load(open(tpath))["kernels"].items() if "gemm256_kernel" in k]
+            ks = [v for k, v in json.load(open(tpath))["kernels"].items() if "gemm256f_kernel" in k or "gemm256_kernel" in k]
             n = sum(v["launches"] for v in ks)
             if n:
                 traffic = round(sum(v["launches"] * v["hbm_bytes_per_launch"] for v in ks) / n)
                 traffic_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch)" % cands[-1]
-        roofline = {"bound": "mfma", "kernel": "gemm256_kernel<A_KS,B_KS> (bf16 MFMA 16x16x32, 256x256x64 tiles, all 3 layouts)",
+        roofline = {"bound": "mfma", "kernel": "gemm256f_kernel<A_KS,B_KS> (bf16 MFMA 16x16x32, 256x256x64 tiles, interleaved-ring K loop, all 3 layouts; "
+                              "gemm256_kernel = the two-stage loop, for dynamic tiles at N > 1)",
                     "achieved": round(ach, 2), "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "algorithmic_flops_per_launch": round(tot_fl / max(len(recs), 1)),
