@@ -94,6 +94,12 @@ int kbner_crf_pair_posterior(const float* emit, const float* trans, const int* l
 int kbner_crf_exact_kd(const float* emit, const float* trans, const int* lens, const float* pair, const float* start_score,
                        const float* end_score, const float* wgt, float tau, int B, int n, int T, int start, int stop, float* loss,
                        float* demit, float* dtrans, float* ws, void* stream);
+/* `distill_emission` (sequence_tagger_model.py:2311-2365 -> _calculate_distillation_loss :2384-2398) for a CRF student: per token
+ * tau^2 KL(p || softmax(emit / tau)), p = softmax(teacher / tau) or the teacher row itself (teacher_is_prob: `distill_prob`, the
+ * trainer stored softmax(logits), finetune_trainer.py:1474); loss f32[B] WRITTEN per sentence (unweighted), demit f32[B,n,T]
+ * WRITTEN with d(sum_b wgt[b] loss[b]) / d emit (0 behind a sentence's end).  T <= 64. */
+int kbner_emission_kl(const float* emit, const float* teacher, const int* lens, const float* wgt, float tau, int teacher_is_prob,
+                      int B, int n, int T, float* loss, float* demit, void* stream);
 /* n-best Viterbi (SequenceTagger._viterbi_decode_nbest, sequence_tagger_model.py:1660-1818; called on KD teachers at
  * finetune_trainer.py:1600, distillation_trainer.py:819): decode i32 [B, n, nbest] tag indices and path_score f32 [B, nbest]
  * (softmax over the nbest end scores).  The NCRF++ decoder's conventions are kept as they are: trans indexed [from, to],

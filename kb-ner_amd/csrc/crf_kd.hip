@@ -441,7 +441,67 @@ __global__ __launch_bounds__(64) void crf_exact_kd_kernel(const float* __restric
   }
 }
 
+// Emission-level distillation of a CRF student (`distill_emission`, sequence_tagger_model.py:2311-2365 -> :2384-2398): per token
+// T^2 KL(p || softmax(emit / tau)) with p = softmax(teacher / tau) or, when the trainer stored probabilities (distill_prob), the
+// teacher row itself; a term with p = 0 contributes 0 (torch's kl_div).  One wave per sentence walks its tokens, lane = tag:
+// no scan, the sentence-level grouping only keeps the per-sentence loss free of atomics.
+//   loss[b] = tau^2 sum_{i < len} sum_t p_t (log p_t - log q_t);   demit[b,i,t] = wgt[b] tau (q_t sum_t' p_t' - p_t), 0 behind the end
+template <bool PROB>
+__global__ __launch_bounds__(64) void emission_kl_kernel(const float* __restrict__ emit, const float* __restrict__ teacher,
+                                                         const int* __restrict__ lens, const float* __restrict__ wgt, float tau,
+                                                         int n, int T, float* __restrict__ loss, float* __restrict__ demit) {
+  const int b = blockIdx.x, t = threadIdx.x;
+  const bool live = t < T;
+  const int len = min(max(lens[b], 0), n);
+  const float w = wgt[b], itau = 1.0f / tau;
+  const float* e = emit + (size_t)b * n * T;
+  const float* tc = teacher + (size_t)b * n * T;
+  float* d = demit + (size_t)b * n * T;
+  float acc = 0.0f;
+  for (int i = 0; i < len; ++i) {
+    const float s = live ? e[(size_t)i * T + t] * itau : -INFINITY;
+    const float smax = wave_max(s);
+    const float lq = s - smax - __logf(wave_sum(live ? __expf(s - smax) : 0.0f));      // log softmax(emit / tau)
+    float p, lp;
+    if (PROB) {
+      p = live ? tc[(size_t)i * T + t] : 0.0f;
+      lp = p > 0.0f ? __logf(p) : 0.0f;
+    } else {
+      const float u = live ? tc[(size_t)i * T + t] * itau : -INFINITY;
+      const float umax = wave_max(u);
+      lp = u - umax - __logf(wave_sum(live ? __expf(u - umax) : 0.0f));
+      p = live ? __expf(lp) : 0.0f;
+    }
+    const float psum = PROB ? wave_sum(p) : 1.0f;
+    if (live) {
+      acc += p > 0.0f ? p * (lp - lq) : 0.0f;
+      d[(size_t)i * T + t] = w * tau * (__expf(lq) * psum - p);
+    }
+  }
+  for (int i = len; i < n; ++i)
+    if (live) d[(size_t)i * T + t] = 0.0f;
+  acc = wave_sum(acc);
+  if (t == 0) loss[b] = acc * tau * tau;
+}
+
 extern "C" {
+
+// Emission-level distillation term of a CRF student (see emission_kl_kernel): emit, teacher f32[B,n,T]; teacher_is_prob: the
+// teacher rows are probabilities (distill_prob) instead of scores; loss f32[B] WRITTEN (unweighted), demit f32[B,n,T] WRITTEN with
+// d(sum_b wgt[b] loss[b]) / d emit.  T <= 64.
+int kbner_emission_kl(const float* emit, const float* teacher, const int* lens, const float* wgt, float tau, int teacher_is_prob,
+                      int B, int n, int T, float* loss, float* demit, void* stream) {
+  KBNER_CHECK_ARG(B >= 0 && n >= 0 && T > 0 && T <= 64 && tau > 0.0f);
+  if (B == 0) return 0;
+  KBNER_CHECK_ARG(emit != nullptr && teacher != nullptr && lens != nullptr && wgt != nullptr && loss != nullptr && demit != nullptr);
+  if (teacher_is_prob)
+    hipLaunchKernelGGL(emission_kl_kernel<true>, dim3(B), dim3(64), 0, (hipStream_t)stream, emit, teacher, lens, wgt, tau, n, T, loss,
+                       demit);
+  else
+    hipLaunchKernelGGL(emission_kl_kernel<false>, dim3(B), dim3(64), 0, (hipStream_t)stream, emit, teacher, lens, wgt, tau, n, T,
+                       loss, demit);
+  KBNER_LAUNCH_RET();
+}
 
 // floats of workspace kbner_crf_posterior_kl needs
 size_t kbner_crf_posterior_kl_ws_floats(int B, int n, int T) { return (size_t)B * 4 * n * T; }

@@ -274,6 +274,7 @@ class Sentence:
         # knowledge-distillation targets, one entry per teacher (flair/data.py:364-370 of the reference)
         self._teacher_target, self._teacher_weights, self._teacher_posteriors = [], [], []
         self._teacher_startscores, self._teacher_endscores = [], []
+        self._teacher_prediction = []
         if text is not None:
             pos = 0
             for word in text.split():
@@ -447,6 +448,9 @@ class Sentence:
     def set_teacher_target(self, vector, storage_mode=None):       # int [len, best_k] n-best tag sequences
         self._teacher_target.append(self._host(vector)[:len(self)])
 
+    def set_teacher_prediction(self, vector, storage_mode=None):   # f32 [len, T] teacher emissions (softmax of them: distill_prob)
+        self._teacher_prediction.append(self._host(vector)[:len(self)])
+
     def set_teacher_weights(self, vector, storage_mode=None):      # f32 [best_k] path weights
         self._teacher_weights.append(self._host(vector))
 
@@ -462,6 +466,13 @@ class Sentence:
     def get_teacher_target(self):
         import numpy as np
         return np.concatenate(self._teacher_target, -1)
+
+    def get_teacher_prediction(self, pooling="mean", weight=None):
+        """flair/data.py:786-807, the pooling a CRF student uses: the mean over the teachers"""
+        import numpy as np
+        if pooling != "mean" or weight is not None:
+            raise NotImplementedError("weighted teacher pooling (language attention) is outside the hot path")
+        return np.stack(self._teacher_prediction).mean(0)
 
     def get_teacher_weights(self):
         import numpy as np

@@ -26,12 +26,11 @@ log = logging.getLogger("flair")
 START_TAG: str = "<START>"
 STOP_TAG: str = "<STOP>"
 
-# constructor switches of the reference that select code outside the hot path (softmax-head / emission KD, MFVI, attention
-# variants, ACE controller training): accepted by name, rejected when switched on.  The CRF knowledge-distillation switches
-# (distill_crf, crf_attention, distill_with_gold, exp_score, distill_posterior, distill_exact) ARE implemented.
+# constructor switches of the reference that select code outside the hot path (softmax head, MFVI, attention variants, ACE
+# controller training): accepted by name, rejected when switched on.  The CRF knowledge-distillation switches (distill_crf,
+# crf_attention, distill_with_gold, exp_score, distill_posterior, distill_exact, distill_emission, distill_prob) ARE implemented.
 _UNSUPPORTED_TRUE = ("use_mfvi", "use_cnn", "biaf_attention", "use_language_attention",
-                     "token_level_attention", "distill_prob",
-                     "distill_emission", "posterior_constraint", "use_language_vector", "enhanced_crf",
+                     "token_level_attention", "posterior_constraint", "use_language_vector", "enhanced_crf",
                      "use_language_id", "use_transition_attention", "unlabel_entropy_loss", "relearn_embeddings", "map_embeddings",
                      "no_encoder", "new_drop", "use_embedding_masks", "use_gumbel", "embedding_attention",
                      "train_initial_hidden_state")
@@ -80,7 +79,15 @@ class SequenceTagger(flair.nn.Model):
             raise ValueError("calculate_l2_loss is a term of the multi-view loss: enable multi_view_training")
         # teacher-student knowledge distillation (`distill_mode: true` of ModelFinetuner; simple_forward_distillation_loss below):
         # distill_posterior (without multi_view_training), distill_crf (+ crf_attention, distill_with_gold, exp_score), distill_exact
-        kd_student = ((distill_posterior or distill_exact) and not multi_view_training) or distill_crf
+        # and distill_emission (+ distill_prob): the emission-level KL of :2311-2365, on its own or next to distill_posterior
+        kd_student = ((distill_posterior or distill_exact) and not multi_view_training) or distill_crf or distill_emission
+        if distill_emission and multi_view_training:
+            raise NotImplementedError("distill_emission belongs to distill_mode (teacher-student) training, not to multi_view_training")
+        if distill_emission and (distill_crf or distill_exact) and not distill_posterior:
+            # the trainer then stores n-best / pairwise targets only (finetune_trainer.py:616-619) and the emission branch stacks
+            # empty `_teacher_prediction` lists (sequence_tagger_model.py:2358): the reference fails on this combination
+            raise ValueError("distill_emission next to distill_crf / distill_exact needs distill_posterior (whose teacher scores the "
+                             "emission term then reads, sequence_tagger_model.py:2349-2353)")
         if kd_student and use_rnn:
             raise NotImplementedError("knowledge distillation is implemented for the fine-tuning student (use_rnn: false)")
         if distill_exact and distill_posterior and not multi_view_training:
@@ -119,7 +126,7 @@ class SequenceTagger(flair.nn.Model):
         self.biaf_attention = False
         self.use_language_attention = False
         self.use_language_vector = False
-        self.distill_prob = self.distill_emission = False
+        self.distill_emission, self.distill_prob = bool(distill_emission), bool(distill_prob)
         self.distill_crf, self.distill_exact = bool(distill_crf), bool(distill_exact)
         self.distill_posterior = bool(distill_posterior)
         self.multi_view_training = bool(multi_view_training)
@@ -521,6 +528,17 @@ class SequenceTagger(flair.nn.Model):
                 pair[b, :L] = p[:L]
                 s_sc[b], e_sc[b] = sn._teacher_startscores[0], sn._teacher_endscores[0]
             kd["exact"] = (torch.from_numpy(pair).to(dev), torch.from_numpy(s_sc).to(dev), torch.from_numpy(e_sc).to(dev))
+        if self.distill_emission:
+            if self.distill_posterior:      # :2349-2353: the first teacher's forward-backward scores
+                kd["emission"] = (kd["scores"][0], self.distill_prob)
+            else:                           # :2355-2358: mean over the teachers of the stored predictions, zero rows behind the end
+                teachers_of("_teacher_prediction")
+                pr = np.zeros((B, n, T), np.float32)
+                for b, sn in enumerate(sentences):
+                    p = sn.get_teacher_prediction()
+                    L = min(len(p), n)
+                    pr[b, :L] = p[:L]
+                kd["emission"] = (torch.from_numpy(pr).to(dev), self.distill_prob)
         if self.distill_crf:
             nt = teachers_of("_teacher_target")
             tg = [sn.get_teacher_target() for sn in sentences]          # [len, best_k * teachers]

@@ -52,10 +52,12 @@ class ModelFinetuner:
             if not teachers:
                 raise ValueError("distill_mode: true needs at least one teacher (ConfigParser.create_teachers / create_teachers_list)")
             if not (getattr(model, "distill_crf", False) or getattr(model, "distill_exact", False) or
+                    getattr(model, "distill_emission", False) or
                     (getattr(model, "distill_posterior", False) and not getattr(model, "multi_view_training", False))):
+                # (with none of them the reference's loss for a CRF student is interpolation * 0 + (1 - interpolation) * NLL, :2311,
+                # after labelling the whole training set for nothing)
                 raise NotImplementedError("distill_mode with a CRF student needs one of the model switches distill_crf / "
-                                          "distill_posterior / distill_exact; emission-level KD "
-                                          "(assign_pretrained_teacher_predictions) belongs to softmax students, outside the hot path")
+                                          "distill_posterior / distill_exact / distill_emission")
             for teacher in teachers:
                 teacher.eval()
         self.optimizer_state = optimizer_state     # checkpoint resume (finetune_trainer.py:573,690)
@@ -216,6 +218,41 @@ class ModelFinetuner:
         log.info("Distilled %d sentences", counter)
         return [sn for data in coupled_train_data for sn in data]
 
+    def assign_pretrained_teacher_predictions(self, coupled_train_data, teachers, is_professor=False, faster=False,
+                                              mini_batch_size=32):
+        """finetune_trainer.py:1417-1513 for sequence labelling: every teacher's emission scores over the training sets it teaches,
+        `softmax` of them when the student sets distill_prob (:1474), stored per sentence trimmed to its length (:1492; the
+        student's batches zero-pad them, `resort` :2008-2012 = FastSequenceTagger._kd_batch).  Computed on the device
+        (teacher.forward = the HIP encoder + head), kept on the host.  Returns the flat list of training sentences."""
+        if is_professor or faster:
+            raise NotImplementedError("professors / the `faster` batch-level storage are outside the hot path")
+        log.info("Distilling sentences...")
+        if len(self.corpus.targets) != len(coupled_train_data):
+            raise ValueError("Coupled train data is not equal to target!")
+        m = self.model
+        counter = 0
+        for teacher in teachers:
+            if m.tag_dictionary.item2idx != teacher.tag_dictionary.item2idx:
+                raise ValueError("the tag_dictionaries of the teacher and student are not same")
+            teacher.eval()
+            for index, train_data in enumerate(coupled_train_data):
+                if self.corpus.targets[index] not in getattr(teacher, "targets", set(self.corpus.targets)):
+                    continue
+                loader = ColumnDataLoader(list(train_data), mini_batch_size, False, model=teacher,
+                                          sentence_level_batch=self.sentence_level_batch)
+                loader.assign_tags(teacher.tag_type, teacher.tag_dictionary)
+                for batch in loader:
+                    counter += len(batch)
+                    logits = teacher.forward(batch)                                    # f32 [B, n, T], device
+                    if m.distill_prob:
+                        logits = torch.softmax(logits, -1)
+                    logits = logits.cpu().numpy()
+                    for i, sentence in enumerate(batch):
+                        sentence.set_teacher_prediction(logits[i, :len(sentence)].copy())
+                    store_embeddings(batch, "none")
+        log.info("Distilled %d sentences", counter)
+        return [sn for data in coupled_train_data for sn in data]
+
     # ------------------------------------------------------------------ training
     def train(self, base_path: Union[Path, str], learning_rate: float = 5e-5, mini_batch_size: int = 32,
               eval_mini_batch_size: int = None, max_epochs: int = 100, anneal_factor: float = 0.5, patience: int = 10,
@@ -270,8 +307,11 @@ class ModelFinetuner:
         train_data = [s for ds in train_sets for s in ds]
         if self.distill_mode:
             # finetune_trainer.py:597-636: every training sentence gets its teacher targets, then the teachers are released
-            train_data = self.assign_pretrained_teacher_targets(train_sets, self.teachers, best_k=best_k,
-                                                                mini_batch_size=mini_batch_size)
+            if self.model.distill_crf or self.model.distill_posterior or self.model.distill_exact:      # :616-619
+                train_data = self.assign_pretrained_teacher_targets(train_sets, self.teachers, best_k=best_k,
+                                                                    mini_batch_size=mini_batch_size)
+            else:
+                train_data = self.assign_pretrained_teacher_predictions(train_sets, self.teachers, mini_batch_size=mini_batch_size)
             # release the teachers: their engines' device arenas (fp32 parameters, bf16 shadow -- ~3.4 GB for an XLM-R-large-sized
             # teacher) go back to the allocator once no reference is left (train.py drops its own list after building the trainer)
             for t in self.teachers:
@@ -353,7 +393,8 @@ class ModelFinetuner:
         if self.distill_mode:
             multi_view = False
             log.info("distill_mode: interpolation * KD(%s) + (1 - interpolation) * NLL, interpolation %s, T = %s",
-                     "+".join(k for k in ("distill_posterior", "distill_crf", "distill_exact") if getattr(self.model, k, False)),
+                     "+".join(k for k in ("distill_posterior", "distill_crf", "distill_exact", "distill_emission")
+                              if getattr(self.model, k, False)),
                      "annealed from 1 by %s%% per epoch" % self.anneal_factor if self.teacher_annealing else self.interpolation,
                      self.model.temperature)
         dev_score_history, dev_loss_history, train_loss_history = [], [], []

@@ -665,6 +665,7 @@ class Tagger:
             "targets"  i32[B,n,K] teacher n-best tag sequences, K = best_k * teachers                 (distill_crf)
             "weights"  f32[B,K] their path weights + "att_nums" (sentence, teacher) pairs             (crf_attention)
             "exact"    (pair f32[B,n-1,T*T], start_score f32[B,T], end_score f32[B,T])                (distill_exact)
+            "emission" (teacher f32[B,n,T], rows are probabilities: bool)                             (distill_emission / _prob)
         weights: optional per-sentence weights replacing the 1/B of the batch means.  Returns the loss (0-d device tensor);
         self.last_kd_parts = (kd terms, NLL), both unweighted by the interpolation."""
         return self._launch(self._kd_loss, batch, kd, interpolation, tau, loss_scale, backward, weights, grad_ready)
@@ -710,6 +711,11 @@ class Tagger:
             wk = w * (ip / len(scores))
             per, d = ops.crf_posterior_kl_scores(em, st, trans, lens, wk * loss_scale, tau, self.start, self.stop, dtrans)
             kd_val = kd_val + (per * w).sum() / len(scores)
+            acc(d)
+        if kd.get("emission") is not None:                               # :2311-2365, 2384-2398: token-level KL on the emissions
+            teach, is_prob = kd["emission"]
+            per, d = ops.emission_kl(em, teach, lens, w * (ip * loss_scale), tau, is_prob)
+            kd_val = kd_val + (per * w).sum()
             acc(d)
         if kd.get("exact") is not None:                                  # :2139-2244
             pair, s_sc, e_sc = kd["exact"]

@@ -139,6 +139,20 @@ def crf_posterior_kl_scores(emit_s, score_t, trans, lens, weights, tau, start, s
     return loss, demit
 
 
+def emission_kl(emit, teacher, lens, weights, tau, teacher_is_prob=False):
+    """`distill_emission` term of a CRF student: (loss f32[B] = tau^2 sum_tokens KL(p_teacher || softmax(emit / tau)),
+    demit f32[B,n,T] = d(sum_b weights[b] loss[b]) / d emit)"""
+    _chk(emit, F32, "emit"); _chk(teacher, F32, "teacher"); _chk(lens, I32, "lens"); _chk(weights, F32, "weights")
+    if emit.shape != teacher.shape:
+        raise L.KbnerError("student emissions and teacher predictions must have the same [B, n, T] shape")
+    B, n, T = emit.shape
+    loss = torch.empty((B,), dtype=F32, device=emit.device)
+    demit = torch.empty_like(emit)
+    L.call("kbner_emission_kl", ptr(emit), ptr(teacher), ptr(lens), ptr(weights), float(tau), int(bool(teacher_is_prob)), B, n, T,
+           ptr(loss), ptr(demit), stream_ptr())
+    return loss, demit
+
+
 def crf_pair_posterior(emit, trans, lens, tau, start, stop, suppress=()):
     """teacher targets of `distill_exact` (finetune_trainer.py:1705-1722): (pair f32[B,n-1,T*T], start_score f32[B,T],
     end_score f32[B,T])"""

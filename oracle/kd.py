@@ -10,7 +10,8 @@ Reference (restated, never copied):
   student side  FastSequenceTagger.simple_forward_distillation_loss (flair/models/sequence_tagger_model.py:2110-2372):
                 interpolation * (posterior + crf + exact) + (1 - interpolation) * NLL, each term as restated below.
 
-Pinned by tests/golden/kd_loss.npz, captured by running those reference methods under autograd (oracle/gen_golden_kd.py);
+Pinned by tests/golden/kd_loss.npz (+ kd_emission.npz for the emission-level term), captured by running those reference methods
+under autograd (oracle/gen_golden_kd.py, oracle/gen_golden_kd_emission.py);
 tests/test_oracle_golden.py checks every function here against it.  Differentiable through torch autograd, which is what the
 reference itself uses."""
 import torch
@@ -132,10 +133,25 @@ def target_term(es, trans, lens, tags, start, stop, x_idx=None):
     return crf_nll_torch(ce, ct, kl, trans, start, stop).mean()
 
 
+def emission_term(es, lens, teacher, tau, teacher_is_prob=False):
+    """distill_emission (:2311-2365 -> _calculate_distillation_loss :2384-2398, use_crf: sum / batch size):
+    T^2 sum_b sum_{i < len_b} KL(p_teacher || softmax(es / T)) / B with p_teacher = softmax(teacher / T), or `teacher` itself when
+    the trainer stored probabilities (distill_prob).  teacher [B, n, T]: the mean over the teachers of what
+    assign_pretrained_teacher_predictions stored (zero rows behind a sentence's end), or -- distill_posterior also on -- the
+    first teacher's forward-backward scores.  Pinned by tests/golden/kd_emission.npz (oracle/gen_golden_kd_emission.py)."""
+    B, n, T = es.shape
+    mask = lengths_mask(lens, n, es.dtype)
+    tp = teacher.to(es.dtype) if teacher_is_prob else torch.softmax(teacher.to(es.dtype) / tau, dim=-1)
+    kd = torch.nn.functional.kl_div(torch.log_softmax(es / tau, dim=-1), tp, reduction="none")
+    return (kd * mask[:, :, None]).sum() * tau * tau / B
+
+
 def kd_loss(es, trans, lens, tags, start, stop, x_idx, tau, interpolation, scores_t=None, targets=None, weights=None,
-            att_nums=None, exact=None):
+            att_nums=None, exact=None, emission=None, emission_is_prob=False):
     """simple_forward_distillation_loss for a CRF student (:2372)"""
     kd = 0.0
+    if emission is not None:
+        kd = kd + emission_term(es, lens, emission, tau, emission_is_prob)
     if scores_t:
         kd = kd + posterior_term(es, trans, lens, scores_t, tau, start, stop)
     if exact is not None:

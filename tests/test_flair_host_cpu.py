@@ -408,3 +408,27 @@ def test_kd_batch_assembly_reproduces_the_reference_loss():
         ref = float(g["c%d_loss" % c])
         assert abs(float(loss) - ref) <= 3e-5 * max(1.0, abs(ref)), (c, float(loss), ref)
     assert seen_gold == 2
+
+
+def test_kd_batch_assembly_emission_reproduces_the_reference_loss():
+    """the same for distill_emission (+ distill_prob, + distill_posterior): FastSequenceTagger._kd_batch's "emission" entry fed to
+    the oracle reproduces the loss the REFERENCE computed (tests/golden/kd_emission.npz)"""
+    import os
+    import torch
+    import tiny_assets
+    from flair.models import FastSequenceTagger
+    from oracle import kd as okd
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "kd_emission.npz"))
+    start, stop, x_idx = int(g["start"]), int(g["stop"]), int(g["x_idx"])
+    for c in range(int(g["n_cases"])):
+        fake, sents, hb = tiny_assets.kd_emission_golden_batch(g, c)
+        kd = FastSequenceTagger._kd_batch(fake, sents, hb)
+        teach, is_prob = kd["emission"]
+        assert tuple(teach.shape) == g["c%d_es" % c].shape and is_prob == bool(g["c%d_flags" % c][0])
+        kw = {"emission": teach.cpu(), "emission_is_prob": is_prob}
+        if "scores" in kd:
+            kw["scores_t"] = [x.cpu() for x in kd["scores"]]
+        loss = okd.kd_loss(torch.from_numpy(g["c%d_es" % c]), torch.from_numpy(g["trans_s"]), g["c%d_lens" % c], g["c%d_tags" % c], start,
+                           stop, x_idx, float(g["c%d_tau" % c]), float(g["c%d_interpolation" % c]), **kw)
+        ref = float(g["c%d_loss" % c])
+        assert abs(float(loss) - ref) <= 3e-5 * max(1.0, abs(ref)), (c, float(loss), ref)

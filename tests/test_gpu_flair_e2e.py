@@ -753,6 +753,85 @@ def test_kd_training_vs_reference_run(tmp_path, name):
     assert len(out["dev_score_history"]) == len(ref["dev_score_history"])
 
 
+@pytest.mark.parametrize("prob", [False, True])
+def test_kd_emission_training(tmp_path, prob):
+    """`distill_mode` with `distill_emission` (+ `distill_prob`) through the trainer: the teacher labels the training set with its
+    emissions (assign_pretrained_teacher_predictions: teacher.forward, softmax under distill_prob), and the student's first loss is
+    interpolation * T^2 KL(teacher || student emissions) / B + (1 - interpolation) * NLL -- checked against the oracle restatement
+    (pinned to the reference's own loss by tests/golden/kd_emission.npz) evaluated on the student's emissions of that batch"""
+    import tiny_assets
+    from flair.config_parser import ConfigParser
+    from flair.trainers import ModelFinetuner
+    from flair.utils.from_params import Params
+    from oracle import kd as okd
+    cfg, tcfg = tiny_assets.kd_config(str(tmp_path), posterior=False, crf=False, attention=False, exact=False, temperature=2.0,
+                                      interpolation=0.6, max_epochs=3)
+    cfg["model"]["FastSequenceTagger"].update(distill_emission=True, distill_prob=prob)
+    with open(tmp_path / "cfg.yaml", "w") as f:
+        yaml.safe_dump(cfg, f)
+    with open(tmp_path / "teacher.yaml", "w") as f:
+        yaml.safe_dump(tcfg, f)
+    cp = ConfigParser(Params.from_file(str(tmp_path / "cfg.yaml")))
+    teacher = cp.create_model(Params.from_file(str(tmp_path / "teacher.yaml")))
+    g = torch.Generator().manual_seed(11)
+    T = len(cp.tag_dictionary)
+    teacher.engine.set_param("linear.weight", torch.randn(T, teacher.engine.cfg.hidden_size, generator=g) * 0.3)
+    tdir = os.path.join(tcfg["target_dir"], tcfg["model_name"])
+    os.makedirs(tdir, exist_ok=True)
+    teacher.save(os.path.join(tdir, "best-model.pt"))
+    sents = list(cp.corpus.train_list[0])
+    want = {}
+    for s in sents:                       # the teacher's emissions, one sentence at a time
+        em = teacher.forward([s])[0, :len(s)].float().cpu()
+        want[s.to_tokenized_string()] = (torch.softmax(em, -1) if prob else em).numpy()
+    del teacher
+    teachers = cp.create_teachers_list()
+    student = cp.create_student()
+    assert student.distill_emission and student.distill_prob == prob
+    trainer = ModelFinetuner(student, teachers, cp.corpus, config=cp.config, professors=[], **cp.config["ModelFinetuner"])
+    calls = []
+    fb = student.forward_backward
+
+    def spy(data_points, *a, **k):
+        ip = float(k["distill_interpolation"])
+        with torch.no_grad():
+            student.eval()
+            es = student.forward(data_points).float().cpu()
+            student.train()
+        before = (ip, es, list(data_points), student.transitions.float().cpu().clone())
+        out = fb(data_points, *a, **k)
+        calls.append((float(out),) + before)
+        return out
+
+    student.forward_backward = spy
+    out = trainer.train(cp.get_target_path, fuse_accumulation=False, **cp.config["train"])
+    assert trainer.teachers == []
+    worst = 0.0
+    for s in sents:
+        got = s.get_teacher_prediction()
+        ref = want[s.to_tokenized_string()]
+        assert got.shape == ref.shape
+        worst = max(worst, float(np.abs(got - ref).max() / max(1.0, np.abs(ref).max())))
+    # (batched vs one-at-a-time teacher forward: the same kernels on differently padded batches)
+    assert worst < 2e-2, worst
+    # the first micro-batch of the run, before any update: loss == the oracle's on the student's own emissions
+    loss0, ip, es, batch, trans0 = calls[0]
+    assert ip == 0.6
+    B, n, _ = es.shape
+    lens = np.asarray([len(s) for s in batch])
+    teach = np.zeros((B, n, T), np.float32)
+    tags = np.zeros((B, n), np.int64)
+    for b, s in enumerate(batch):
+        teach[b, :len(s)] = s.get_teacher_prediction()
+        tags[b, :len(s)] = [student.tag_dictionary.get_idx_for_item(t.get_tag("ner").value) for t in s]
+    x_idx = student.tag_dictionary.get_idx_for_item("S-X")
+    ref = okd.kd_loss(es, trans0, lens, tags, student.start_idx, student.stop_idx, x_idx, 2.0, ip,
+                      emission=torch.from_numpy(teach), emission_is_prob=prob)
+    print("emission KD first loss", loss0, float(ref), "teacher prediction worst rel", worst, "history", out["train_loss_history"])
+    assert abs(loss0 - float(ref)) <= 5e-3 * abs(float(ref)), (loss0, float(ref))
+    assert out["train_loss_history"][-1] < out["train_loss_history"][0]
+
+
 def ColumnDataLoaderFor(trainer, cp):
     """the training loader ModelFinetuner.train builds (same arguments)"""
     from flair.custom_data_loader import ColumnDataLoader

@@ -656,7 +656,7 @@ def test_kd_teacher_targets_vs_reference_golden(golden_dir):
                     assert np.allclose(mine[fin], want[fin], rtol=1e-5, atol=3e-4) and (mine[~fin] < -1e10).all(), c
 
 
-def _kd_device_case(g, c):
+def _kd_device_case(g, c, assemble=True):
     """one golden case as (emissions, device batch, kd dict) for Tagger.kd_crf_terms; the kd dict is assembled by the product's
     own host code (FastSequenceTagger._kd_batch) from sentences carrying the reference's teacher targets"""
     import tiny_assets
@@ -676,8 +676,10 @@ def _kd_device_case(g, c):
         ctags[b, :len(k)] = tags[b, k]
     db = {"lengths": torch.from_numpy(lens.astype(np.int32)).cuda(), "cfeat_idx": torch.from_numpy(cfeat.reshape(-1)).cuda(),
           "ctags": torch.from_numpy(ctags).cuda(), "clens": torch.from_numpy(clens).cuda()}
-    fake, sents, hb = tiny_assets.kd_golden_batch(g, c)
-    kd = FastSequenceTagger._kd_batch(fake, sents, hb)
+    kd = None
+    if assemble:
+        fake, sents, hb = tiny_assets.kd_golden_batch(g, c)
+        kd = FastSequenceTagger._kd_batch(fake, sents, hb)
     return torch.from_numpy(es).cuda(), db, kd
 
 
@@ -711,6 +713,65 @@ def test_kd_loss_vs_reference_golden(golden_dir):
         assert np.abs(de.cpu().numpy() - ref).max() <= 1e-4 * max(1e-3, np.abs(ref).max()), c
         ref = g["c%d_dtrans" % c]
         assert np.abs(dtr.cpu().numpy() - ref).max() <= 2e-4 * max(1e-3, np.abs(ref).max()), c
+
+
+def test_kd_emission_vs_reference_golden(golden_dir):
+    """the distill_emission term (kbner_emission_kl inside Tagger.kd_crf_terms; teacher rows = scores, probabilities under
+    distill_prob, or the teacher's forward-backward scores next to distill_posterior) + the gold NLL, against
+    FastSequenceTagger.simple_forward_distillation_loss run under autograd by the reference (tests/golden/kd_emission.npz)"""
+    import tiny_assets
+    from flair.models import FastSequenceTagger
+    g = np.load(os.path.join(golden_dir, "kd_emission.npz"))
+    start, stop = int(g["start"]), int(g["stop"])
+    tg = _kd_tagger(g["trans_s"].shape[0], start, stop, g["trans_s"])
+    for c in range(int(g["n_cases"])):
+        em, db, _ = _kd_device_case(g, c, assemble=False)
+        fake, sents, hb = tiny_assets.kd_emission_golden_batch(g, c)
+        kd = FastSequenceTagger._kd_batch(fake, sents, hb)
+        dtr = torch.zeros_like(tg.arena.param("transitions"))
+        loss, de = tg.kd_crf_terms(em, db, kd, float(g["c%d_interpolation" % c]), float(g["c%d_tau" % c]), dtrans=dtr)
+        torch.cuda.synchronize()
+        ref = float(g["c%d_loss" % c])
+        assert abs(float(loss) - ref) <= 5e-5 * max(1.0, abs(ref)), (c, float(loss), ref)
+        ref = g["c%d_des" % c]
+        assert np.abs(de.cpu().numpy() - ref).max() <= 1e-4 * max(1e-3, np.abs(ref).max()), c
+        ref = g["c%d_dtrans" % c]
+        assert np.abs(dtr.cpu().numpy() - ref).max() <= 2e-4 * max(1e-3, np.abs(ref).max()), c
+
+
+@pytest.mark.parametrize("B,n,T,tau,prob", [(32, 40, 29, 4.0, False), (5, 1, 21, 1.0, True), (16, 17, 64, 2.0, False),
+                                            (3, 450, 29, 3.0, True), (128, 386, 29, 1.0, False)])
+def test_emission_kl_vs_oracle(B, n, T, tau, prob):
+    """kbner_emission_kl against the fp64 autograd restatement (oracle/kd.py:emission_term) on ragged random batches: T up to 64
+    (every lane live), one-token sentences, the path's real size (n = 386 / 450 word tokens), probabilities with exact zeros"""
+    from kbner import ops
+    from oracle import kd as okd
+    rng = np.random.default_rng(B * 31 + n)
+    es = (rng.standard_normal((B, n, T)) * 2.0).astype(np.float32)
+    te = (es + rng.standard_normal((B, n, T)) * 1.5).astype(np.float32)
+    if prob:
+        e = np.exp(te - te.max(-1, keepdims=True))
+        te = (e / e.sum(-1, keepdims=True)).astype(np.float32)
+        te[:, :, 0] = 0.0                        # an exact zero probability contributes nothing (torch's kl_div)
+    lens = rng.integers(1, n + 1, size=B)
+    lens[0] = n
+    w = rng.random(B).astype(np.float32)
+    per, d = ops.emission_kl(torch.from_numpy(es).cuda(), torch.from_numpy(te).cuda(), torch.from_numpy(lens.astype(np.int32)).cuda(),
+                             torch.from_numpy(w).cuda(), tau, prob)
+    torch.cuda.synchronize()
+    eo = torch.from_numpy(es).double().requires_grad_(True)
+    mask = okd.lengths_mask(lens, n, torch.float64)
+    tp = torch.from_numpy(te).double() if prob else torch.softmax(torch.from_numpy(te).double() / tau, -1)
+    kl = (torch.nn.functional.kl_div(torch.log_softmax(eo / tau, -1), tp, reduction="none") * mask[:, :, None]).sum((1, 2)) * tau * tau
+    (kl * torch.from_numpy(w).double()).sum().backward()
+    assert np.abs(per.cpu().numpy() - kl.detach().numpy()).max() <= 2e-5 * max(1.0, float(kl.max()))
+    ref = eo.grad.numpy()
+    assert np.abs(d.cpu().numpy() - ref).max() <= 2e-5 * max(1e-3, np.abs(ref).max())
+    valid = np.arange(n)[None, :] < lens[:, None]
+    assert (d.cpu().numpy()[~valid] == 0).all()
+    # and the whole-batch form the loss uses: sum / B == oracle.emission_term
+    tot = okd.emission_term(torch.from_numpy(es).double(), lens, torch.from_numpy(te).double(), tau, prob)
+    assert abs(float(per.sum()) / B - float(tot)) <= 2e-5 * max(1.0, abs(float(tot)))
 
 
 @pytest.mark.parametrize("B,n,T,tau,K", [(32, 40, 29, 4.0, 5), (5, 1, 21, 1.0, 1), (16, 17, 32, 2.0, 3), (3, 150, 29, 3.0, 10)])

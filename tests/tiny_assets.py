@@ -287,7 +287,36 @@ def kd_golden_batch(g, c):
                 s.set_teacher_endscores(g["c%d_t%d_end_score" % (c, t)][b])
         sents.append(s)
     fake = types.SimpleNamespace(tagset_size=T, distill_posterior=posterior, distill_crf=crf, crf_attention=att, distill_exact=exact,
-                                 distill_with_gold=with_gold, exp_score=exp_score,
+                                 distill_with_gold=with_gold, exp_score=exp_score, distill_emission=False, distill_prob=False,
                                  gold_const=float(g["c%d_gold_const" % c]) if with_gold else 1.0)
+    hb = {"row_idx": np.zeros(B * n, np.int32), "tags": tags.astype(np.int32)}
+    return fake, sents, hb
+
+
+def kd_emission_golden_batch(g, c):
+    """one case of tests/golden/kd_emission.npz the same way: the sentences carry what ModelFinetuner.
+    assign_pretrained_teacher_predictions stores (the teacher's emissions, softmax of them under distill_prob, trimmed to the
+    sentence) or, with distill_posterior also on, the teacher's forward-backward scores"""
+    import types
+    import numpy as np
+    from flair.data import Sentence
+    es, lens, tags = g["c%d_es" % c], g["c%d_lens" % c], g["c%d_tags" % c]
+    B, n, T = es.shape
+    prob, posterior = [bool(x) for x in g["c%d_flags" % c]]
+    sents = []
+    for b in range(B):
+        L = int(lens[b])
+        s = Sentence(" ".join("w%d" % i for i in range(L)))
+        for t in range(int(g["c%d_n_teachers" % c])):
+            lg = g["c%d_t%d_logits" % (c, t)][b, :L].astype(np.float64)
+            if prob:
+                e = np.exp(lg - lg.max(-1, keepdims=True))
+                lg = e / e.sum(-1, keepdims=True)
+            s.set_teacher_prediction(lg.astype(np.float32))
+        if posterior:
+            s.set_teacher_posteriors(g["c%d_t0_fb_score" % c][b, :L])
+        sents.append(s)
+    fake = types.SimpleNamespace(tagset_size=T, distill_posterior=posterior, distill_crf=False, crf_attention=False, distill_exact=False,
+                                 distill_with_gold=False, exp_score=False, gold_const=1.0, distill_emission=True, distill_prob=prob)
     hb = {"row_idx": np.zeros(B * n, np.int32), "tags": tags.astype(np.int32)}
     return fake, sents, hb
