@@ -978,7 +978,11 @@ __global__ __launch_bounds__(512, 2) void gemm256f_kernel(const GroupArgs ga) {
   typedef s4v __attribute__((address_space(3))) lds_s4v;
   auto tr2_ = [&](unsigned addr) -> bf16x8 {   // the two transposed 8-byte reads of a k-strided fragment (k rows r and r + 4)
     const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(size_t)addr);
+#if defined(RF_EXP_HALFTR)     /* timing only (wrong operands): one transposed read per fragment instead of two */
+    const s4v hi = lo;
+#else
     const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(size_t)(addr + 4u * 512u));
+#endif
     s8v v;
     v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
     v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
@@ -991,7 +995,11 @@ __global__ __launch_bounds__(512, 2) void gemm256f_kernel(const GroupArgs ga) {
     } else {
       // (block ^ swizzle) << 5 with block = 8 wm + mi: the low three bits of the block are mi, so the row block is an XOR on
       // address bits 5-7 (one VALU instruction per fragment; the k half is an immediate: 32 k rows x 512 B)
+#if defined(RF_EXP_NOXOR)      /* timing only (wrong operands): what do the 16 address XORs of a TN K step cost? */
+      return tr2_(pa0 + (unsigned)mi * 32u + (unsigned)ks * 16384u);
+#else
       return tr2_((pa0 ^ ((unsigned)mi << 5)) + (unsigned)ks * 16384u);
+#endif
     }
   };
   auto fb_ = [&](int ks, int ni) -> bf16x8 {
@@ -1082,7 +1090,9 @@ __global__ __launch_bounds__(512, 2) void gemm256f_kernel(const GroupArgs ga) {
       b0[0] = RF_FB(0, 0);
       a0[0] = RF_FA(0, 0);
       RF_SB();
-      RF_GROUP(a1, b1, 3, b0[1] = RF_FB(0, 1), b0[2] = RF_FB(0, 2), b0[3] = RF_FB(0, 3), a0[1] = RF_FA(0, 1), RF_PB(0), RF_PB(1), RF_PB(2), RF_PB(3))
+      // (B pieces alternate with the fragment reads: the same cycles per step on the NT / NN layouts, -1.7 % on TN, whose 48
+      // transpose reads per step leave no MFMA without a filler -- tools/gemm_clk_ab.sh)
+      RF_GROUP(a1, b1, 3, b0[1] = RF_FB(0, 1), RF_PB(0), b0[2] = RF_FB(0, 2), RF_PB(1), b0[3] = RF_FB(0, 3), RF_PB(2), a0[1] = RF_FA(0, 1), RF_PB(3))
       RF_TAKE_NEXT(t + 1 == nt)
       RF_BODY(false)
     }

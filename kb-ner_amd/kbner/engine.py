@@ -192,6 +192,7 @@ class _Acts:
         self.qkv = [z(Mp, 3 * H) for _ in range(L)]
         self.ctx = [z(Mp, H) for _ in range(L)]
         self.ctx_lo = [None] * L   # O - bf16(O) in bytes, allocated by the first training forward (Engine.ATTN_RESIDUAL)
+        self.infer_graph = None    # Engine.encoder_forward(need_grad=False): static inputs + the captured HIP graph of this shape
         self.lse = [z(B, A, S, dt=F32) for _ in range(L)]
         self.h1 = [z(Mp, H) for _ in range(L)]
         self.x1 = [z(Mp, H) for _ in range(L)]
@@ -378,7 +379,47 @@ class Tagger:
             ops.gemm(layout, A, W, Mp, N, K, C=C, bias=bias, addend=addend, epi=epi, drop=drop, occupancy=True)
 
     # ---------------------------------------------------------------- encoder
+    # Forward-only passes (evaluate, predict, the frozen encoders of a stack) are ~170 launches of ~50 us of Python + ctypes each:
+    # 9.7 ms of host time per batch of 32 next to 11.8 ms of device time -- device-bound by a narrow margin on a fast host,
+    # host-bound on a slower one (the driver's round-3 box: 1154 instead of 2400-2700 sentences/s).  Nothing in such a pass
+    # depends on the host (no dropout seeds, fixed shapes, buffers that live as long as the (B, S) activation set), so the third
+    # pass over a shape is captured into a HIP graph and every later one is three small input copies + ONE graph launch.
+    # KBNER_INFER_GRAPH=0 keeps the eager launches (A/B).
+    INFER_GRAPH = os.environ.get("KBNER_INFER_GRAPH", "1") != "0"
+
     def encoder_forward(self, ids, pos_ids, maskbias, B, S, need_grad=True):
+        if (need_grad or not self.INFER_GRAPH or self.training or self.dynamic_tiles or ops.GEMM_HOOK is not None
+                or self.device.type != "cuda"):
+            return self._encoder_forward(ids, pos_ids, maskbias, B, S, need_grad)
+        ac = self.acts(B, S)
+        st = ac.infer_graph
+        if st is None:
+            st = ac.infer_graph = {"calls": 0, "graph": None, "ids": torch.empty_like(ids), "pos": torch.empty_like(pos_ids),
+                                   "mb": torch.empty_like(maskbias), "variant": ops.gemm_variant()}
+        if (st["ids"].shape != ids.shape or st["mb"].shape != maskbias.shape or st["variant"] != ops.gemm_variant()
+                or torch.cuda.is_current_stream_capturing()):
+            return self._encoder_forward(ids, pos_ids, maskbias, B, S, False)
+        st["ids"].copy_(ids)
+        st["pos"].copy_(pos_ids)
+        st["mb"].copy_(maskbias)
+        if st["graph"] is None:
+            st["calls"] += 1
+            if st["calls"] < 3:   # two eager passes first: every kernel's one-time attribute call and workspace allocation is behind us
+                return self._encoder_forward(st["ids"], st["pos"], st["mb"], B, S, False)
+            g = torch.cuda.CUDAGraph()
+            prev = L_._stream_cached
+            try:
+                with torch.cuda.graph(g):
+                    L_._stream_cached = L_.c_void_p(torch.cuda.current_stream().cuda_stream)   # the capture stream
+                    st["out"] = self._encoder_forward(st["ids"], st["pos"], st["mb"], B, S, False)
+            finally:
+                L_._stream_cached = prev
+            st["graph"] = g
+        self._enc_saved = None
+        st["graph"].replay()
+        return st["out"]
+
+    def _encoder_forward(self, ids, pos_ids, maskbias, B, S, need_grad=True):
         """ids/pos_ids i32[Mp], maskbias f32[B,S] -> last hidden state bf16 [Mp,H] (rows >= B*S are padding).
         need_grad=False (inference: evaluate, the frozen encoders of an embedding stack) runs the FFN-up epilogue without the
         gelu' output that only encoder_backward reads; a backward after such a forward fails loudly."""

@@ -303,6 +303,32 @@ def test_encoder_d64_three_layers_vs_hf_golden(golden_dir):
         assert torch.equal(keep[l], ac.x[l]), l
     with pytest.raises(RuntimeError):
         tg.encoder_backward(torch.zeros_like(ac.x[L]))
+    # ... and from the third forward-only pass over a shape on it is ONE replayed HIP graph (Tagger.INFER_GRAPH): same bits, on
+    # other inputs too, and it follows the weights (they are read through the arena's pointers, not baked in)
+    assert ac.infer_graph is not None and ac.infer_graph["graph"] is None
+    for _ in range(3):
+        tg.encoder_forward(bd["ids"], bd["pos_ids"], bd["maskbias"], b["B"], b["S"], need_grad=False)
+    torch.cuda.synchronize()
+    assert ac.infer_graph["graph"] is not None
+    for l in range(L + 1):
+        assert torch.equal(keep[l], ac.x[l]), l
+    ids2 = bd["ids"].clone()
+    ids2[:S0] = torch.flip(bd["ids"][:S0], (0,))
+    tg.encoder_forward(ids2, bd["pos_ids"], bd["maskbias"], b["B"], b["S"], need_grad=False)
+    torch.cuda.synchronize()
+    replayed = ac.x[L].clone()
+    assert not torch.equal(replayed, keep[L])
+    tg._encoder_forward(ids2, bd["pos_ids"], bd["maskbias"], b["B"], b["S"], False)
+    torch.cuda.synchronize()
+    assert torch.equal(replayed, ac.x[L])
+    tg.arena.param("l0.qkv.bias").add_(0.25)
+    tg._encoder_forward(ids2, bd["pos_ids"], bd["maskbias"], b["B"], b["S"], False)
+    torch.cuda.synchronize()
+    eager = ac.x[L].clone()
+    assert not torch.equal(eager, replayed)
+    tg.encoder_forward(ids2, bd["pos_ids"], bd["maskbias"], b["B"], b["S"], need_grad=False)
+    torch.cuda.synchronize()
+    assert torch.equal(eager, ac.x[L])
 
 
 def test_full_step_vs_oracle(st):

@@ -12,7 +12,7 @@ M, N, K = 65536, 4096, 1024
 x = (torch.randn(M, K, device=dev) * 0.5).to(BF); W = (torch.randn(N, K, device=dev) * 0.5).to(BF)
 C = torch.empty(M, N, device=dev, dtype=BF); P = torch.empty(M, N, device=dev, dtype=BF); b = torch.randn(N, device=dev)
 import os
-VAR = [int(v) for v in os.environ.get("TRACE_VARIANTS", "0,1").split(",")]
+VAR = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else os.environ.get("TRACE_VARIANTS", "0,1")).split(",")]
 from kbner.lib import EPI_ADD
 add = (torch.randn(M, N, device=dev)).to(BF)
 for var in VAR:
