@@ -205,7 +205,8 @@ def main():
     # single 2.24 GB all-reduce for A/B.
     reducer = None
     if world > 1 or args.dynamic_tiles:
-        tg.dynamic_tiles = not args.static_tiles
+        # N > 1: dynamic from the first bucket's all-reduce to the end of backward; --dynamic-tiles (the N = 1 A/B): every launch
+        tg.dynamic_tiles = False if args.static_tiles else ("always" if args.dynamic_tiles else True)
     if world > 1:
         from kbner import dp
         a = tg.arena

@@ -255,7 +255,10 @@ class Tagger:
         self.word_dropout = 0.0
         self.seed_dropout(20220711)
         # data-parallel runs: the persistent GEMM draws its tiles dynamically (kbner_gemm_bf16_grouped_dyn) so that CUs taken
-        # by an overlapped RCCL collective cost their share of the launch, not a second pass; off for a single process
+        # by an overlapped RCCL collective cost their share of the launch, not a second pass; off for a single process.
+        # True: from the moment a micro-batch's first gradient bucket is handed to the reducer (encoder_backward) to the end of
+        # its backward pass -- the forward pass and the first WGRAD_GROUP layers of backward stay static launches, i.e. the
+        # interleaved-ring loop; "always": every GEMM launch (bench.py --dynamic-tiles, the N = 1 A/B)
         self.dynamic_tiles = False
         self._sched_ring = None
 
@@ -388,7 +391,7 @@ class Tagger:
     INFER_GRAPH = os.environ.get("KBNER_INFER_GRAPH", "1") != "0"
 
     def encoder_forward(self, ids, pos_ids, maskbias, B, S, need_grad=True):
-        if (need_grad or not self.INFER_GRAPH or self.training or self.dynamic_tiles or ops.GEMM_HOOK is not None
+        if (need_grad or not self.INFER_GRAPH or self.training or ops.SCHED_RING is not None or ops.GEMM_HOOK is not None
                 or self.device.type != "cuda"):
             return self._encoder_forward(ids, pos_ids, maskbias, B, S, need_grad)
         ac = self.acts(B, S)
@@ -521,6 +524,7 @@ class Tagger:
                     lo_off = a.offsets["l%d.qkv.weight" % l]
                     hi_off = a.offsets["l%d.qkv.weight" % hi_l] if hi_l < L else a.offsets["emb.word"]
                     grad_ready(lo_off, hi_off)
+                    ops.sched_active(True)   # a collective is in flight from here to the end of this backward pass
             dx = ac.dx
         ops.embed_ln_bwd(dx, ac.h0, ac.emb_mean, ac.emb_rstd, a.param("emb.ln.g"), ids, pos_ids, a.grad("emb.ln.g"),
                          a.grad("emb.ln.b"), a.grad("emb.word"), a.grad("emb.pos"), a.grad("emb.type")[0], drop=d_emb)
@@ -562,7 +566,8 @@ class Tagger:
             if self._sched_ring is None:
                 self._sched_ring = torch.zeros((512, 8), dtype=I32, device=self.device)
             self._sched_ring.zero_()     # one memset per micro-batch covers its ~200 GEMM launches
-            ops.sched_ring_reset(self._sched_ring)
+            # dynamic_tiles True: from the first gradient bucket's all-reduce on (encoder_backward); "always": every launch (A/B)
+            ops.sched_ring_reset(self._sched_ring, active=(self.dynamic_tiles == "always"))
             try:
                 return fn(*args)
             finally:

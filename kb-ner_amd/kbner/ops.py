@@ -339,13 +339,22 @@ GEMM_HOOK = None  # bench.py sets this to a list to time every GEMM launch with 
 # Dynamic tile scheduling of the 256x256 kernel (data-parallel steps, see include/kbner.h): a ring of 8-int counter slots,
 # int32 [slots, 8], zeroed by its owner (the engine, once per micro-batch); every grouped launch takes the next slot.
 SCHED_RING = None
+SCHED_ACTIVE = True   # with a ring installed: draw tiles dynamically NOW (sched_active); False = static launches for the moment
 _sched_pos = 0
 
 
-def sched_ring_reset(ring):
+def sched_ring_reset(ring, active=True):
     """make `ring` (or None) the current scheduler ring; the caller has zeroed it on the current stream"""
-    global SCHED_RING, _sched_pos
-    SCHED_RING, _sched_pos = ring, 0
+    global SCHED_RING, SCHED_ACTIVE, _sched_pos
+    SCHED_RING, SCHED_ACTIVE, _sched_pos = ring, bool(active), 0
+
+
+def sched_active(on):
+    """data-parallel steps: the GEMMs of a micro-batch draw their tiles dynamically only from the moment its first gradient
+    bucket's all-reduce is enqueued (CUs may then be held by RCCL's kernels); before that they are static launches, which take the
+    faster interleaved-ring loop (the dynamic draw exists in the two-stage loop only)"""
+    global SCHED_ACTIVE
+    SCHED_ACTIVE = bool(on)
 
 
 def _addr(t):
@@ -385,7 +394,7 @@ def gemm_grouped(layout, problems):
         ev0.record()
     global _sched_pos
     ring = SCHED_RING
-    if ring is not None and _sched_pos < ring.shape[0]:
+    if ring is not None and SCHED_ACTIVE and _sched_pos < ring.shape[0]:
         slot = c_void_p(ring.data_ptr() + 32 * _sched_pos)
         _sched_pos += 1
         L.call("kbner_gemm_bf16_grouped_dyn", layout, n, ctypes.cast(arr, ctypes.c_void_p), slot, stream_ptr())
