@@ -492,7 +492,7 @@ static __device__ __forceinline__ void flush_colsum(f4v (&acc)[4], float (*red)[
 // contains the dropped probabilities through O).
 // It also produces D[b,h,q] = rowdot(dO, O) (the softmax-backward correction) for its own queries from the dO / O
 // fragments it already needs, and writes it for the dK/dV kernel that runs next: no separate row-dot pass.
-template <bool DROP>
+template <bool DROP, bool RES>
 __global__ __launch_bounds__(AT_NWB * 64) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dctx,
                                                              const bf16_t* __restrict__ ctx, const uint8_t* __restrict__ ctx_lo,
                                                              const float* __restrict__ maskbias, const float* __restrict__ lse,
@@ -540,8 +540,11 @@ __global__ __launch_bounds__(AT_NWB * 64) void attn_bwd_dq_kernel(const bf16_t* 
     const size_t sidx = ((size_t)b * A + h) * S + q0 + li;
     const float l_q = lse[sidx] * 1.4426950408889634f;  // log2 domain
     // D = sum_d dO[q,d] O[q,d]: each lane group g holds 16 of the 64 d of row q0+li in its two fragments
-    float d_part = dot8(do0, glb_frag(ob, H, q0, 0, lane)) + dot8(do1, glb_frag(ob, H, q0, 1, lane));
-    if (ctx_lo) d_part += res_dot16(do0, do1, at_res_block(ctx_lo, b, A, h, S, q0), lane);   // the residual of O
+    const bf16x8 of0 = glb_frag(ob, H, q0, 0, lane), of1 = glb_frag(ob, H, q0, 1, lane);
+    uint32_t rw[4];
+    if (RES) res_words(at_res_block(ctx_lo, b, A, h, S, q0), lane, rw);
+    float d_part = dot8(do0, of0) + dot8(do1, of1);
+    if (RES) d_part += res_dot16(do0, do1, rw);   // the residual of O
     const float d_true = group4_sum(d_part);
     if (g == 0) Dv[sidx] = d_true;
     // dropout: dS = (1 / (1-p)) P (m dP - (1-p) D) -- the 1 / (1-p) leaves through the final dQ scale (see attn_bwd_dq2_kernel)
@@ -803,7 +806,11 @@ static __device__ __forceinline__ int stage_mask_klen(const float* __restrict__ 
   return klen;
 }
 
-template <bool DROP>
+// RES: ctx_lo is given.  A template parameter, not a run-time test: behind `if (ctx_lo)` the residual loads could not be issued
+// with the pass's other loads and their HBM latency came on top of the O fragments' (in situ, where nothing of ctx_lo is cached,
+// the kernel ran 375 us per layer against 337 without the residual; the lab, whose buffers stay in the memory-side cache, had
+// shown +8 us)
+template <bool DROP, bool RES>
 __global__ __launch_bounds__(512) void attn_bwd_dq2_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dctx,
                                                           const bf16_t* __restrict__ ctx, const uint8_t* __restrict__ ctx_lo,
                                                           const float* __restrict__ maskbias,
@@ -852,18 +859,29 @@ __global__ __launch_bounds__(512) void attn_bwd_dq2_kernel(const bf16_t* __restr
     float l_q[2], d_q[2];
     uint32_t rk[2];
     f4v dq[2][4];
+    bf16x8 of[2][2];
+    uint32_t rw[2][4];
+    float lse_q[2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < 2; ++j) {   // every load of the pass first, so that their latencies overlap
       const int qj = q0 + j * 16;
       qf[j][0] = glb_frag(base, ld, qj, 0, lane);
       qf[j][1] = glb_frag(base, ld, qj, 1, lane);
       dof[j][0] = glb_frag(dob, H, qj, 0, lane);
       dof[j][1] = glb_frag(dob, H, qj, 1, lane);
+      of[j][0] = glb_frag(ob, H, qj, 0, lane);
+      of[j][1] = glb_frag(ob, H, qj, 1, lane);
+      if (RES) res_words(at_res_block(ctx_lo, b, A, h, S, qj), lane, rw[j]);
+      lse_q[j] = lse[((size_t)b * A + h) * S + qj + li];
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int qj = q0 + j * 16;
       const size_t sidx = ((size_t)b * A + h) * S + qj + li;
-      l_q[j] = -lse[sidx] / scale;   // accumulator init of the score MFMAs: exp2(scale2 * (q.k + mask/scale - lse/scale))
-      float d_part = dot8(dof[j][0], glb_frag(ob, H, qj, 0, lane)) + dot8(dof[j][1], glb_frag(ob, H, qj, 1, lane));
-      if (ctx_lo)   // the residual O - bf16(O) the forward kept: D to ~12 bits of O (see kbner_attn_bwd)
-        d_part += res_dot16(dof[j][0], dof[j][1], at_res_block(ctx_lo, b, A, h, S, qj), lane);
+      l_q[j] = -lse_q[j] / scale;   // accumulator init of the score MFMAs: exp2(scale2 * (q.k + mask/scale - lse/scale))
+      float d_part = dot8(dof[j][0], of[j][0]) + dot8(dof[j][1], of[j][1]);
+      if (RES)   // the residual O - bf16(O) the forward kept: D to ~12 bits of O (see kbner_attn_bwd)
+        d_part += res_dot16(dof[j][0], dof[j][1], rw[j]);
       d_q[j] = group4_sum(d_part);
       if (g == 0) Dv[sidx] = d_q[j];
       // with dropout dS = P (m dP / (1-p) - D) = (1 / (1-p)) P (m dP - (1-p) D): the 1 / (1-p) moves to the final dQ scale and the
@@ -1201,11 +1219,12 @@ static int launch_attn_fwd(const bf16_t* qkv, const float* maskbias, bf16_t* ctx
   return launch_attn_fwd2<NKB, false>(qkv, maskbias, ctx, ctx_lo, lse, B, H, A, rpw, seed, thresh, stream, rows32);
 }
 
-template <bool DROP>
-static int launch_attn_bwd(const bf16_t* qkv, const bf16_t* ctx, const uint8_t* ctx_lo, const bf16_t* dctx, const float* maskbias, const float* lse, float* Dws,
-                           bf16_t* dqkv, int B, int S, int H, int A, uint32_t seed, uint32_t thresh, float* dbias, hipStream_t s) {
+template <bool DROP, bool RES>
+static int launch_attn_bwd2(const bf16_t* qkv, const bf16_t* ctx, const uint8_t* ctx_lo, const bf16_t* dctx, const float* maskbias,
+                            const float* lse, float* Dws, bf16_t* dqkv, int B, int S, int H, int A, uint32_t seed, uint32_t thresh,
+                            float* dbias, hipStream_t s) {
   static std::atomic<unsigned long long> done0{0}, done1{0}, done2{0}, done3{0};   // one bit per device (common.h)
-  int r = kbner_set_max_lds_once(done0, reinterpret_cast<const void*>(attn_bwd_dq_kernel<DROP>), AT_LDS_BYTES);
+  int r = kbner_set_max_lds_once(done0, reinterpret_cast<const void*>(attn_bwd_dq_kernel<DROP, RES>), AT_LDS_BYTES);
   if (r) return r;
   r = kbner_set_max_lds_once(done1, reinterpret_cast<const void*>(attn_bwd_dkv_kernel<DROP>), AT_LDS_BYTES);
   if (r) return r;
@@ -1214,25 +1233,30 @@ static int launch_attn_bwd(const bf16_t* qkv, const bf16_t* ctx, const uint8_t* 
   const dim3 grid((S + rpw - 1) / rpw, A, B);
   // 32-row-stationary kernels whenever a workgroup's row tile gives each of its 8 waves whole 32-row passes
   if (rpw % 256 == 0 && S % 32 == 0) {
-    r = kbner_set_max_lds_once(done2, reinterpret_cast<const void*>(attn_bwd_dq2_kernel<DROP>), AT_LDS_BYTES);
+    r = kbner_set_max_lds_once(done2, reinterpret_cast<const void*>(attn_bwd_dq2_kernel<DROP, RES>), AT_LDS_BYTES);
     if (r) return r;
     r = kbner_set_max_lds_once(done3, reinterpret_cast<const void*>(attn_bwd_dkv2_kernel<DROP>), AT_LDS_BYTES);
     if (r) return r;
-    hipLaunchKernelGGL(attn_bwd_dq2_kernel<DROP>, grid, dim3(512), AT_LDS_BYTES, s, qkv, dctx, ctx, ctx_lo, maskbias, lse, Dws, dqkv, S,
-                       H, A,
-                       0.125f, rpw, seed, thresh, dbias);
+    hipLaunchKernelGGL((attn_bwd_dq2_kernel<DROP, RES>), grid, dim3(512), AT_LDS_BYTES, s, qkv, dctx, ctx, ctx_lo, maskbias, lse, Dws,
+                       dqkv, S, H, A, 0.125f, rpw, seed, thresh, dbias);
     hipLaunchKernelGGL(attn_bwd_dkv2_kernel<DROP>, grid, dim3(512), AT_LDS_BYTES, s, qkv, dctx, maskbias, lse, Dws, dqkv, S, H, A,
                        0.125f, rpw, seed, thresh, dbias);
     hipError_t e2 = hipGetLastError();
     return e2 == hipSuccess ? 0 : -(int)e2;
   }
-  hipLaunchKernelGGL(attn_bwd_dq_kernel<DROP>, grid, dim3(AT_NWB * 64), AT_LDS_BYTES, s, qkv, dctx, ctx, ctx_lo, maskbias, lse, Dws, dqkv, S,
-                       H, A,
-                     0.125f, rpw, seed, thresh, dbias);
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<DROP, RES>), grid, dim3(AT_NWB * 64), AT_LDS_BYTES, s, qkv, dctx, ctx, ctx_lo, maskbias, lse,
+                     Dws, dqkv, S, H, A, 0.125f, rpw, seed, thresh, dbias);
   hipLaunchKernelGGL(attn_bwd_dkv_kernel<DROP>, grid, dim3(AT_NWB * 64), AT_LDS_BYTES, s, qkv, dctx, maskbias, lse, Dws, dqkv, S, H, A,
                      0.125f, rpw, seed, thresh, dbias);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
+}
+template <bool DROP>
+static int launch_attn_bwd(const bf16_t* qkv, const bf16_t* ctx, const uint8_t* ctx_lo, const bf16_t* dctx, const float* maskbias,
+                           const float* lse, float* Dws, bf16_t* dqkv, int B, int S, int H, int A, uint32_t seed, uint32_t thresh,
+                           float* dbias, hipStream_t s) {
+  if (ctx_lo) return launch_attn_bwd2<DROP, true>(qkv, ctx, ctx_lo, dctx, maskbias, lse, Dws, dqkv, B, S, H, A, seed, thresh, dbias, s);
+  return launch_attn_bwd2<DROP, false>(qkv, ctx, ctx_lo, dctx, maskbias, lse, Dws, dqkv, B, S, H, A, seed, thresh, dbias, s);
 }
 
 // round-3 kernels (attention3.hip): same contracts as the entry points below

@@ -126,24 +126,30 @@ static __device__ __forceinline__ uint8_t* at_res_block(uint8_t* base, int b, in
 static __device__ __forceinline__ const uint8_t* at_res_block(const uint8_t* base, int b, int A, int h, int S, int q) {
   return base + (((size_t)(b * A + h) * (S >> 4) + (q >> 4)) << 10);
 }
-// sum_d dO[row][d] * residual[row][d] over this lane's 16 d (the two glb_frag fragments of a row: d = ks*32 + g*8 + e): element e of
-// fragment ks is byte e%4 of word db = ks*2 + g/2 of forward lane (g' = (g%2)*2 + e/4, li)
-static __device__ __forceinline__ float res_dot16(const bf16x8 do0, const bf16x8 do1, const uint8_t* __restrict__ blk, int lane) {
+// this lane's residual words for the two glb_frag fragments of a row (d = ks*32 + g*8 + e): element e of fragment ks is byte e%4 of
+// word db = ks*2 + g/2 of forward lane (g' = (g%2)*2 + e/4, li) -> w[0], w[1] = fragment 0 (e 0..3, 4..7), w[2], w[3] = fragment 1
+static __device__ __forceinline__ void res_words(const uint8_t* __restrict__ blk, int lane, uint32_t (&w)[4]) {
   const int g = lane >> 4, li = lane & 15;
-  const uint32_t* w = reinterpret_cast<const uint32_t*>(blk + ((((g & 1) * 2) * 16 + li) << 4)) + (g >> 1);
-  const uint32_t a0 = w[0], b0 = w[64], a1 = w[2], b1 = w[66];   // (ks 0: g', g'+1), (ks 1: g', g'+1); +64 words = 16 lanes on
+  const uint32_t* p = reinterpret_cast<const uint32_t*>(blk + ((((g & 1) * 2) * 16 + li) << 4)) + (g >> 1);
+  w[0] = p[0];
+  w[1] = p[64];   // + 16 lanes
+  w[2] = p[2];
+  w[3] = p[66];
+}
+// sum_d dO[row][d] * residual[row][d] over this lane's 16 d
+static __device__ __forceinline__ float res_dot16(const bf16x8 do0, const bf16x8 do1, const uint32_t (&w)[4]) {
   const s8v x0 = __builtin_bit_cast(s8v, do0), x1 = __builtin_bit_cast(s8v, do1);
   auto f = [](const s8v& x, int e) { return __uint_as_float(((uint32_t)(uint16_t)x[e]) << 16); };
   float acc = 0.0f;
   f2v r;
-  r = __builtin_amdgcn_cvt_pk_f32_bf8((int)a0, false); acc += f(x0, 0) * r[0] + f(x0, 1) * r[1];
-  r = __builtin_amdgcn_cvt_pk_f32_bf8((int)a0, true);  acc += f(x0, 2) * r[0] + f(x0, 3) * r[1];
-  r = __builtin_amdgcn_cvt_pk_f32_bf8((int)b0, false); acc += f(x0, 4) * r[0] + f(x0, 5) * r[1];
-  r = __builtin_amdgcn_cvt_pk_f32_bf8((int)b0, true);  acc += f(x0, 6) * r[0] + f(x0, 7) * r[1];
-  r = __builtin_amdgcn_cvt_pk_f32_bf8((int)a1, false); acc += f(x1, 0) * r[0] + f(x1, 1) * r[1];
-  r = __builtin_amdgcn_cvt_pk_f32_bf8((int)a1, true);  acc += f(x1, 2) * r[0] + f(x1, 3) * r[1];
-  r = __builtin_amdgcn_cvt_pk_f32_bf8((int)b1, false); acc += f(x1, 4) * r[0] + f(x1, 5) * r[1];
-  r = __builtin_amdgcn_cvt_pk_f32_bf8((int)b1, true);  acc += f(x1, 6) * r[0] + f(x1, 7) * r[1];
+  r = __builtin_amdgcn_cvt_pk_f32_bf8((int)w[0], false); acc += f(x0, 0) * r[0] + f(x0, 1) * r[1];
+  r = __builtin_amdgcn_cvt_pk_f32_bf8((int)w[0], true);  acc += f(x0, 2) * r[0] + f(x0, 3) * r[1];
+  r = __builtin_amdgcn_cvt_pk_f32_bf8((int)w[1], false); acc += f(x0, 4) * r[0] + f(x0, 5) * r[1];
+  r = __builtin_amdgcn_cvt_pk_f32_bf8((int)w[1], true);  acc += f(x0, 6) * r[0] + f(x0, 7) * r[1];
+  r = __builtin_amdgcn_cvt_pk_f32_bf8((int)w[2], false); acc += f(x1, 0) * r[0] + f(x1, 1) * r[1];
+  r = __builtin_amdgcn_cvt_pk_f32_bf8((int)w[2], true);  acc += f(x1, 2) * r[0] + f(x1, 3) * r[1];
+  r = __builtin_amdgcn_cvt_pk_f32_bf8((int)w[3], false); acc += f(x1, 4) * r[0] + f(x1, 5) * r[1];
+  r = __builtin_amdgcn_cvt_pk_f32_bf8((int)w[3], true);  acc += f(x1, 6) * r[0] + f(x1, 7) * r[1];
   return acc * (1.0f / KBNER_RES8_SCALE);
 }
 
