@@ -109,11 +109,11 @@ class _RoundBf16(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, t):
-        return t.to(torch.bfloat16).to(torch.float32)
+        return t.to(torch.bfloat16).to(t.dtype)
 
     @staticmethod
     def backward(ctx, g):
-        return g.to(torch.bfloat16).to(torch.float32)
+        return g.to(torch.bfloat16).to(g.dtype)
 
 
 def round_bf16(t):
@@ -122,7 +122,7 @@ def round_bf16(t):
 
 def round_bf16_weight(w):
     """the bf16 shadow of an fp32 master weight: rounded value forward, fp32 gradient (straight through) backward"""
-    return w + (w.to(torch.bfloat16).to(torch.float32) - w).detach()
+    return w + (w.to(torch.bfloat16).to(w.dtype) - w).detach()
 
 
 class _AttnCoreFlash(torch.autograd.Function):
@@ -134,10 +134,12 @@ class _AttnCoreFlash(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, q, k, v, ext, mult, o_split):
+        """o_split: False / True as above; "exact" = no rounding anywhere (the self-check of these backward formulas against
+        autograd, tests/test_oracle_golden.py)"""
         d = q.shape[-1]
         p = torch.softmax(torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(d) + ext, dim=-1)
         pm = p if mult is None else p * mult
-        pb = pm.to(torch.bfloat16).to(torch.float32)
+        pb = pm if o_split == "exact" else pm.to(torch.bfloat16).to(q.dtype)
         o = torch.matmul(pb, v)
         ctx.save_for_backward(q, k, v, p, pb, o, mult if mult is not None else torch.tensor(0.0))
         ctx.has_mult, ctx.o_split = mult is not None, o_split
@@ -147,10 +149,10 @@ class _AttnCoreFlash(torch.autograd.Function):
     def backward(ctx, do):
         q, k, v, p, pb, o, mult = ctx.saved_tensors
         d = q.shape[-1]
-        rb = lambda t: t.to(torch.bfloat16).to(torch.float32)   # noqa: E731
+        rb = (lambda t: t) if ctx.o_split == "exact" else (lambda t: t.to(torch.bfloat16).to(q.dtype))   # noqa: E731
         o_st = rb(o)
-        if ctx.o_split:
-            o_st = o_st + ((o - o_st) * 16384.0).to(torch.float8_e5m2).to(torch.float32) / 16384.0
+        if ctx.o_split is True:
+            o_st = o_st + ((o - o_st) * 16384.0).to(torch.float32).to(torch.float8_e5m2).to(o.dtype) / 16384.0
         dd = (do * o_st).sum(-1, keepdim=True)
         dp = torch.matmul(do, v.transpose(-1, -2))
         if ctx.has_mult:
@@ -176,8 +178,8 @@ def encoder_forward(params, cfg, input_ids, attention_mask, return_all=False, ma
     # wherever the HIP path stores bf16 -- GEMM weights (shadow), every activation tensor between kernels (and, through autograd,
     # the gradient that comes back through it), the attention probabilities fed to P.V -- and nowhere else (fp32 accumulation,
     # fp32 LayerNorm statistics, fp32 softmax as in the kernels)
-    r = round_bf16 if bf16_points else (lambda t: t)
-    rw = round_bf16_weight if bf16_points else (lambda w: w)
+    r = round_bf16 if bf16_points and bf16_points != "flash_exact" else (lambda t: t)
+    rw = round_bf16_weight if bf16_points and bf16_points != "flash_exact" else (lambda w: w)
     H, A = cfg.hidden_size, cfg.num_attention_heads
     d = H // A
     B, S = input_ids.shape
@@ -198,8 +200,9 @@ def encoder_forward(params, cfg, input_ids, attention_mask, return_all=False, ma
         q = q.view(B, S, A, d).transpose(1, 2)
         k = k.view(B, S, A, d).transpose(1, 2)
         v = v.view(B, S, A, d).transpose(1, 2)
-        if bf16_points in ("flash", "flash_split"):    # + the backward formulas of the attention kernels (see _AttnCoreFlash)
-            c = _AttnCoreFlash.apply(q, k, v, ext, masks.get(("attn", i)), bf16_points == "flash_split")
+        if bf16_points in ("flash", "flash_split", "flash_exact"):    # + the backward formulas of the attention kernels (see _AttnCoreFlash)
+            c = _AttnCoreFlash.apply(q, k, v, ext, masks.get(("attn", i)),
+                                     "exact" if bf16_points == "flash_exact" else bf16_points == "flash_split")
             c = r(c.transpose(1, 2).reshape(B, S, H))
         else:
             sc = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(d) + ext

@@ -50,7 +50,7 @@ def tagger_forward_loss(params, cfg, batch, start, stop, x_idx, masks=None, word
     mask (flair/nn.py:176-183: one Bernoulli per token position shared by the whole batch, no rescale)."""
     hidden = enc.encoder_forward(params, cfg, batch["input_ids"], batch["attention_mask"], masks=masks, bf16_points=bf16_points)
     pooled = enc.gather_first_subtoken(hidden, batch["first_idx"], batch.get("first_row"))
-    if bf16_points:   # the pooled rows are a bf16 tensor on the HIP path; the head runs in fp32
+    if bf16_points and bf16_points != "flash_exact":   # the pooled rows are a bf16 tensor on the HIP path; the head runs in fp32
         pooled = enc.round_bf16(pooled)
     if word_keep is not None:
         pooled = pooled * word_keep.to(pooled.dtype)[None, :, None]
