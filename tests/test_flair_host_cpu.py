@@ -432,3 +432,36 @@ def test_kd_batch_assembly_emission_reproduces_the_reference_loss():
                            stop, x_idx, float(g["c%d_tau" % c]), float(g["c%d_interpolation" % c]), **kw)
         ref = float(g["c%d_loss" % c])
         assert abs(float(loss) - ref) <= 3e-5 * max(1.0, abs(ref)), (c, float(loss), ref)
+
+
+def test_distill_emission_switch_combinations():
+    """the emission-level KD switches are accepted for a CRF student where the reference's loss is defined, and refused with the
+    reason where it is not (checked before any device work): next to distill_crf / distill_exact the reference's trainer stores
+    n-best / pairwise targets only and its loss then stacks empty prediction lists (sequence_tagger_model.py:2358); the multi-view
+    loss has no emission term"""
+    from flair.data import Dictionary
+    from flair.models import FastSequenceTagger
+    from flair.trainers import ModelFinetuner
+    td = Dictionary(add_unk=True)
+    for t in ("O", "B-X", "S-X", "<START>", "<STOP>"):
+        td.add_item(t)
+    base = dict(hidden_size=8, embeddings=None, tag_dictionary=td, tag_type="ner", use_crf=True, use_rnn=False)
+    with pytest.raises(ValueError, match="needs distill_posterior"):
+        FastSequenceTagger(distill_emission=True, distill_crf=True, **base)
+    with pytest.raises(ValueError, match="needs distill_posterior"):
+        FastSequenceTagger(distill_emission=True, distill_exact=True, **base)
+    with pytest.raises(NotImplementedError, match="multi_view_training"):
+        FastSequenceTagger(distill_emission=True, multi_view_training=True, distill_posterior=True, remove_x=True, **base)
+    with pytest.raises(NotImplementedError, match="use_rnn: false"):
+        FastSequenceTagger(distill_emission=True, **dict(base, use_rnn=True))
+    # the trainer's gate: a CRF student in distill_mode needs one of the KD switches, distill_emission now among them
+    import types
+    student = types.SimpleNamespace(distill_crf=False, distill_exact=False, distill_posterior=False, distill_emission=False,
+                                    multi_view_training=False)
+    teacher = types.SimpleNamespace(eval=lambda: None)
+    with pytest.raises(NotImplementedError, match="distill_emission"):
+        ModelFinetuner(student, [teacher], corpus=None, distill_mode=True)
+    student.distill_emission = True
+    tr = ModelFinetuner(student, [teacher], corpus=None, distill_mode=True)
+    assert tr.distill_mode and tr.teachers == [teacher]
+
