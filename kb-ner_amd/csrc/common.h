@@ -143,9 +143,8 @@ static __device__ __forceinline__ void gelu_half_erf2(f2v x, f2v ax, f2v& h, f2v
 //     Phi(x) ~= s(x) = 1 / (1 + exp(-(x (p0 + p1 x^2 + p2 x^4))))        gelu = x s,   gelu' = s + x s (1 - s) (p0 + 3 p1 x^2 + 5 p2 x^4)
 // p fitted (minimax) to |gelu error| <= 3.8e-5 and |gelu' error| <= 9.3e-5 in fp32, 11 packed fp32 operations + 2 v_exp + 2 v_rcp per
 // element PAIR instead of 17 + 4.  Measured on one box, alternating processes: 945.1 / 945.1 sentences/s against 945.0 / 943.0 with
-// the erf series -- the GELU epilogues are bound by their stores, not by their VALU work -- while the fit's error,
-// unlike bf16 rounding, has the same sign for every element of a region of x and shows in aggregates: the gradient norm of
-// tests/selftest.py check_train_steps moves from 1.4e-4 to 5.4e-4 relative to the oracle's.  No speed for less accuracy: rejected.
+// the erf series -- 4 of the ~30 vector instructions per element pair of an epilogue that is one of nine GEMMs: 0.3 %
+// of the step, inside the noise.  No measurable speed for a 250 times larger error: rejected.
 // x^2 is clamped at 36: beyond |x| = 6 the fit's polynomial is not monotone, s is 0 / 1 to 1e-9 there.
 #define KBNER_GELU_P0 1.59484492f
 #define KBNER_GELU_P1 7.40112029e-02f

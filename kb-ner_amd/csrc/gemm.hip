@@ -216,14 +216,16 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
         v[3] *= __uint_as_float(u.y & 0xffff0000u);
       }
       if (epi & EPI_GELU_FWD) {
-        const f2v y0 = gelu2(unpack2bf(pack2bf(v[0], v[1]))), y1 = gelu2(unpack2bf(pack2bf(v[2], v[3])));
+        const f2v y0 = gelu2((f2v){v[0], v[1]}), y1 = gelu2((f2v){v[2], v[3]});
         v[0] = y0[0]; v[1] = y0[1]; v[2] = y1[0]; v[3] = y1[1];
       }
       if (epi & EPI_GELU) {
-        // C = gelu(pre), out2 = gelu'(pre), both evaluated at the bf16-rounded pre-activation (same as gemm256.hip)
+        // C = gelu(pre), out2 = gelu'(pre), both evaluated at the fp32 pre-activation (rounds 1-3 rounded it to bf16 first, as if it
+        // had been stored: 3 of the ~30 vector instructions per element pair of this issue-bound epilogue, and a rounding the
+        // reference's fp32 path does not have) (same as gemm256.hip)
         f2v y0, d0, y1, d1;
-        gelu_both2(unpack2bf(pack2bf(v[0], v[1])), y0, d0);
-        gelu_both2(unpack2bf(pack2bf(v[2], v[3])), y1, d1);
+        gelu_both2((f2v){v[0], v[1]}, y0, d0);
+        gelu_both2((f2v){v[2], v[3]}, y1, d1);
         uint2 du;
         du.x = pack2bf(d0[0], d0[1]);
         du.y = pack2bf(d1[0], d1[1]);

@@ -440,19 +440,21 @@ static __device__ __forceinline__ void epilogue256(const GemmProblem& g, f4v (&a
       if (epi & EPI_GELU_FWD) {   // inference: the activation alone (no erf derivative, no second output)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const f2v y = gelu2(unpack2bf(pack2bf(v[2 * r], v[2 * r + 1])));
+          const f2v y = gelu2((f2v){v[2 * r], v[2 * r + 1]});
           v[2 * r] = y[0];
           v[2 * r + 1] = y[1];
         }
       }
       if (epi & EPI_GELU) {
-        // C = gelu(pre), out2 = gelu'(pre), both evaluated at the bf16-rounded pre-activation
+        // C = gelu(pre), out2 = gelu'(pre), both evaluated at the fp32 pre-activation (rounds 1-3 rounded it to bf16 first, as if it
+        // had been stored: 3 of the ~30 vector instructions per element pair of this issue-bound epilogue, and a rounding the
+        // reference's fp32 path does not have)
         uint4 du;
         uint32_t dw[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           f2v y, dy;
-          gelu_both2(unpack2bf(pack2bf(v[2 * r], v[2 * r + 1])), y, dy);
+          gelu_both2((f2v){v[2 * r], v[2 * r + 1]}, y, dy);
           v[2 * r] = y[0];
           v[2 * r + 1] = y[1];
           dw[r] = pack2bf(dy[0], dy[1]);

@@ -211,7 +211,7 @@ def encoder_forward(params, cfg, input_ids, attention_mask, return_all=False, ma
         o = mul(F.linear(c, rw(params[p + "attention.output.dense.weight"]), params[p + "attention.output.dense.bias"]), ("o", i))
         x = r(F.layer_norm(r(o + x), (H,), params[p + "attention.output.LayerNorm.weight"],
                            params[p + "attention.output.LayerNorm.bias"], eps))
-        h = r(F.gelu(r(F.linear(x, rw(params[p + "intermediate.dense.weight"]), params[p + "intermediate.dense.bias"]))))
+        h = r(F.gelu(F.linear(x, rw(params[p + "intermediate.dense.weight"]), params[p + "intermediate.dense.bias"])))
         o = mul(F.linear(h, rw(params[p + "output.dense.weight"]), params[p + "output.dense.bias"]), ("ffn", i))
         x = r(F.layer_norm(r(o + x), (H,), params[p + "output.LayerNorm.weight"], params[p + "output.LayerNorm.bias"], eps))
         hs.append(x)

@@ -88,12 +88,12 @@ def check_gemm(layout, M, N, K, epi=0, splitk=1, seed=0, drop_p=0.0):
     if epi & EPI_GELU:
         out2 = torch.zeros(M, N, dtype=BF16, device=DEV)
         kw["out2"] = out2
-        pre = ref.float().to(BF16).double()
+        pre = ref            # gelu / gelu' of the fp32 pre-activation (rounds 1-3: of its bf16 rounding)
         cdf = 0.5 * (1 + torch.erf(pre / np.sqrt(2.0)))
         ref_pre = cdf + pre * torch.exp(-0.5 * pre * pre) / np.sqrt(2 * np.pi)   # out2 = gelu'(pre)
         ref = torch.nn.functional.gelu(pre)
-    if epi & EPI_GELU_FWD:  # the activation alone, at the bf16-rounded pre-activation like EPI_GELU
-        ref = torch.nn.functional.gelu(ref.float().to(BF16).double())
+    if epi & EPI_GELU_FWD:  # the activation alone, at the fp32 pre-activation like EPI_GELU
+        ref = torch.nn.functional.gelu(ref)
     if epi & (EPI_ATOMIC32 | EPI_RMW32):
         C32 = torch.full((M, N), 1.0, dtype=F32, device=DEV)
         ops.gemm(layout, Ad, Bd, M, N, K, C32=C32, epi=epi, splitk=splitk, **kw)

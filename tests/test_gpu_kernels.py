@@ -435,9 +435,14 @@ def test_optimizer_steps_vs_oracle_trainer(st):
     linear decay) on the HIP engine vs the oracle trainer: loss trajectory, clip norms, direction of every parameter update"""
     r = st.check_train_steps(steps=3, accum=2)
     print("check_train_steps:", {k: v for k, v in r.items() if not k.startswith("dcos_")})
-    # 3x the round-1 driver observation (GPUTEST_r01.json: loss 4.7e-4, clip norm 1.7e-4, update cosine 0.9995, transitions 7e-4 of the move)
+    # 3x the observed values (round 1's driver run: loss 4.7e-4, update cosine 0.9995, transitions 7e-4 of the move).  The clip
+    # norm: 1.2-1.7e-4 while the GELU epilogue rounded its pre-activation to bf16 before the erf; 5.2e-4 since round 4 evaluates
+    # GELU / GELU' on the fp32 accumulator -- elementwise closer to the fp32 reference (one rounding less; check_gemm), but the norm
+    # of a whole gradient is a sum in which that rounding's bias had been cancelling part of the others' (the logistic GELU
+    # experiment of the same round, DESIGN.md section 3, landed at the same 5.4e-4).  A gradient norm to 5e-4 moves a clip
+    # coefficient by as much; 3x = 1.6e-3.
     assert r["loss_rel_max"] < 1.5e-3, r
-    assert r["norm_rel_max"] < 5.1e-4, r
+    assert r["norm_rel_max"] < 1.6e-3, r
     assert r["loss_decreased"], r
     assert r["delta_cos_min"] > 0.9985, r
     assert r["transitions_maxabs"] < 2.1e-3 * r["transitions_moved"], r
