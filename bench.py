@@ -122,18 +122,19 @@ def main():
         # `python bench.py --gpus N` without a launcher: become N ranks (one process per GPU) under torch.distributed.run on
         # this node -- the same command line the driver uses -- and pass its exit code on.  (KBNER_BENCH_LAUNCH_DRYRUN: print the
         # command instead; tests/test_bench_launch_cpu.py.)
-        import socket
         import subprocess
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0))
-            port = sk.getsockname()[1]
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        if os.environ.get("KBNER_BENCH_CHILD"):
+            sys.exit("bench.py: a launched rank found no WORLD_SIZE in its environment -- refusing to launch again")
+        # --standalone: torchrun picks (and holds) a free rendezvous port itself -- no bind-then-close race between picking a
+        # port here and the launcher binding it, and concurrent bench launches on one box cannot collide
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+               "--nproc-per-node", str(args.gpus), os.path.abspath(__file__)] + sys.argv[1:]
         if os.environ.get("KBNER_BENCH_LAUNCH_DRYRUN"):
             print(json.dumps({"launch": cmd}))
             return
         env = dict(os.environ)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env["KBNER_BENCH_CHILD"] = "1"
         sys.exit(subprocess.call(cmd, env=env))
 
     if args.launch_check:

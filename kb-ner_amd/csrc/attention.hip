@@ -1259,15 +1259,12 @@ static int launch_attn_bwd(const bf16_t* qkv, const bf16_t* ctx, const uint8_t* 
   return launch_attn_bwd2<DROP, false>(qkv, ctx, ctx_lo, dctx, maskbias, lse, Dws, dqkv, B, S, H, A, seed, thresh, dbias, s);
 }
 
-// round-3 kernels (attention3.hip): same contracts as the entry points below
+#ifdef KBNER_ATTN_LAB
+// Lab builds only (-DKBNER_ATTN_LAB, linked with tools/experiments/attention3.hip): the round-3 streaming forward and the A/B
+// switch KBNER_ATTN (1 = the 16-row-per-pass forward, 3 = streaming forward where it applies, 4 = forced).  The product
+// library has neither: it reads no environment variable.
 int kbner_attn_fwd3(const bf16_t* qkv, const float* maskbias, bf16_t* ctx, float* lse, int B, int S, int H, int A,
                     uint32_t drop_seed, uint32_t drop_thresh, hipStream_t stream);
-
-// KBNER_ATTN: 2 (default) = the round-2 kernels; 3 = the round-3 streaming forward (attention3.hip) where it applies, 4 = forced
-// (tests of small cases).  The streaming kernel is correct on every shape of tools/micro/attn_lab but not faster yet (282-300 us
-// against 270 us per B=128 forward in the lab), so it stays opt-in.
-// (an atomic: two host threads may make their first call at the same time; both then store the same value.  With
-// kbner_gemm_set_variant and the once-per-device flags this is all of the library's mutable process state.)
 static int attn_variant() {
   static std::atomic<int> v{-1};
   int r = v.load(std::memory_order_relaxed);
@@ -1278,6 +1275,7 @@ static int attn_variant() {
   }
   return r;
 }
+#endif
 
 extern "C" {
 
@@ -1290,11 +1288,14 @@ int kbner_attn_fwd(const bf16_t* qkv, const float* maskbias, bf16_t* ctx, uint8_
   KBNER_CHECK_ARG(B > 0 && A > 0 && H == A * AT_D && S % 64 == 0 && S >= 64 && S <= AT_MAXS);
   const int rpw = pick_rpw(B, S, A);
   hipStream_t st = (hipStream_t)stream;
-  // whole heads per workgroup, at least one per CU: the software-pipelined 32-row kernel
-  // (the streaming kernel counts its own stores and does not write ctx_lo: with a residual requested the round-2 kernels run)
+#ifdef KBNER_ATTN_LAB
+  // (the streaming kernel counts its own stores and does not write ctx_lo: with a residual requested the panel kernels run)
   if (!ctx_lo && ((attn_variant() == 3 && S >= 256 && B * A >= at_cu_count()) || attn_variant() >= 4))   // 4: forced (small cases)
     return kbner_attn_fwd3(qkv, maskbias, ctx, lse, B, S, H, A, drop_seed, drop_thresh, st);
-  const bool rows32 = attn_variant() != 1;   // KBNER_ATTN=1: the 16-row-per-pass forward of round 2 (A/B)
+  const bool rows32 = attn_variant() != 1;
+#else
+  const bool rows32 = true;   // 32 query rows per wave and pass wherever launch_attn_fwd can use them (no dropout, >= 256 rows)
+#endif
   switch (S / 64) {
     case 1: return launch_attn_fwd<4>(qkv, maskbias, ctx, ctx_lo, lse, B, H, A, rpw, drop_seed, drop_thresh, st, rows32);
     case 2: return launch_attn_fwd<8>(qkv, maskbias, ctx, ctx_lo, lse, B, H, A, rpw, drop_seed, drop_thresh, st, rows32);

@@ -215,8 +215,12 @@ static __device__ __forceinline__ f2v unpack2bf(uint32_t w) {
 static __device__ __forceinline__ uint32_t pack2bf_res8(float lo, float hi, uint32_t& res, bool hi_half) {
   const uint32_t w = pack2bf(lo, hi);
   const f2v r = unpack2bf(w);
-  res = hi_half ? (uint32_t)__builtin_amdgcn_cvt_pk_bf8_f32((lo - r[0]) * KBNER_RES8_SCALE, (hi - r[1]) * KBNER_RES8_SCALE, (int)res, true)
-                : (uint32_t)__builtin_amdgcn_cvt_pk_bf8_f32((lo - r[0]) * KBNER_RES8_SCALE, (hi - r[1]) * KBNER_RES8_SCALE, 0, false);
+  // clamped to the e5m2 maximum: the residual is <= |O| 2^-9, so the scaled value passes 57344 once |O| > ~1800 and the convert
+  // (no fp8 saturation in the default MODE) would store inf -> NaN in D -> NaN dQ on one activation outlier
+  const float rl = __builtin_amdgcn_fmed3f((lo - r[0]) * KBNER_RES8_SCALE, -57344.f, 57344.f);
+  const float rh = __builtin_amdgcn_fmed3f((hi - r[1]) * KBNER_RES8_SCALE, -57344.f, 57344.f);
+  res = hi_half ? (uint32_t)__builtin_amdgcn_cvt_pk_bf8_f32(rl, rh, (int)res, true)
+                : (uint32_t)__builtin_amdgcn_cvt_pk_bf8_f32(rl, rh, 0, false);
   return w;
 }
 

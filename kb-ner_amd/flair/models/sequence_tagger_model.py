@@ -88,6 +88,13 @@ class SequenceTagger(flair.nn.Model):
             # empty `_teacher_prediction` lists (sequence_tagger_model.py:2358): the reference fails on this combination
             raise ValueError("distill_emission next to distill_crf / distill_exact needs distill_posterior (whose teacher scores the "
                              "emission term then reads, sequence_tagger_model.py:2349-2353)")
+        if distill_emission and distill_posterior and distill_prob:
+            # next to distill_posterior the emission term's "teacher prediction" is the teacher's forward-backward SCORES
+            # (sequence_tagger_model.py:2349-2353): log-domain, mostly negative, not normalised.  Read as probabilities
+            # (distill_prob) the reference's xlogy of a negative target yields NaN; here it would be a finite wrong gradient
+            raise ValueError("distill_prob cannot be combined with distill_emission + distill_posterior: the emission term then "
+                             "reads the teacher's forward-backward scores, which are not probabilities (the reference's loss is "
+                             "NaN for this combination)")
         if kd_student and use_rnn:
             raise NotImplementedError("knowledge distillation is implemented for the fine-tuning student (use_rnn: false)")
         if distill_exact and distill_posterior and not multi_view_training:
@@ -190,6 +197,9 @@ class SequenceTagger(flair.nn.Model):
         if eng is not None and getattr(eng, "arena", None) is not None:
             eng.arena.g = None
             eng.arena.emb_flags = None
+            views = eng.arena.__dict__.get("_views")
+            if views:      # cached ('g', name) views keep the gradient buffer alive
+                eng.arena.__dict__["_views"] = {k: v for k, v in views.items() if k[0] != "g"}
 
     def release_device_memory(self):
         """drop the engine (parameter arena, bf16 shadow, activation buffers): the tagger cannot run afterwards"""
@@ -369,7 +379,7 @@ class SequenceTagger(flair.nn.Model):
             yield p
 
     def zero_grad(self, set_to_none=False):
-        if self.engine is not None:
+        if self.engine is not None and self.engine.arena.g is not None:    # None: a teacher after drop_gradients()
             self.engine.arena.g.zero_()
 
     def to(self, *a, **k):
@@ -401,6 +411,8 @@ class SequenceTagger(flair.nn.Model):
         """emissions f32 [B, n, T] for every word token (device tensor); sets self.mask to the length mask"""
         if self.use_rnn:
             return self._forward_stack(sentences)
+        if self.engine is None:
+            raise RuntimeError("this tagger's device memory was released (release_device_memory()): it cannot run any more")
         self.embeddings.embed(sentences)
         hb, db = self._device_batch(sentences)
         feats = self.engine.forward_features(db)

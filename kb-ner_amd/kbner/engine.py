@@ -10,6 +10,7 @@ Data layout in HBM (sized for 288 GB: everything stays resident, nothing is reco
   * activations are token-major bf16 [M_pad, width] (M = B*S padded to 128 rows); per layer the
     engine keeps x, qkv, ctx, h1, x1, gelu'(pre), act, h2 (+ fp32 LN stats, softmax lse) for backward.
 """
+import logging
 import math
 
 import os
@@ -18,7 +19,10 @@ import torch
 
 from . import lib as L_
 from . import ops
+from .dp import world_size as dp_world_size
 from .lib import EPI_ADD, EPI_ATOMIC32, EPI_BIAS, EPI_COLSUM, EPI_COLSUM_WS, EPI_DGELU, EPI_GELU, EPI_GELU_FWD, EPI_RMW32, GEMM_NN, GEMM_NT, GEMM_TN
+
+log = logging.getLogger("kbner")
 
 BF16, F32, I32 = torch.bfloat16, torch.float32, torch.int32
 
@@ -389,6 +393,7 @@ class Tagger:
     # pass over a shape is captured into a HIP graph and every later one is three small input copies + ONE graph launch.
     # KBNER_INFER_GRAPH=0 keeps the eager launches (A/B).
     INFER_GRAPH = os.environ.get("KBNER_INFER_GRAPH", "1") != "0"
+    INFER_GRAPH_DP = os.environ.get("KBNER_INFER_GRAPH_DP", "0") == "1"    # opt in on data-parallel ranks (untested over RCCL)
 
     def encoder_forward(self, ids, pos_ids, maskbias, B, S, need_grad=True):
         if (need_grad or not self.INFER_GRAPH or self.training or ops.SCHED_RING is not None or ops.GEMM_HOOK is not None
@@ -399,8 +404,8 @@ class Tagger:
         if st is None:
             st = ac.infer_graph = {"calls": 0, "graph": None, "ids": torch.empty_like(ids), "pos": torch.empty_like(pos_ids),
                                    "mb": torch.empty_like(maskbias), "variant": ops.gemm_variant()}
-        if (st["ids"].shape != ids.shape or st["mb"].shape != maskbias.shape or st["variant"] != ops.gemm_variant()
-                or torch.cuda.is_current_stream_capturing()):
+        if (st["graph"] is False or st["ids"].shape != ids.shape or st["mb"].shape != maskbias.shape
+                or st["variant"] != ops.gemm_variant() or torch.cuda.is_current_stream_capturing()):
             return self._encoder_forward(ids, pos_ids, maskbias, B, S, False)
         st["ids"].copy_(ids)
         st["pos"].copy_(pos_ids)
@@ -409,12 +414,26 @@ class Tagger:
             st["calls"] += 1
             if st["calls"] < 3:   # two eager passes first: every kernel's one-time attribute call and workspace allocation is behind us
                 return self._encoder_forward(st["ids"], st["pos"], st["mb"], B, S, False)
+            if dp_world_size() > 1 and not self.INFER_GRAPH_DP:
+                # a data-parallel rank has a live RCCL watchdog thread and collectives of other ranks' making in flight; the
+                # capture has not been exercised there (1-GPU boxes), so sharded evaluation keeps the eager launches
+                st["graph"] = False
+                return self._encoder_forward(st["ids"], st["pos"], st["mb"], B, S, False)
             g = torch.cuda.CUDAGraph()
             prev = L_._stream_cached
             try:
-                with torch.cuda.graph(g):
+                # thread_local: another thread's HIP call (a watchdog, a loader) must not invalidate this capture
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     L_._stream_cached = L_.c_void_p(torch.cuda.current_stream().cuda_stream)   # the capture stream
                     st["out"] = self._encoder_forward(st["ids"], st["pos"], st["mb"], B, S, False)
+            except Exception as e:   # a failed capture disables the graph for this shape ONCE; the pass itself runs eagerly
+                L_._stream_cached = prev
+                st["graph"] = False
+                st.pop("out", None)
+                log.warning("HIP-graph capture of the forward-only encoder pass failed for shape (%d, %d): %s -- this shape "
+                            "keeps eager launches", B, S, e)
+                torch.cuda.synchronize()
+                return self._encoder_forward(st["ids"], st["pos"], st["mb"], B, S, False)
             finally:
                 L_._stream_cached = prev
             st["graph"] = g

@@ -164,9 +164,31 @@ class _AttnCoreFlash(torch.autograd.Function):
         return dq, dk, dv, None, None, None
 
 
-def encoder_forward(params, cfg, input_ids, attention_mask, return_all=False, masks=None, bf16_points=False):
+class _GeluStored(torch.autograd.Function):
+    """erf-GELU the way the FFN-up GEMM epilogue runs it (csrc/gemm256.hip, EPI_GELU): the activation AND gelu'(pre) leave the
+    epilogue as bf16 tensors, backward is dpre = bf16(dact * stored gelu') (EPI_DGELU).  pre_rounded=False: both evaluated on the
+    fp32 accumulator (round 4 onwards); True: on its bf16 rounding, as if the pre-activation had been stored (rounds 1-3)."""
+
+    @staticmethod
+    def forward(ctx, pre, pre_rounded):
+        rb = lambda t: t.to(torch.bfloat16).to(t.dtype)   # noqa: E731
+        p = rb(pre) if pre_rounded else pre
+        gp = 0.5 * (1.0 + torch.erf(p * (1.0 / math.sqrt(2.0)))) + p * torch.exp(-0.5 * p * p) * (1.0 / math.sqrt(2.0 * math.pi))
+        ctx.save_for_backward(rb(gp))
+        return rb(F.gelu(p))
+
+    @staticmethod
+    def backward(ctx, g):
+        (gp,) = ctx.saved_tensors
+        return (g * gp).to(torch.bfloat16).to(g.dtype), None
+
+
+def encoder_forward(params, cfg, input_ids, attention_mask, return_all=False, masks=None, bf16_points=False, gelu_stored=None):
     """input_ids int64[B,S], attention_mask {0,1}[B,S] -> last hidden state f32[B,S,H]
     (== hidden_states[-1], the only layer the path uses: `layers: '-1'`).
+    gelu_stored (with bf16_points): None = autograd through F.gelu with the activation rounded (the default storage-rounding
+    pass); "acc" / "pre" = _GeluStored on the fp32 accumulator / on its bf16 rounding (attribution of the clip-norm distance,
+    tests/selftest.py check_train_steps).
 
     masks (training-mode dropout, transformers 3.0.0 modeling_bert: BertEmbeddings.forward dropout after the LayerNorm,
     BertSelfAttention `attention_probs = self.dropout(attention_probs)`, BertSelfOutput / BertOutput dense -> dropout ->
@@ -211,7 +233,8 @@ def encoder_forward(params, cfg, input_ids, attention_mask, return_all=False, ma
         o = mul(F.linear(c, rw(params[p + "attention.output.dense.weight"]), params[p + "attention.output.dense.bias"]), ("o", i))
         x = r(F.layer_norm(r(o + x), (H,), params[p + "attention.output.LayerNorm.weight"],
                            params[p + "attention.output.LayerNorm.bias"], eps))
-        h = r(F.gelu(F.linear(x, rw(params[p + "intermediate.dense.weight"]), params[p + "intermediate.dense.bias"])))
+        pre = F.linear(x, rw(params[p + "intermediate.dense.weight"]), params[p + "intermediate.dense.bias"])
+        h = _GeluStored.apply(pre, gelu_stored == "pre") if (gelu_stored and bf16_points) else r(F.gelu(pre))
         o = mul(F.linear(h, rw(params[p + "output.dense.weight"]), params[p + "output.dense.bias"]), ("ffn", i))
         x = r(F.layer_norm(r(o + x), (H,), params[p + "output.LayerNorm.weight"], params[p + "output.LayerNorm.bias"], eps))
         hs.append(x)

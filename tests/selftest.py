@@ -167,8 +167,9 @@ def attn_reference(qkv, maskbias, B, S, H, A, dctx=None, pmask=None):
     return ctx.detach(), lse.detach(), x.grad
 
 
-def check_attention(B, S, A, seed=0, ragged=True, drop_p=0.0, residual=False, collapse=0.0):
+def check_attention(B, S, A, seed=0, ragged=True, drop_p=0.0, residual=False, collapse=0.0, v_scale=1.0):
     """residual: the forward also stores O - bf16(O) and the backward takes D from the pair (include/kbner.h kbner_attn_bwd).
+    v_scale: multiplies the V rows (activation outliers: the residual byte's e5m2 range, csrc/common.h pack2bf_res8).
     collapse > 0: the K and V rows of a head are one common row + collapse * noise (what deep layers of a freshly initialised
     encoder look like): dS = P (dP - D) cancels and the rounding of a bf16 O is amplified into dQ."""
     H = A * 64
@@ -177,6 +178,8 @@ def check_attention(B, S, A, seed=0, ragged=True, drop_p=0.0, residual=False, co
     if collapse:
         common = torch.randn(1, 2 * H, generator=g)
         qkv[:, H:] = common + collapse * qkv[:, H:]
+    if v_scale != 1.0:
+        qkv[:, 2 * H:] *= v_scale
     qkv = qkv.to(BF16)
     dctx = (torch.randn(B * S, H, generator=g)).to(BF16)
     am = torch.ones(B, S)
@@ -200,6 +203,7 @@ def check_attention(B, S, A, seed=0, ragged=True, drop_p=0.0, residual=False, co
     dq = dqkv.cpu().float()
     bias_ref = dqkv_ref.sum(0)
     return {
+        "finite": bool(torch.isfinite(dq).all() and torch.isfinite(ctx.float()).all()),
         # fused d qkv.bias = column sums of dqkv; the K third is ~0 by construction (softmax shift invariance), so it is
         # compared on the absolute scale of the Q / V thirds
         "dbias": float((dbias.cpu().double() - bias_ref).abs().max() / (bias_ref.abs().max() + 1e-30)),
@@ -552,24 +556,37 @@ def check_train_steps(steps=3, accum=2, lr=2e-4, lr_rate=50.0, t_total=10):
                               max_position_embeddings=cfg.max_position_embeddings)
     p0 = oracle_params(tg, round_gemm=False)
     tr = ots.OracleTrainer(p0, ocfg, start, stop, x_idx, lr=lr, lr_rate=lr_rate, accum=accum, t_total=t_total)
+    # the same steps from the same parameters through the storage-rounding oracle (the HIP path's GELU placement): reported
+    tr16 = ots.OracleTrainer(p0, ocfg, start, stop, x_idx, lr=lr, lr_rate=lr_rate, accum=accum, t_total=t_total,
+                             bf16_points=True, gelu_stored="acc")
     opt = engine.FusedAdamW(tg.arena, lr=lr, lr_rate=lr_rate, t_total=t_total)
     dev_b = [kb.to_device(b, DEV) for b in batches]
     ob = [dict(input_ids=torch.from_numpy(b["input_ids"]), attention_mask=torch.from_numpy(b["attention_mask"]),
                first_idx=torch.from_numpy(b["first_idx"]), tags=torch.from_numpy(b["tags"].astype(np.int64)),
                lengths=torch.from_numpy(b["lengths"].astype(np.int64))) for b in batches]
-    lh, lo, nh, no = [], [], [], []
+    lh, lo, nh, no, n16 = [], [], [], [], []
     for _ in range(steps):
         for k in range(accum):
             lh.append(float(tg.forward_loss(dev_b[k], loss_scale=1.0 / accum, backward=True)))
             lo.append(tr.micro_batch(ob[k]))
+            tr16.micro_batch(ob[k])
         nh.append(float(opt.step().sqrt()))
         no.append(tr.optimizer_step(max_norm=5.0))
+        n16.append(tr16.optimizer_step(max_norm=5.0))
     torch.cuda.synchronize()
     p1 = oracle_params(tg, round_gemm=False)
     res = {"loss_hip": lh, "loss_oracle": lo, "norm_hip": nh, "norm_oracle": no,
            "loss_rel_max": max(abs(a - b_) / abs(b_) for a, b_ in zip(lh, lo)),
            "norm_rel_max": max(abs(a - b_) / abs(b_) for a, b_ in zip(nh, no)),
            "loss_decreased": lh[-accum] < lh[0]}
+    # attribution of the clip-norm distance (assert_train_steps): what storage rounding alone does to this figure
+    spread = ots.clip_norm_rounding_spread(steps=2, accum=accum, lr=lr, lr_rate=lr_rate, t_total=t_total)
+    res["norm_sigma_storage_rounding"] = float(np.sqrt((spread["acc"] ** 2).mean()))
+    res["norm_sigma_storage_rounding_pre"] = float(np.sqrt((spread["pre"] ** 2).mean()))
+    res["norm_rel_sigmas"] = res["norm_rel_max"] / res["norm_sigma_storage_rounding"]
+    res["norm_storage_oracle"] = n16
+    res["norm_rel_storage_oracle_vs_fp32"] = [(a - b_) / b_ for a, b_ in zip(n16, no)]
+    res["norm_rel_hip_vs_fp32"] = [(a - b_) / b_ for a, b_ in zip(nh, no)]
     # parameter movement: direction agreement of (after - before) for the tensors that carry most of the update
     worst = 1.0
     for k in ("transitions", "linear.weight", "encoder.layer.1.output.dense.weight", "encoder.layer.0.attention.self.value.weight",
@@ -620,12 +637,48 @@ def check_adamw(n=4096 + 64, seed=0):
     return {"p_abs": worst, "shadow_abs": shadow_err}
 
 
+# ---- ONE definition of every tolerance that smoke() and the pytest wrappers (tests/test_gpu_kernels.py) share: both call
+# the assert_* functions below, so the two copies of a threshold that diverged in round 4 (GPUTEST_r04: smoke red, pytest
+# green) cannot exist.
+STEP_TOL = {            # check_step(): 3x what the round-1 driver run observed (loss 2.3e-4, emissions 5.6e-3, worst gradient
+    "loss_rel": 7e-4,   # 0.0121 / cosine 0.99993, head 4.5e-3, transitions 5.1e-4)
+    "emissions_rel": 1.7e-2, "grad_min_cos": 0.9998, "grad_worst_rel": 0.037, "grad_linear.weight": 1.4e-2,
+    "grad_transitions": 1.6e-3}
+TRAIN_TOL = {           # check_train_steps(): 3x round 1's driver observations (loss 4.7e-4, update cosine 0.9995,
+    "loss_rel_max": 1.5e-3, "delta_cos_min": 0.9985, "transitions_rel": 2.1e-3,   # transitions 7e-4 of the move), and
+    "norm_sigmas": 4.0,          # the clip norm within 4 sigma of what bf16 storage rounding ALONE does to it (below)
+    "placement_ratio": 2.0}      # ... where the two GELU placements must have the same sigma within this factor
+
+
+def assert_step(r):
+    assert r["loss_rel"] < STEP_TOL["loss_rel"], r
+    assert r["emissions_rel"] < STEP_TOL["emissions_rel"], r
+    assert r["grad_min_cos"] > STEP_TOL["grad_min_cos"] and r["grad_worst_rel"] < STEP_TOL["grad_worst_rel"], r
+    assert r["grad_linear.weight"] < STEP_TOL["grad_linear.weight"] and r["grad_transitions"] < STEP_TOL["grad_transitions"], r
+    assert r["viterbi_equal"], r
+
+
+def assert_train_steps(r):
+    """The clip-norm tolerance is DERIVED, not picked: oracle/train_step.py clip_norm_rounding_spread runs the fp32 oracle
+    trainer next to storage-rounding oracle trainers over 16 independent (weights, batches) draws of this tiny tagger.  The
+    norm's relative deviation is a zero-mean draw with sigma = 2.6-2.8e-4 (max over 32 draws 6.6-6.9e-4) for BOTH placements
+    of the GELU rounding -- so the HIP path's 1.2-1.7e-4 of rounds 1-3 and its 5.2e-4 since round 4 evaluates GELU on the fp32
+    accumulator are two ordinary draws of one distribution (0.5 and 1.9 sigma); round 4's story of a rounding bias that had
+    been cancelling the others is refuted by the same ensemble (equal sigmas, means -1.5e-4 / -6e-5 of either sign)."""
+    assert r["loss_rel_max"] < TRAIN_TOL["loss_rel_max"], r
+    sa, sp = r["norm_sigma_storage_rounding"], r["norm_sigma_storage_rounding_pre"]
+    assert 1.0 / TRAIN_TOL["placement_ratio"] < sa / sp < TRAIN_TOL["placement_ratio"], r      # the attribution
+    assert 1e-4 < sa < 6e-4, r                                                                 # the ensemble itself is sane
+    assert r["norm_rel_max"] < TRAIN_TOL["norm_sigmas"] * sa, r
+    assert r["loss_decreased"], r
+    assert r["delta_cos_min"] > TRAIN_TOL["delta_cos_min"], r
+    assert r["transitions_maxabs"] < TRAIN_TOL["transitions_rel"] * r["transitions_moved"], r
+
+
 def smoke():
     r = check_step()
     print("smoke:", r)
-    assert r["loss_rel"] < 7e-4, r          # 3x the round-1 driver observation (2.3e-4)
-    assert r["grad_min_cos"] > 0.9998, r    # observed 0.99993
-    assert r["viterbi_equal"], r
+    assert_step(r)
     t = check_train_steps(steps=2)
     print("smoke train steps:", {k: v for k, v in t.items() if not k.startswith("dcos_")})
-    assert t["loss_rel_max"] < 1.5e-3 and t["norm_rel_max"] < 5.1e-4, t   # observed 4.7e-4 / 1.7e-4
+    assert_train_steps(t)

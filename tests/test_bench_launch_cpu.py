@@ -9,7 +9,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _env():
-    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
+                                                            "KBNER_BENCH_CHILD")}
     return env
 
 
@@ -22,7 +23,7 @@ def test_gpus_flag_builds_the_torchrun_command():
     cmd = json.loads(out.stdout.strip().splitlines()[-1])["launch"]
     assert cmd[1:3] == ["-m", "torch.distributed.run"]
     assert "--nnodes=1" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "8"
-    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert "--standalone" in cmd and cmd[cmd.index("--local-addr") + 1] == "127.0.0.1"     # torchrun picks the port itself
     tail = cmd[cmd.index(os.path.join(ROOT, "bench.py")) + 1:]
     assert tail == ["--gpus", "8", "--steps", "3", "--warmup", "1"]
 

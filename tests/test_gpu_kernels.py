@@ -136,27 +136,15 @@ def test_attention_residual_context(st, B, S, A):
     assert plain["dq"] > 4 * fixed["dq"], (plain, fixed)     # the amplification is real and the residual removes most of it
 
 
-def test_attention_streaming_forward_variant():
-    """the opt-in streaming forward kernel (csrc/attention3.hip, KBNER_ATTN=4 forces it for every shape) ships in the library, so it
-    is held to the default kernel's tolerances: ragged masks, dropout, S = 64 ... 512 (own process: the variant is read once)"""
-    import subprocess
-    import sys
-    code = ("import sys, json; sys.path.insert(0, 'tests'); import selftest as st\n"
-            "out = []\n"
-            "for (B, S, A, ragged, p) in ((2, 64, 2, False, 0.0), (3, 192, 2, True, 0.0), (2, 512, 4, True, 0.0), (2, 256, 2, True, 0.1), "
-            "(2, 512, 2, False, 0.1)):\n"
-            "    r = st.check_attention(B, S, A, ragged=ragged, drop_p=p)\n"
-            "    out.append({k: float(v) for k, v in r.items() if k in ('ctx', 'lse', 'dq', 'dk', 'dv')})\n"
-            "print('RESULT' + json.dumps(out))\n")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, KBNER_ATTN="4", PYTHONPATH=os.path.join(root, "kb-ner_amd") + os.pathsep + root)
-    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
-    assert r.returncode == 0, r.stderr.decode(errors="replace")[-2000:]
-    import json
-    line = [l for l in r.stdout.decode().split("\n") if l.startswith("RESULT")][0]
-    for res in json.loads(line[len("RESULT"):]):
-        assert res["ctx"] < 1.5e-2 and res["lse"] < 2e-2, res
-        assert res["dq"] < 3e-2 and res["dk"] < 3e-2 and res["dv"] < 3e-2, res     # backward consumes this forward's lse
+def test_attention_residual_byte_saturates_on_outliers(st):
+    """V rows of magnitude ~1e4 (an activation outlier): O - bf16(O) scaled by 2^14 passes the e5m2 maximum (57344) once
+    |O| > ~1800; pack2bf_res8 clamps before v_cvt_pk_bf8_f32 -- without the clamp the byte is inf and D, dQ, dK are NaN
+    (ADVICE round 4).  The saturated residual only costs accuracy of the correction, never finiteness."""
+    r = st.check_attention(2, 128, 2, ragged=True, residual=True, v_scale=1.0e4)
+    print("attention residual, V x 1e4", r)
+    assert r["finite"], r
+    assert r["ctx"] < 1.5e-2 and r["dv"] < 3e-2, r
+    assert r["dq"] < 6e-2 and r["dk"] < 6e-2, r
 
 
 @pytest.mark.parametrize("M,H", [(256, 128), (300, 768), (512, 1024)])
@@ -332,15 +320,10 @@ def test_encoder_d64_three_layers_vs_hf_golden(golden_dir):
 
 
 def test_full_step_vs_oracle(st):
-    """thresholds = 3x what the round-1 driver run observed (GPUTEST_r01.json smoke: loss 2.3e-4, emissions 5.6e-3, worst
-    gradient 0.0121 / cosine 0.99993, head 4.5e-3, transitions 5.1e-4)"""
+    """tolerances: tests/selftest.py STEP_TOL / assert_step (shared with smoke())"""
     r = st.check_step()
     print("check_step:", {k: v for k, v in r.items() if k != "grad_table_top"})
-    assert r["loss_rel"] < 7e-4, r
-    assert r["emissions_rel"] < 1.7e-2, r
-    assert r["grad_min_cos"] > 0.9998 and r["grad_worst_rel"] < 0.037, r
-    assert r["grad_linear.weight"] < 1.4e-2 and r["grad_transitions"] < 1.6e-3, r
-    assert r["viterbi_equal"], r
+    st.assert_step(r)
 
 
 def test_base_config_step_vs_oracle(st):
@@ -432,20 +415,12 @@ def test_crf_posterior_vs_reference_golden(st, golden_dir):
 
 def test_optimizer_steps_vs_oracle_trainer(st):
     """three whole optimiser steps (2 accumulated micro-batches, clip 5.0, HF AdamW with the transitions group at lr*lr_rate,
-    linear decay) on the HIP engine vs the oracle trainer: loss trajectory, clip norms, direction of every parameter update"""
+    linear decay) on the HIP engine vs the oracle trainer: loss trajectory, clip norms, direction of every parameter update.
+    Tolerances and the derivation of the clip-norm one: tests/selftest.py TRAIN_TOL / assert_train_steps -- the SAME function
+    __graft_entry__.smoke() asserts with."""
     r = st.check_train_steps(steps=3, accum=2)
     print("check_train_steps:", {k: v for k, v in r.items() if not k.startswith("dcos_")})
-    # 3x the observed values (round 1's driver run: loss 4.7e-4, update cosine 0.9995, transitions 7e-4 of the move).  The clip
-    # norm: 1.2-1.7e-4 while the GELU epilogue rounded its pre-activation to bf16 before the erf; 5.2e-4 since round 4 evaluates
-    # GELU / GELU' on the fp32 accumulator -- elementwise closer to the fp32 reference (one rounding less; check_gemm), but the norm
-    # of a whole gradient is a sum in which that rounding's bias had been cancelling part of the others' (the logistic GELU
-    # experiment of the same round, DESIGN.md section 3, landed at the same 5.4e-4).  A gradient norm to 5e-4 moves a clip
-    # coefficient by as much; 3x = 1.6e-3.
-    assert r["loss_rel_max"] < 1.5e-3, r
-    assert r["norm_rel_max"] < 1.6e-3, r
-    assert r["loss_decreased"], r
-    assert r["delta_cos_min"] > 0.9985, r
-    assert r["transitions_maxabs"] < 2.1e-3 * r["transitions_moved"], r
+    st.assert_train_steps(r)
 
 
 @pytest.mark.parametrize("layout,M,N,K,splits,drop_p", [(0, 512, 256, 1024, 4, 0.0), (1, 256, 512, 768, 3, 0.0), (0, 256, 256, 256, 2, 0.1),
