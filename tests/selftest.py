@@ -670,6 +670,10 @@ def assert_train_steps(r):
     assert 1.0 / TRAIN_TOL["placement_ratio"] < sa / sp < TRAIN_TOL["placement_ratio"], r      # the attribution
     assert 1e-4 < sa < 6e-4, r                                                                 # the ensemble itself is sane
     assert r["norm_rel_max"] < TRAIN_TOL["norm_sigmas"] * sa, r
+    # ... and the storage-rounding oracle run from the SAME parameters and batches lands where the HIP path does (GPU box,
+    # round 5: oracle -4.2e-4 / -3.1e-4, HIP -5.2e-4 / -1.7e-4 against the fp32 trainer: same sign, ratio of the maxima 0.80)
+    so = max(abs(x) for x in r["norm_rel_storage_oracle_vs_fp32"])
+    assert 0.5 < so / r["norm_rel_max"] < 2.0, r
     assert r["loss_decreased"], r
     assert r["delta_cos_min"] > TRAIN_TOL["delta_cos_min"], r
     assert r["transitions_maxabs"] < TRAIN_TOL["transitions_rel"] * r["transitions_moved"], r
