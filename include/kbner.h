@@ -12,8 +12,9 @@
  *   - `stream` is a hipStream_t (NULL = default stream); work is enqueued asynchronously on it
  *   - no device allocation: callers pass workspaces.  Mutable process state, all of it in atomics (entry points may be called
  *     from several host threads and on several devices): once-per-device flags (a kernel's dynamic-LDS limit has been raised on
- *     device d; the CU count of device d) and the GEMM main-loop switch (kbner_gemm_set_variant).  The library reads no
- *     environment variable.
+ *     device d; the CU count of device d), the GEMM main-loop switch (kbner_gemm_set_variant) and, in device memory, the eight
+ *     per-XCD round counters of the ring GEMM's long-K launches (monotonic, never reset; csrc/gemm256.hip xcd_tile_sync: two such
+ *     launches running CONCURRENTLY on one device would only lose their L2 sharing).  The library reads no environment variable.
  *   - bf16 tensors are raw uint16_t storage, row-major; fp32 statistics / optimizer state / CRF
  */
 #ifndef KBNER_H

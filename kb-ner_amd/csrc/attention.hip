@@ -1158,6 +1158,10 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv2_kernel(const bf16_t* __rest
   }
 }
 
+#ifdef KBNER_ATTN_LAB
+#include "attn_bwd3.h"   // tools/experiments/: round 5's software-pipelined backward stream (bit-identical, measured slower)
+#endif
+
 #define AT_LDS_BYTES (2 * AT_MAXS * 128 + 3 * AT_MAXS * 4)
 #ifndef KBNER_ATTN_PARTS
 #define KBNER_ATTN_PARTS 2   // key-axis parts of the 32-row forward kernel (4, for S % 128 == 0, measured slower: 263-268 vs 247-251 us)
@@ -1219,6 +1223,24 @@ static int launch_attn_fwd(const bf16_t* qkv, const float* maskbias, bf16_t* ctx
   return launch_attn_fwd2<NKB, false>(qkv, maskbias, ctx, ctx_lo, lse, B, H, A, rpw, seed, thresh, stream, rows32);
 }
 
+#ifdef KBNER_ATTN_LAB
+// Lab builds only (-DKBNER_ATTN_LAB, linked with tools/experiments/attention3.hip): the round-3 streaming forward and the A/B
+// switch KBNER_ATTN (1 = the 16-row-per-pass forward, 3 = streaming forward where it applies, 4 = forced).  The product
+// library has neither: it reads no environment variable.
+int kbner_attn_fwd3(const bf16_t* qkv, const float* maskbias, bf16_t* ctx, float* lse, int B, int S, int H, int A,
+                    uint32_t drop_seed, uint32_t drop_thresh, hipStream_t stream);
+static int attn_variant() {
+  static std::atomic<int> v{-1};
+  int r = v.load(std::memory_order_relaxed);
+  if (r < 0) {
+    const char* e = getenv("KBNER_ATTN");
+    r = e ? atoi(e) : 2;
+    v.store(r, std::memory_order_relaxed);
+  }
+  return r;
+}
+#endif
+
 template <bool DROP, bool RES>
 static int launch_attn_bwd2(const bf16_t* qkv, const bf16_t* ctx, const uint8_t* ctx_lo, const bf16_t* dctx, const float* maskbias,
                             const float* lse, float* Dws, bf16_t* dqkv, int B, int S, int H, int A, uint32_t seed, uint32_t thresh,
@@ -1237,6 +1259,21 @@ static int launch_attn_bwd2(const bf16_t* qkv, const bf16_t* ctx, const uint8_t*
     if (r) return r;
     r = kbner_set_max_lds_once(done3, reinterpret_cast<const void*>(attn_bwd_dkv2_kernel<DROP>), AT_LDS_BYTES);
     if (r) return r;
+#ifdef KBNER_ATTN_LAB
+    if (!DROP && attn_variant() == 5) {   // KBNER_ATTN=5: the pipelined backward stream (lab builds)
+      static std::atomic<unsigned long long> done4{0}, done5{0};
+      r = kbner_set_max_lds_once(done4, reinterpret_cast<const void*>(attn_bwd_dq3_kernel<RES>), AT_LDS_BYTES);
+      if (r) return r;
+      r = kbner_set_max_lds_once(done5, reinterpret_cast<const void*>(attn_bwd_dkv3_kernel), AT_LDS_BYTES);
+      if (r) return r;
+      hipLaunchKernelGGL((attn_bwd_dq3_kernel<RES>), grid, dim3(512), AT_LDS_BYTES, s, qkv, dctx, ctx, ctx_lo, maskbias, lse, Dws, dqkv, S,
+                         H, A, 0.125f, rpw, dbias);
+      hipLaunchKernelGGL(attn_bwd_dkv3_kernel, grid, dim3(512), AT_LDS_BYTES, s, qkv, dctx, maskbias, lse, Dws, dqkv, S, H, A, 0.125f, rpw,
+                         dbias);
+      hipError_t e3 = hipGetLastError();
+      return e3 == hipSuccess ? 0 : -(int)e3;
+    }
+#endif
     hipLaunchKernelGGL((attn_bwd_dq2_kernel<DROP, RES>), grid, dim3(512), AT_LDS_BYTES, s, qkv, dctx, ctx, ctx_lo, maskbias, lse, Dws,
                        dqkv, S, H, A, 0.125f, rpw, seed, thresh, dbias);
     hipLaunchKernelGGL(attn_bwd_dkv2_kernel<DROP>, grid, dim3(512), AT_LDS_BYTES, s, qkv, dctx, maskbias, lse, Dws, dqkv, S, H, A,
@@ -1259,23 +1296,6 @@ static int launch_attn_bwd(const bf16_t* qkv, const bf16_t* ctx, const uint8_t* 
   return launch_attn_bwd2<DROP, false>(qkv, ctx, ctx_lo, dctx, maskbias, lse, Dws, dqkv, B, S, H, A, seed, thresh, dbias, s);
 }
 
-#ifdef KBNER_ATTN_LAB
-// Lab builds only (-DKBNER_ATTN_LAB, linked with tools/experiments/attention3.hip): the round-3 streaming forward and the A/B
-// switch KBNER_ATTN (1 = the 16-row-per-pass forward, 3 = streaming forward where it applies, 4 = forced).  The product
-// library has neither: it reads no environment variable.
-int kbner_attn_fwd3(const bf16_t* qkv, const float* maskbias, bf16_t* ctx, float* lse, int B, int S, int H, int A,
-                    uint32_t drop_seed, uint32_t drop_thresh, hipStream_t stream);
-static int attn_variant() {
-  static std::atomic<int> v{-1};
-  int r = v.load(std::memory_order_relaxed);
-  if (r < 0) {
-    const char* e = getenv("KBNER_ATTN");
-    r = e ? atoi(e) : 2;
-    v.store(r, std::memory_order_relaxed);
-  }
-  return r;
-}
-#endif
 
 extern "C" {
 
@@ -1290,7 +1310,7 @@ int kbner_attn_fwd(const bf16_t* qkv, const float* maskbias, bf16_t* ctx, uint8_
   hipStream_t st = (hipStream_t)stream;
 #ifdef KBNER_ATTN_LAB
   // (the streaming kernel counts its own stores and does not write ctx_lo: with a residual requested the panel kernels run)
-  if (!ctx_lo && ((attn_variant() == 3 && S >= 256 && B * A >= at_cu_count()) || attn_variant() >= 4))   // 4: forced (small cases)
+  if (!ctx_lo && ((attn_variant() == 3 && S >= 256 && B * A >= at_cu_count()) || attn_variant() == 4))   // 4: forced (small cases)
     return kbner_attn_fwd3(qkv, maskbias, ctx, lse, B, S, H, A, drop_seed, drop_thresh, st);
   const bool rows32 = attn_variant() != 1;
 #else

@@ -26,7 +26,7 @@
 
 #define G2_MAXP 16
 #ifndef KBNER_GEMM_VARIANT_DEFAULT
-#define KBNER_GEMM_VARIANT_DEFAULT 1
+#define KBNER_GEMM_VARIANT_DEFAULT 3
 #endif
 
 struct GemmProblem {
@@ -812,6 +812,28 @@ static __device__ __forceinline__ void glds16_quad(const void* sbase, unsigned v
       : "memory", "m0");
 }
 
+// Round 5: tile-boundary re-synchronisation of the workgroups that share an XCD's L2 (long-K launches of the ring kernel only).
+// The 8 x 4 patch of tiles an XCD works on shares 8 A panels and 4 B panels through its 4-MiB L2 -- as long as the 32 workgroups
+// stay within the ~10 K steps of history that L2 holds.  The two-stage loop of rounds 1-3 waited for every stage's landing, so a
+// workgroup that ran ahead paid the misses and the others caught up: its miss count on the weight-gradient launch (K = 65536:
+// 3 x 1024 K steps per workgroup) is the same to four digits in every launch (TCC_MISS 8.760e7 lines = 11.2 GB, tools/wgrad_pmc.sh).
+// The ring loop hides the landing time (issue-bound), nothing pulls a straggler back, and the drift accumulates over a launch:
+// 2.31e7 misses at K = 16384 (= the two-stage loop's), but 1.28-1.44e8 at K = 65536 (16.4-18.5 GB, +46...+65 %, different in every
+// launch).  So: after each of a workgroup's tiles but the last, thread 0 counts itself in on its XCD's counter and waits (bounded)
+// for the other 31; the workgroup's other waves are held by the first K step's barrier.  Monotonic counters (one round = +32),
+// never reset; a timed-out wait only costs the sharing.  Grid = 256 launches only (32 workgroups per counter).
+__device__ int g2_xcd_round[8 * 32];   // one counter per XCD, 128 B apart
+static __device__ __forceinline__ void xcd_tile_sync(int xcd) {
+  int* c = g2_xcd_round + xcd * 32;
+  const int v = __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int target = (v | 31) + 1;
+#pragma unroll 1
+  for (int spin = 0; spin < 2048; ++spin) {   // <= ~2048 x (load round trip + 64 cycles): a few hundred us at the very most
+    if (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target >= 0) break;
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------
 // The INTERLEAVED ring loop (round 4, final form).  tools/micro/issue_probe.hip is the cost model behind it: next to 64 MFMAs
 // per wave and two waves per SIMD in lockstep (identical code from the same barrier -- the GEMM's situation), an instruction
@@ -823,7 +845,7 @@ static __device__ __forceinline__ void glds16_quad(const void* sbase, unsigned v
 // held across the barrier), its 8-MFMA groups and their one-group-ahead fragment prefetch -- but every fragment read, every DMA
 // piece (own M0 write: two scalar instructions) and the cursor arithmetic is a statement placed after ONE MFMA, pinned with
 // sched_barrier; no branch inside a step.
-template <bool A_KS, bool B_KS, int ABL = 0>
+template <bool A_KS, bool B_KS, int ABL = 0, bool MIDSYNC = false>
 __global__ __launch_bounds__(512, 2) void gemm256f_kernel(const GroupArgs ga) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
@@ -832,6 +854,13 @@ __global__ __launch_bounds__(512, 2) void gemm256f_kernel(const GroupArgs ga) {
   const int wm = wid >> 2, wn = wid & 3;
   const int total = ga.total_tiles;
   const int gstep = (int)gridDim.x;
+  // (ga.pad_: tile-boundary sync requested by the launcher -- long K, grid of 256; see xcd_tile_sync)
+  const int sync_rounds = (ga.pad_ && gstep == 256) ? total / 256 - 1 : 0;
+  // ... and, when every problem of the launch has the same K, also every (sync_mask + 1) K steps inside each of the total / 256
+  // tiles that every workgroup has (ga.pad_ >> 8 = the period; 0 = tile boundaries only)
+  // (MIDSYNC: its own instantiation -- the test in the K loop costs the other layouts scalar registers they do not have)
+  const int sync_mask = (MIDSYNC && ga.pad_ && gstep == 256) ? (ga.pad_ >> 8) - 1 : -1;
+  const int sync_tiles = total / 256;
   G2_CLK(0)
 
   int lane_m = lane;   // opaque copy for the main loop's address arithmetic (see gemm256pp_kernel)
@@ -1087,6 +1116,7 @@ __global__ __launch_bounds__(512, 2) void gemm256f_kernel(const GroupArgs ga) {
     RF_TAKE_NEXT(nt == 1)
     RF_BODY(true)
     for (int t = 1; t < nt; ++t) {
+      if (MIDSYNC && sync_mask > 0 && (t & sync_mask) == 0 && tile_no < sync_tiles && tid == 0) xcd_tile_sync(blockIdx.x & 7);
       // behind the barrier: request the first fragments of the new stage, then the group held back across the barrier
       // (group 7 of the previous step), which covers their latency
       b0[0] = RF_FB(0, 0);
@@ -1139,6 +1169,8 @@ __global__ __launch_bounds__(512, 2) void gemm256f_kernel(const GroupArgs ga) {
     G2_T(2)
     ++tile_no;
     if (x_pi < 0) break;
+    // long-K launches: meet the XCD's other workgroups before the next tile (every workgroup has at least sync_rounds + 1 tiles)
+    if (tile_no <= sync_rounds && tid == 0) xcd_tile_sync(blockIdx.x & 7);
     c_pi = x_pi;
     m0 = x_m;
     n0 = x_n;
@@ -1171,13 +1203,13 @@ __global__ __launch_bounds__(512, 2) void gemm256f_kernel(const GroupArgs ga) {
 #undef RF_STEP_BASES
 }
 
-template <bool A_KS, bool B_KS, int ABL = 0>
+template <bool A_KS, bool B_KS, int ABL = 0, bool MIDSYNC = false>
 static int launch256f(const GroupArgs& ga, hipStream_t stream) {
   static std::atomic<unsigned long long> attr_done{0};
-  const int r = kbner_set_max_lds_once(attr_done, reinterpret_cast<const void*>(gemm256f_kernel<A_KS, B_KS, ABL>), PP_LDS_BYTES);
+  const int r = kbner_set_max_lds_once(attr_done, reinterpret_cast<const void*>(gemm256f_kernel<A_KS, B_KS, ABL, MIDSYNC>), PP_LDS_BYTES);
   if (r) return r;
   const int grid = ga.total_tiles < ga.ncu ? ga.total_tiles : ga.ncu;
-  hipLaunchKernelGGL((gemm256f_kernel<A_KS, B_KS, ABL>), dim3(grid), dim3(512), PP_LDS_BYTES, stream, ga);
+  hipLaunchKernelGGL((gemm256f_kernel<A_KS, B_KS, ABL, MIDSYNC>), dim3(grid), dim3(512), PP_LDS_BYTES, stream, ga);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
 }
@@ -1315,7 +1347,14 @@ static int gemm_grouped_impl(int layout, int nprob, const kbner_gemm_problem* pr
   }
   ga.total_tiles = tiles;
   ga.ncu = device_cu_count();
-  ga.pad_ = 0;
+  // tile-boundary sync of the ring kernel (variant bit 1): every problem's K loop is long enough for the drift to matter
+  int min_k = 0x7fffffff;
+  for (int i = 0; i < nprob; ++i) min_k = probs[i].K < min_k ? probs[i].K : min_k;
+  int max_k = 0;
+  for (int i = 0; i < nprob; ++i) max_k = probs[i].K > max_k ? probs[i].K : max_k;
+  const int gv = g_gemm_variant.load(std::memory_order_relaxed);
+  ga.pad_ = ((gv & 2) && min_k >= 256 * BK2 && tiles >= 2 * ga.ncu) ? 1 : 0;
+  if (ga.pad_ && (gv & 4) && layout == 2 && min_k == max_k && min_k >= 512 * BK2) ga.pad_ |= 256 << 8;   // + every 256 K steps inside a tile
   ga.sched = sched;
   hipStream_t st = (hipStream_t)stream;
   if (sched != nullptr) {
@@ -1349,7 +1388,7 @@ static int gemm_grouped_impl(int layout, int nprob, const kbner_gemm_problem* pr
     switch (layout) {
       case 0: return launch256f<false, false>(ga, st);
       case 1: return launch256f<false, true>(ga, st);
-      default: return launch256f<true, true>(ga, st);
+      default: return (ga.pad_ >> 8) ? launch256f<true, true, 0, true>(ga, st) : launch256f<true, true>(ga, st);
     }
   }
   switch (layout) {

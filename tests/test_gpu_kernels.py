@@ -119,6 +119,40 @@ def test_gemm_variants_bit_identical():
     assert out.count("checked M=") == 7, out[-2000:]
 
 
+def test_gemm_long_k_xcd_sync_is_bit_identical():
+    """kbner_gemm_set_variant bits 1 / 2 (round 5: the ring kernel's workgroups re-synchronise per XCD at tile boundaries / every
+    256 K steps on long-K launches, csrc/gemm256.hip xcd_tile_sync): a weight-gradient-shaped grouped TN launch (K = 32768 tokens,
+    3 x 256 tiles, fp32 accumulate in place) gives the same bits as the two-stage loop, twice in a row (the counters are
+    monotonic across launches) -- and finishes (a lost round only times out)."""
+    import torch
+    from kbner import ops
+    from kbner.lib import GEMM_TN, EPI_RMW32
+    K, shapes = 32768, ((4096, 4096), (4096, 4096), (2048, 8192))
+    g = torch.Generator(device="cuda").manual_seed(3)
+    ops_ = []
+    for (m, n) in shapes:
+        a = (torch.randn(K, m, device="cuda", generator=g) * 0.5).to(torch.bfloat16)
+        b = (torch.randn(K, n, device="cuda", generator=g) * 0.5).to(torch.bfloat16)
+        ops_.append((a, b, m, n))
+    prev = ops.gemm_variant()
+    outs = {}
+    try:
+        for v in (0, 1, 3, 7, 7):
+            ops.gemm_variant(v)
+            cs = [torch.full((m, n), 0.25, device="cuda") for (_, _, m, n) in ops_]
+            ops.gemm_grouped(GEMM_TN, [ops.make_problem(a, b, m, n, K, C32=c, epi=EPI_RMW32) for (a, b, m, n), c in zip(ops_, cs)])
+            torch.cuda.synchronize()
+            outs.setdefault(v, []).append(cs)
+    finally:
+        ops.gemm_variant(prev)
+    ref = outs[0][0]
+    assert all(torch.isfinite(c).all() for c in ref) and float(ref[0].abs().max()) > 1.0
+    for v, runs in outs.items():
+        for cs in runs:
+            for c, r in zip(cs, ref):
+                assert torch.equal(c, r), v
+
+
 @pytest.mark.parametrize("B,S,A", [(2, 128, 2), (32, 512, 8)])
 def test_attention_residual_context(st, B, S, A):
     """kbner_attn_fwd / _bwd with ctx_lo (the engine's training default): on ordinary inputs nothing changes beyond rounding, and where the K / V rows of a head are nearly parallel -- dS = P (dP - D) cancels --
