@@ -743,6 +743,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GroupArgs ga) {
     }
   } else if (A_KS && epi == EPI_RMW32) {
     epilogue256<EPI_RMW32, MI>(g, acc, m0, n0, wm, wn, lane, scr);
+  } else if (A_KS && epi == EPI_STORE32) {
+    epilogue256<EPI_STORE32, MI>(g, acc, m0, n0, wm, wn, lane, scr);
   } else if (!A_KS && epi == EPI_ADD) {
     epilogue256<EPI_ADD, MI>(g, acc, m0, n0, wm, wn, lane, scr);
   } else if (!A_KS && epi == 0) {
@@ -1153,6 +1155,8 @@ __global__ __launch_bounds__(512, 2) void gemm256f_kernel(const GroupArgs ga) {
       }
     } else if (A_KS && epi == EPI_RMW32) {
       epilogue256<(EPI_RMW32), 8, false, true>(g, acc, m0, n0, wm, wn, lane_e, scr, scr2);
+    } else if (A_KS && epi == EPI_STORE32) {   // weight gradients of the first backward pass after an optimizer step: overwrite
+      epilogue256<(EPI_STORE32), 8, false, true>(g, acc, m0, n0, wm, wn, lane_e, scr, scr2);
     } else if (!A_KS && epi == EPI_ADD) {
       epilogue256<(EPI_ADD), 8, false, true>(g, acc, m0, n0, wm, wn, lane_e, scr, scr2);
     } else if (!A_KS && epi == 0) {

@@ -381,6 +381,7 @@ class SequenceTagger(flair.nn.Model):
     def zero_grad(self, set_to_none=False):
         if self.engine is not None and self.engine.arena.g is not None:    # None: a teacher after drop_gradients()
             self.engine.arena.g.zero_()
+            self.engine.arena.wgrad_stale = False
 
     def to(self, *a, **k):
         return self

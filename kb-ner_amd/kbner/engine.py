@@ -20,7 +20,8 @@ import torch
 from . import lib as L_
 from . import ops
 from .dp import world_size as dp_world_size
-from .lib import EPI_ADD, EPI_ATOMIC32, EPI_BIAS, EPI_COLSUM, EPI_COLSUM_WS, EPI_DGELU, EPI_GELU, EPI_GELU_FWD, EPI_RMW32, GEMM_NN, GEMM_NT, GEMM_TN
+from .lib import (EPI_ADD, EPI_ATOMIC32, EPI_BIAS, EPI_COLSUM, EPI_COLSUM_WS, EPI_DGELU, EPI_GELU, EPI_GELU_FWD, EPI_RMW32, EPI_STORE32, GEMM_NN, GEMM_NT,
+                  GEMM_TN)
 
 log = logging.getLogger("kbner")
 
@@ -98,6 +99,13 @@ class Arena:
         self.emb_flags = None
         if with_grad and "emb.word" in self.shapes:
             self.emb_flags = torch.zeros(self.shapes["emb.word"][0], dtype=torch.uint8, device=device)
+        # The GEMM-weight gradients g[:n_shadow] need no zeroing when the backward pass that follows an optimizer step OVERWRITES
+        # them (the grouped weight-gradient launch with KBNER_EPI_STORE32 instead of the fp32 read-modify-write): 4 B / parameter
+        # less written by AdamW and 4 B / parameter less read by the first micro-batch's weight-gradient epilogues.
+        # wgrad_overwrite_ok: the owner (Tagger) guarantees that every weight gradient goes through that launch.
+        # wgrad_stale: g[:n_shadow] holds the PREVIOUS step's gradients (set by FusedAdamW.step, cleared by encoder_backward).
+        self.wgrad_overwrite_ok = False
+        self.wgrad_stale = False
 
     def _view(self, buf, name):
         off, shape = self.offsets[name], self.shapes[name]
@@ -250,6 +258,9 @@ class Tagger:
         self.cfg, self.T, self.start, self.stop = cfg, num_tags, start_idx, stop_idx
         self.device = torch.device(device)
         self.arena = Arena(tagger_specs(cfg, num_tags), self.device, with_grad=not inference)
+        # every weight gradient of the encoder is a tile of the grouped 256 x 256 launch (_wgrads): it may overwrite
+        self.arena.wgrad_overwrite_ok = (not inference and cfg.hidden_size % 256 == 0 and cfg.intermediate_size % 256 == 0
+                                         and os.environ.get("KBNER_WGRAD_OVERWRITE", "1") != "0")
         self._acts = {}
         self._saved = None
         # Dropout (active only while `training`): the encoder's three HF sites (embeddings, attention probabilities,
@@ -545,6 +556,7 @@ class Tagger:
                     grad_ready(lo_off, hi_off)
                     ops.sched_active(True)   # a collective is in flight from here to the end of this backward pass
             dx = ac.dx
+        a.wgrad_stale = False   # every GEMM-weight gradient has been written by this pass
         ops.embed_ln_bwd(dx, ac.h0, ac.emb_mean, ac.emb_rstd, a.param("emb.ln.g"), ids, pos_ids, a.grad("emb.ln.g"),
                          a.grad("emb.ln.b"), a.grad("emb.word"), a.grad("emb.pos"), a.grad("emb.type")[0], drop=d_emb)
         if a.emb_flags is not None:
@@ -553,7 +565,9 @@ class Tagger:
     def _wgrads(self, pairs, Mp):
         a = self.arena
         if all(n_ % 256 == 0 and k_ % 256 == 0 for _, _, n_, k_, _ in pairs):
-            ops.gemm_grouped(GEMM_TN, [ops.make_problem(dy, x, n_, k_, Mp, C32=a.grad(nm), epi=EPI_RMW32)
+            # the first backward pass after an optimizer step overwrites the stale gradients (Arena.wgrad_stale), later ones add
+            epi = EPI_STORE32 if (a.wgrad_stale and a.wgrad_overwrite_ok) else EPI_RMW32
+            ops.gemm_grouped(GEMM_TN, [ops.make_problem(dy, x, n_, k_, Mp, C32=a.grad(nm), epi=epi)
                                        for dy, x, n_, k_, nm in pairs])
         else:
             for dy, x, n_, k_, nm in pairs:
@@ -888,6 +902,12 @@ class FusedAdamW:
         # the word-embedding table (46 % of XLM-R's parameters) is updated row-sparsely: rows that never received a gradient
         # have g = m = v = 0 and, with weight decay 0, HF AdamW leaves them where they are -- they are not read at all
         sparse = self.sparse_embedding and a.emb_flags is not None and self.wd == 0.0
+        # GEMM-weight gradients: left in place for the next backward pass to overwrite (Arena.wgrad_overwrite_ok); if no backward
+        # pass has written them since the last step they are that step's: a step without gradients sees zeros, as it always did
+        keep = a.wgrad_overwrite_ok and a.n_shadow > 0
+        if a.wgrad_stale:
+            a.g[:a.n_shadow].zero_()
+            a.wgrad_stale = False
         if sparse:
             e0 = a.offsets["emb.word"]
             V, H = a.shapes["emb.word"]
@@ -896,16 +916,21 @@ class FusedAdamW:
             ops.grad_sqnorm(a.g[:e0], self.ws, self.norm_sq)
             ops.grad_sqnorm_rows(rows(a.g), a.emb_flags, self.ws, self.norm_sq, accumulate=True)
             ops.grad_sqnorm(a.g[e1:], self.ws, self.norm_sq, accumulate=True)
-            ranges = ((0, e0, self.lr * lam), (e1, s, self.lr * lam), (s, a.n, self.lr * self.lr_rate * lam))
+            ranges = [(0, e0, self.lr * lam), (e1, s, self.lr * lam), (s, a.n, self.lr * self.lr_rate * lam)]
         else:
             ops.grad_sqnorm(a.g, self.ws, self.norm_sq)
-            ranges = ((0, s, self.lr * lam), (s, a.n, self.lr * self.lr_rate * lam))
+            ranges = [(0, s, self.lr * lam), (s, a.n, self.lr * self.lr_rate * lam)]
+        if keep:   # the GEMM weights as a range of their own (they are the first n_shadow elements)
+            ranges = [r for lo, hi, lr in ranges
+                      for r in (((lo, a.n_shadow, lr), (a.n_shadow, hi, lr)) if lo < a.n_shadow < hi else ((lo, hi, lr),))]
         for lo, hi, lr in ranges:
             if hi <= lo:
                 continue
             nsh = min(a.n_shadow, hi) - lo if lo < a.n_shadow else 0
             ops.adamw(a.p[lo:hi], a.g[lo:hi], a.m[lo:hi], a.v[lo:hi], a.shadow[lo:] if nsh > 0 else None, max(nsh, 0),
-                      lr * bc, lr * self.wd, b1, b2, self.eps, self.norm_sq, self.max_norm, grad_scale, True)
+                      lr * bc, lr * self.wd, b1, b2, self.eps, self.norm_sq, self.max_norm, grad_scale,
+                      not (keep and hi <= a.n_shadow))
+        a.wgrad_stale = keep
         if sparse:
             ops.adamw_rows(rows(a.p), rows(a.g), rows(a.m), rows(a.v), a.emb_flags, self.lr * lam * bc, b1, b2, self.eps,
                            self.norm_sq, self.max_norm, grad_scale, True)

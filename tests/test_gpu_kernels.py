@@ -651,6 +651,75 @@ def test_sparse_embedding_optimizer_equals_dense():
     assert float((tg.arena.param("emb.word")[~dead] - p0[~dead]).abs().max()) > 0
 
 
+def test_weight_gradients_overwrite_instead_of_zeroing():
+    """round 5: with every weight gradient a tile of the grouped 256 x 256 launch (H, F multiples of 256) FusedAdamW.step leaves
+    g[:n_shadow] in place and the next backward pass's first weight-gradient launch OVERWRITES it (KBNER_EPI_STORE32), later
+    micro-batches of the step add (KBNER_EPI_RMW32).
+    (a) one accumulation group of two micro-batches on a NaN-poisoned stale range == the same group on a zeroed range, bit for
+        bit on the GEMM-weight gradients (no atomics on that path);
+    (b) three optimizer steps next to a zero-and-accumulate twin: the stale range is never read (poisoned after every step),
+        everything else is zeroed as before, parameters agree to 1e-3 of the largest entry (the twins are not bit-reproducible:
+        fp32 atomics in the embedding / bias gradients move the clip norm by 5e-5 between two runs of ONE twin; a missed
+        overwrite or a doubled gradient moves Adam's update by its full lr or to NaN);
+    (c) a step with no backward pass since the last one sees zero gradients."""
+    import torch
+    from kbner import batch as kb
+    from kbner import engine
+    T, start, stop, x_idx = 29, 27, 28, 9
+    cfg = engine.EncoderConfig(vocab_size=600, hidden_size=256, num_hidden_layers=2, num_attention_heads=4, intermediate_size=512,
+                               max_position_embeddings=130, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    tgs, opts = [], []
+    for overwrite in (True, False):
+        tg = engine.Tagger(cfg, T, start, stop, device="cuda")
+        tg.init_random(seed=7)
+        assert tg.arena.wgrad_overwrite_ok
+        tg.arena.wgrad_overwrite_ok = overwrite
+        tgs.append(tg)
+        opts.append(engine.FusedAdamW(tg.arena, lr=1e-3, lr_rate=10.0, t_total=50, max_norm=0.5))
+    ns = tgs[0].arena.n_shadow
+    mbs = [kb.to_device(kb.synthetic_batch(4, 128, vocab=600, T=T, x_idx=x_idx, start=start, stop=stop, seed=300 + k), "cuda")
+           for k in range(2)]
+    # (a)
+    a0, a1 = tgs[0].arena, tgs[1].arena
+    a0.g[:ns].fill_(float("nan"))
+    a0.wgrad_stale = True
+    for tg in tgs:
+        for mb in mbs:
+            tg.forward_loss(mb, loss_scale=0.5, backward=True)
+        assert not tg.arena.wgrad_stale
+    torch.cuda.synchronize()
+    assert torch.isfinite(a0.g).all() and float(a1.g[:ns].abs().max()) > 0
+    assert torch.equal(a0.g[:ns], a1.g[:ns])
+    for a in (a0, a1):
+        a.g.zero_()
+    # (b)
+    for step in range(3):
+        mbs = [kb.to_device(kb.synthetic_batch(4, 128, vocab=600, T=T, x_idx=x_idx, start=start, stop=stop, seed=310 + 2 * step + k),
+                            "cuda") for k in range(2)]
+        norms = []
+        for tg, opt in zip(tgs, opts):
+            for mb in mbs:
+                tg.forward_loss(mb, loss_scale=0.5, backward=True)
+            assert not tg.arena.wgrad_stale
+            norms.append(float(opt.step()))
+            if tg.arena.wgrad_overwrite_ok:
+                assert tg.arena.wgrad_stale
+                assert float(tg.arena.g[ns:].abs().max()) == 0.0          # everything else is zeroed as before
+                tg.arena.g[:ns].fill_(float("nan"))                      # ... and this range is never READ again
+            else:
+                assert float(tg.arena.g.abs().max()) == 0.0
+        assert norms[0] == norms[0] and abs(norms[0] - norms[1]) <= 1e-3 * norms[1], (step, norms)
+        for name in ("p", "m", "v"):
+            x_, y_ = getattr(a0, name), getattr(a1, name)
+            assert torch.isfinite(x_).all() and float((x_ - y_).abs().max()) <= 1e-3 * float(y_.abs().max()), (step, name)
+    # (c)
+    p_before = a0.p.clone()
+    n0, n1 = float(opts[0].step()), float(opts[1].step())
+    assert n0 == n1 == 0.0
+    assert torch.isfinite(a0.p).all() and float((a0.p - a1.p).abs().max()) <= 1e-3 * float(a1.p.abs().max())
+    assert not torch.equal(a0.p, p_before)      # (Adam's first moment still moves the parameters)
+
+
 # ---------------------------------------------------------------- teacher-student knowledge distillation (SURVEY.md 8f-4)
 def _kd_suppress(g):
     return (int(g["stop"]), int(g["start"]), int(g["unk"]))
