@@ -23,6 +23,11 @@ sys.path.insert(0, os.path.join(ROOT, "kb-ner_amd"))
 MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16
 SUSTAINED_MFMA_RANDOM_BF16_TFLOPS = 1993.0   # measured, profiles/round2_mfma_power.txt (v_mfma_f32_16x16x32_bf16, 2.03-2.16 GHz)
 HBM_PEAK_GBS = 8000.0
+# Sentences per micro-batch of the default workload (x accumulate 1).  configs[1] fixes the model, the sequence length and the
+# precision, not the batch: rounds 1-4 ran 128 (52 GB of saved activations), round 5 runs 256 (104 GB of the 288 GB): the per-step
+# costs that do not grow with the batch (optimizer 3.7 ms, launch tails, the tile-count rounding of every GEMM) are paid once per 256
+# sentences.  `extra.micro_batch_x_accumulate` keeps the 128 x 1 point and BASELINE.md's {1, 4, 16, 32} x 4 next to it.
+DEFAULT_MICRO_BATCH = 256
 
 
 def encoder_flops_per_sentence(cfg, S):
@@ -95,7 +100,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--micro-batch", type=int, default=128)
+    ap.add_argument("--micro-batch", type=int, default=DEFAULT_MICRO_BATCH)
     ap.add_argument("--accum", type=int, default=1)
     ap.add_argument("--seq-len", type=int, default=512)
     ap.add_argument("--model", default="large", choices=["large", "base"])
@@ -312,8 +317,10 @@ def main():
         pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
         cands = sorted(f for f in (os.listdir(pdir) if os.path.isdir(pdir) else []) if f.endswith("_hbm_traffic.json"))
         tpath = os.path.join(pdir, cands[-1]) if cands else ""
-        if args.model == "large" and B == 128 and S == 512 and tpath:
-            ks = [v for k, v in json.load(open(tpath))["kernels"].items() if "gemm256f_kernel" in k or "gemm256_kernel" in k]
+        tj = json.load(open(tpath)) if tpath else {}
+        # (a traffic file says which micro-batch it was profiled at; the files of rounds 1-4 carry no tag: 128)
+        if args.model == "large" and B == int(tj.get("micro_batch", 128)) and S == 512 and tpath:
+            ks = [v for k, v in tj["kernels"].items() if "gemm256f_kernel" in k or "gemm256_kernel" in k]
             n = sum(v["launches"] for v in ks)
             if n:
                 traffic = round(sum(v["launches"] * v["hbm_bytes_per_launch"] for v in ks) / n)
@@ -346,7 +353,7 @@ def main():
     # secondary measurements of the SAME step at the other points BASELINE.md / SURVEY.md §8d name: micro-batch {1,4,16,32} x
     # accumulate 4 (the YAMLs run 1 x 4) and dropout 0.1 at every site -- N=1, default workload only, a few steps each
     extra = None
-    if world == 1 and not args.no_extras and args.model == "large" and B == 128 and accum == 1 and args.dropout == 0.0:
+    if world == 1 and not args.no_extras and args.model == "large" and B == DEFAULT_MICRO_BATCH and accum == 1 and args.dropout == 0.0:
         extra = {"micro_batch_x_accumulate": {}, "unit": "sentences/sec"}
 
         def timed(tgx, optx, mbs, steps, warm=1):
@@ -373,25 +380,26 @@ def main():
                                                seed=kb.SEED + 60), dev)]
         sec = timed(tg, opt, mb4, steps=6)
         extra["micro_batch_x_accumulate"]["1x4_fused_by_trainer"] = {"value": round(4 / sec, 2), "ms_per_step": round(sec * 1e3, 3)}
-        # 256 sentences per launch (102 GB of saved activations: what 288 GB of HBM still holds): the fixed per-step costs
-        # (optimizer, launch tails) amortise over twice the sentences -- informational, the headline stays at 128 x 1
+        # rounds 1-4's headline point, 128 sentences per launch (52 GB of saved activations): the fixed per-step costs (optimizer,
+        # launch tails) amortise over half the sentences -- kept for continuity with BENCH_r01..r04
         try:
-            mb256 = [kb.to_device(kb.synthetic_batch(256, S, vocab=cfg.vocab_size, T=T, x_idx=x_idx, start=start, stop=stop,
+            mb128 = [kb.to_device(kb.synthetic_batch(128, S, vocab=cfg.vocab_size, T=T, x_idx=x_idx, start=start, stop=stop,
                                                      seed=kb.SEED + 80), dev)]
-            sec = timed(tg, opt, mb256, steps=3)
-            extra["micro_batch_x_accumulate"]["256x1"] = {"value": round(256 / sec, 2), "ms_per_step": round(sec * 1e3, 3)}
-            del mb256
-            tg._acts.pop((256, S), None)
+            sec = timed(tg, opt, mb128, steps=4, warm=2)
+            extra["micro_batch_x_accumulate"]["128x1"] = {"value": round(128 / sec, 2), "ms_per_step": round(sec * 1e3, 3),
+                                                           "mfma_fraction_end_to_end": round(128 / sec * 3 * encoder_flops_per_sentence(cfg, S) / (MFMA_BF16_DENSE_PEAK_TFLOPS * 1e12), 4)}
+            del mb128
+            tg._acts.pop((128, S), None)
             torch.cuda.empty_cache()
         except Exception as e:
-            extra["micro_batch_x_accumulate"]["256x1"] = {"error": repr(e)}
+            extra["micro_batch_x_accumulate"]["128x1"] = {"error": repr(e)}
         tg.cfg.hidden_dropout_prob = tg.cfg.attention_probs_dropout_prob = 0.1
         tg.train(True)
         tg.word_dropout = 0.1
         sec = timed(tg, opt, micro, steps=3)
         tg.train(False)
         tg.cfg.hidden_dropout_prob = tg.cfg.attention_probs_dropout_prob = 0.0
-        extra["dropout_0.1_all_sites_128x1"] = {"value": round(B / sec, 2), "ms_per_step": round(sec * 1e3, 3)}
+        extra["dropout_0.1_all_sites_%dx1" % B] = {"value": round(B / sec, 2), "ms_per_step": round(sec * 1e3, 3)}
         # what a corpus that uses 30 000 distinct sub-tokens gets (ids uniform in [5, 30000) instead of the whole 250 002-row
         # table): fresh optimizer state, only rows that receive a gradient are live, the other 88 % of the word-embedding table
         # (40 % of all parameters) are skipped by the clip norm and by AdamW -- exactly, their g / m / v are zero
@@ -421,7 +429,7 @@ def main():
                 return (time.perf_counter() - t0) / steps
 
             sec = timed_seq(mbc, steps=3, warm=2)     # the big batch first: it makes (nearly) all 30 000 rows live
-            cv["128x1"] = {"value": round(B / sec, 2), "ms_per_step": round(sec * 1e3, 3)}
+            cv["%dx1" % B] = {"value": round(B / sec, 2), "ms_per_step": round(sec * 1e3, 3)}
             sec = timed_seq(mb4c, steps=8, warm=2)
             cv["1x4_fused_by_trainer"] = {"value": round(4 / sec, 2), "ms_per_step": round(sec * 1e3, 3)}
             cv["live_rows"] = int(tg.arena.emb_flags.sum())
@@ -437,7 +445,7 @@ def main():
                 mod = importlib.util.module_from_spec(spec)
                 spec.loader.exec_module(mod)
                 return mod
-            tg._acts.clear()          # the training step's activation buffers (B = 128) are not needed any more
+            tg._acts.clear()          # the training step's activation buffers are not needed any more
             torch.cuda.empty_cache()
             extra["cfg5"] = _tool("bench_stack").measure(encoders=3, lms=4, reps=3)
             sys.path.insert(0, os.path.join(ROOT, "tests"))

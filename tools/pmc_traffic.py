@@ -40,7 +40,9 @@ def main():
         print("%-70s n=%4d  read %9.1f MB  write %9.1f MB" % (k[:70], v["launches"], v["hbm_read_bytes_per_launch"] / 1e6,
                                                               v["hbm_write_bytes_per_launch"] / 1e6))
     if len(sys.argv) > 3:
+        import os
         json.dump({"note": "FETCH_SIZE x2 (gfx950 correction), WRITE_SIZE as reported; KiB units; per-launch averages",
+                   "micro_batch": int(os.environ.get("KBNER_PROFILE_MICRO_BATCH", "256")),   # what bench.py ran at (its default)
                    "kernels": out}, open(sys.argv[3], "w"), indent=1)
 
 
