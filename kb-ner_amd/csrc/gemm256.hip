@@ -1207,6 +1207,142 @@ __global__ __launch_bounds__(512, 2) void gemm256f_kernel(const GroupArgs ga) {
 #undef RF_STEP_BASES
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Round 5: 128-row tiles on a DEEP ring -- single forward / dgrad problems whose 256 x 256 tiling would occupy at most half of the
+// CUs (small micro-batches: the YAMLs' 4 sentences per optimizer step are M = 2048 tokens).  Such a GEMM is a chain of K / 64
+// steps on every CU that has a tile, and with the two-stage loop (gemm256_kernel<..., 128>) each step is one exposed LDS-DMA round
+// trip: 26-36 us per K = 1024 GEMM whatever M (profiles/round5_mb4x1_kernel_stats.md).  A 128 x 256 x 64 step is only 32 MFMAs per
+// wave (~0.5 us per SIMD), so the landing time has to be hidden by depth, not by work: the A tile is 16 KiB here, which lets the
+// 160 KiB of LDS hold FOUR A slots and THREE B slots -- A is requested three steps ahead, B two.  One workgroup per tile, no
+// persistence (the launch has at most ~2 tiles per CU), one counted wait + one barrier per step:
+//   issue order  A0 B0 A1 B1 A2 | step t: B(t+2) A(t+3)   ->  behind B(t) there are always A(t+1) + B(t+1) + A(t+2) = 8 pieces of
+//   this wave, so the wait is a constant vmcnt(8); requests past the last stage re-read it into a slot nobody reads any more.
+#define R128_A_BYTES 16384
+#define R128_A_SLOTS 4
+#define R128_B_SLOTS 3
+#define R128_B_BASE (R128_A_SLOTS * R128_A_BYTES)
+#define R128_LDS_BYTES (R128_B_BASE + R128_B_SLOTS * TILE2_BYTES)
+
+template <bool B_KS>
+__global__ __launch_bounds__(512, 2) void gemm128r_kernel(const GroupArgs ga) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 2, wn = wid & 3;
+  GemmProblem g;
+  int m0, n0;
+  pick_tile<128>(ga, blockIdx.x, ga.total_tiles, g, m0, n0);
+  const int nt = g.K / BK2;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void*)smem);
+  // per-lane source offsets of this wave's pieces: 2 of the A tile (128 rows x 128 B, row-major image), 4 of the B tile
+  unsigned va[2], vb[4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = (wid * 2 + j) * 8 + (lane >> 3);
+    va[j] = (unsigned)(row * g.lda + (((lane & 7) ^ kc_swz(row)) << 3)) * 2u - (unsigned)j * 1024u;
+  }
+  stage_voff<B_KS, true>(g.ldb, wid, lane, vb);
+  const bf16_t* a_base = g.A + (size_t)m0 * g.lda;
+  const bf16_t* b_base = B_KS ? g.B + n0 : g.B + (size_t)n0 * g.ldb;
+  const size_t b_stride = B_KS ? (size_t)BK2 * g.ldb : (size_t)BK2;
+  const unsigned a_dst0 = lds0 + wid * 2048, b_dst0 = lds0 + R128_B_BASE + wid * 4096;
+#define R1_ISSUE_A(T, SLOT)                                                                                   \
+  {                                                                                                           \
+    const int tt_ = (T) < nt ? (T) : nt - 1;                                                                  \
+    glds16_pair<0>(uniform_ptr(a_base + (size_t)tt_ * BK2), va[0], va[1], a_dst0 + (unsigned)(SLOT) * R128_A_BYTES); \
+  }
+#define R1_ISSUE_B(T, SLOT)                                                                                   \
+  {                                                                                                           \
+    const int tt_ = (T) < nt ? (T) : nt - 1;                                                                  \
+    glds16_quad(uniform_ptr(b_base + (size_t)tt_ * b_stride), vb[0], vb[1], vb[2], vb[3], b_dst0 + (unsigned)(SLOT) * TILE2_BYTES); \
+  }
+  R1_ISSUE_A(0, 0)
+  R1_ISSUE_B(0, 0)
+  R1_ISSUE_A(1, 1)
+  R1_ISSUE_B(1, 1)
+  R1_ISSUE_A(2, 2)
+
+  f4v acc[4][4];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = (f4v){0.0f, 0.0f, 0.0f, 0.0f};
+
+  int sa = 0, sb = 0;   // ring slots of the stage this step consumes
+#pragma unroll 1
+  for (int t = 0; t < nt; ++t) {
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    // the slots consumed one step ago are free: B(t+2) and A(t+3) go there
+    R1_ISSUE_B(t + 2, sb == 0 ? 2 : sb - 1)
+    R1_ISSUE_A(t + 3, (sa + 3) & 3)
+    const unsigned char* as_ = smem + sa * R128_A_BYTES;
+    const unsigned char* bs_ = smem + R128_B_BASE + sb * TILE2_BYTES;
+#define R1_SB() __builtin_amdgcn_sched_barrier(0)
+#define R1_LOADB(dst, ks) _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) dst[ni] = fragB256<B_KS>(bs_, wn * 64, ni, ks, lane)
+#define R1_LOADA(dst, ks, pr)                                          \
+  dst[0] = frag256<false>(as_, wm * 64 + (2 * (pr)) * 16, ks, lane);   \
+  dst[1] = frag256<false>(as_, wm * 64 + (2 * (pr) + 1) * 16, ks, lane)
+#define R1_MM(a, b, pr)                                                                                                  \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) acc[2 * (pr) + j][ni] = \
+      __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[ni], a[j], acc[2 * (pr) + j][ni], 0, 0, 0)
+    bf16x8 b0[4], b1[4], a0[2], a1[2];
+    R1_LOADB(b0, 0);
+    R1_LOADA(a0, 0, 0);
+    R1_SB();
+    R1_LOADA(a1, 0, 1); R1_SB(); R1_MM(a0, b0, 0); R1_SB();
+    R1_LOADB(b1, 1);
+    R1_LOADA(a0, 1, 0); R1_SB(); R1_MM(a1, b0, 1); R1_SB();
+    R1_LOADA(a1, 1, 1); R1_SB(); R1_MM(a0, b1, 0); R1_SB();
+    R1_MM(a1, b1, 1);
+    sa = (sa + 1) & 3;
+    sb = sb == 2 ? 0 : sb + 1;
+  }
+  // the re-read pieces of the last steps may still be landing in the slots the epilogue uses as scratch
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  const int epi = g.epi;
+  unsigned char* scr = smem + wid * 4096;
+  if (!B_KS) {
+    switch (epi) {
+      case 0: epilogue256<0, 4>(g, acc, m0, n0, wm, wn, lane, scr); break;
+      case EPI_BIAS: epilogue256<EPI_BIAS, 4>(g, acc, m0, n0, wm, wn, lane, scr); break;
+      case EPI_BIAS | EPI_GELU: epilogue256<(EPI_BIAS | EPI_GELU), 4>(g, acc, m0, n0, wm, wn, lane, scr); break;
+      case EPI_BIAS | EPI_GELU_FWD: epilogue256<(EPI_BIAS | EPI_GELU_FWD), 4>(g, acc, m0, n0, wm, wn, lane, scr); break;
+      case EPI_BIAS | EPI_ADD: epilogue256<(EPI_BIAS | EPI_ADD), 4>(g, acc, m0, n0, wm, wn, lane, scr); break;
+      case EPI_BIAS | EPI_ADD | EPI_DROP: epilogue256<(EPI_BIAS | EPI_ADD | EPI_DROP), 4>(g, acc, m0, n0, wm, wn, lane, scr); break;
+      default: epilogue256<-1, 4>(g, acc, m0, n0, wm, wn, lane, scr); break;
+    }
+  } else if (epi == EPI_ADD) {
+    epilogue256<EPI_ADD, 4>(g, acc, m0, n0, wm, wn, lane, scr);
+  } else if (epi == 0) {
+    epilogue256<0, 4>(g, acc, m0, n0, wm, wn, lane, scr);
+  } else {
+    epilogue256<-1, 4>(g, acc, m0, n0, wm, wn, lane, scr);
+  }
+#undef R1_ISSUE_A
+#undef R1_ISSUE_B
+#undef R1_SB
+#undef R1_LOADB
+#undef R1_LOADA
+#undef R1_MM
+}
+
+template <bool B_KS>
+static int launch128r(const GroupArgs& ga, hipStream_t stream) {
+  static std::atomic<unsigned long long> attr_done{0};
+  const int r = kbner_set_max_lds_once(attr_done, reinterpret_cast<const void*>(gemm128r_kernel<B_KS>), R128_LDS_BYTES);
+  if (r) return r;
+  hipLaunchKernelGGL((gemm128r_kernel<B_KS>), dim3(ga.total_tiles), dim3(512), R128_LDS_BYTES, stream, ga);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
 template <bool A_KS, bool B_KS, int ABL = 0, bool MIDSYNC = false>
 static int launch256f(const GroupArgs& ga, hipStream_t stream) {
   static std::atomic<unsigned long long> attr_done{0};
@@ -1305,10 +1441,15 @@ int kbner_gemm_bf16_grouped_dyn(int layout, int nprob, const kbner_gemm_problem*
 // tile height of a launch: 128-row tiles when the problem is a single forward / dgrad GEMM whose 256 x 256 tiling would give at
 // most half of the CUs a tile (and the static walk is used); 256 otherwise
 static int pick_tile_rows(int layout, int nprob, const kbner_gemm_problem* probs, bool dyn) {
-  if (layout == 2 || nprob != 1 || dyn) return T2;
-  const kbner_gemm_problem& s = probs[0];
-  if (s.M % T2 != 0 || s.N % T2 != 0) return T2;
-  const long tiles = (long)(s.M / T2) * (s.N / T2);
+  if (layout == 2 || dyn) return T2;
+  // (a grouped launch too -- the K slices of a split-K GEMM -- when the ring kernels run it: round 5)
+  if (nprob != 1 && (!(g_gemm_variant.load(std::memory_order_relaxed) & 1) || (g_gemm_variant.load(std::memory_order_relaxed) & 8))) return T2;
+  long tiles = 0;
+  for (int i = 0; i < nprob; ++i) {
+    const kbner_gemm_problem& s = probs[i];
+    if (s.M % T2 != 0 || s.N % T2 != 0) return T2;
+    tiles += (long)(s.M / T2) * (s.N / T2);
+  }
   return 2 * tiles <= device_cu_count() ? 128 : T2;
 }
 
@@ -1368,8 +1509,12 @@ static int gemm_grouped_impl(int layout, int nprob, const kbner_gemm_problem* pr
       default: return launch256<true, true, true>(ga, st);
     }
   }
-  if (TM == 128) return layout == 0 ? launch256<false, false, false, 128>(ga, st) : launch256<false, true, false, 128>(ga, st);
   const int variant = g_gemm_variant.load(std::memory_order_relaxed);
+  if (TM == 128) {
+    // (variant bit 3 clear = default: the deep-ring kernel; set: the two-stage loop's 128-row tiles of rounds 2-4, for the A/B)
+    if ((variant & 1) && !(variant & 8)) return layout == 0 ? launch128r<false>(ga, st) : launch128r<true>(ga, st);
+    return layout == 0 ? launch256<false, false, false, 128>(ga, st) : launch256<false, true, false, 128>(ga, st);
+  }
 #ifdef G2_TRACE
   if ((variant & 1) && layout == 2 && (variant & 0xF000)) {   // cycle-accounting ablations, TN: no DMA wait / no DMA
     switch ((variant >> 12) & 15) {

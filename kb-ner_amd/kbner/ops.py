@@ -327,7 +327,9 @@ def embed_ln_bwd(dy, h0, mean, rstd, gamma, ids, pos_ids, dgamma, dbeta, dword, 
 FORCE_128 = False  # tests: force the 128^2 kernel
 # below this many 256x256 tiles a GEMM goes to the 128x128 kernel (4x the tiles): a small micro-batch leaves most of the
 # 256 CUs idle on the big tile
-MIN_TILES_256 = int(__import__("os").environ.get("KBNER_MIN_TILES_256", "100"))
+# (100 until round 5; 32 since the 128-row tiles of the 256-path run on the deep-ring kernel, csrc/gemm256.hip gemm128r_kernel:
+# at 4 sentences per step 13.54 -> 12.97 ms, same box, alternating)
+MIN_TILES_256 = int(__import__("os").environ.get("KBNER_MIN_TILES_256", "32"))
 
 
 def uses_256(M, N, occupancy=False):

@@ -658,9 +658,10 @@ def test_weight_gradients_overwrite_instead_of_zeroing():
     (a) one accumulation group of two micro-batches on a NaN-poisoned stale range == the same group on a zeroed range, bit for
         bit on the GEMM-weight gradients (no atomics on that path);
     (b) three optimizer steps next to a zero-and-accumulate twin: the stale range is never read (poisoned after every step),
-        everything else is zeroed as before, parameters agree to 1e-3 of the largest entry (the twins are not bit-reproducible:
-        fp32 atomics in the embedding / bias gradients move the clip norm by 5e-5 between two runs of ONE twin; a missed
-        overwrite or a doubled gradient moves Adam's update by its full lr or to NaN);
+        everything else is zeroed as before, parameters agree to 1e-2 of the largest entry (a loose check on purpose: the twins
+        are not bit-reproducible -- fp32 atomics in the embedding / bias gradients move the clip norm by 5e-5 between two runs of
+        ONE twin and the trajectories drift apart, 3e-4 on m after three steps, once in a dozen runs more than 1e-3; a missed
+        overwrite gives NaN, a doubled gradient an O(1) difference; the sharp check is (a));
     (c) a step with no backward pass since the last one sees zero gradients."""
     import torch
     from kbner import batch as kb
@@ -688,8 +689,8 @@ def test_weight_gradients_overwrite_instead_of_zeroing():
             tg.forward_loss(mb, loss_scale=0.5, backward=True)
         assert not tg.arena.wgrad_stale
     torch.cuda.synchronize()
-    assert torch.isfinite(a0.g).all() and float(a1.g[:ns].abs().max()) > 0
-    assert torch.equal(a0.g[:ns], a1.g[:ns])
+    assert torch.isfinite(a0.g).all() and float(a1.g[:ns].abs().max()) > 0, "(a) finite"
+    assert torch.equal(a0.g[:ns], a1.g[:ns]), ("(a) bit-identical GEMM-weight gradients", float((a0.g[:ns] - a1.g[:ns]).abs().max()))
     for a in (a0, a1):
         a.g.zero_()
     # (b)
@@ -708,15 +709,17 @@ def test_weight_gradients_overwrite_instead_of_zeroing():
                 tg.arena.g[:ns].fill_(float("nan"))                      # ... and this range is never READ again
             else:
                 assert float(tg.arena.g.abs().max()) == 0.0
-        assert norms[0] == norms[0] and abs(norms[0] - norms[1]) <= 1e-3 * norms[1], (step, norms)
+        assert norms[0] == norms[0] and abs(norms[0] - norms[1]) <= 1e-2 * norms[1], ("norm", step, norms)
         for name in ("p", "m", "v"):
             x_, y_ = getattr(a0, name), getattr(a1, name)
-            assert torch.isfinite(x_).all() and float((x_ - y_).abs().max()) <= 1e-3 * float(y_.abs().max()), (step, name)
+            assert torch.isfinite(x_).all(), ("finite", step, name)
+            assert float((x_ - y_).abs().max()) <= 1e-2 * float(y_.abs().max()), (step, name, float((x_ - y_).abs().max()),
+                                                                                   float(y_.abs().max()))
     # (c)
     p_before = a0.p.clone()
     n0, n1 = float(opts[0].step()), float(opts[1].step())
     assert n0 == n1 == 0.0
-    assert torch.isfinite(a0.p).all() and float((a0.p - a1.p).abs().max()) <= 1e-3 * float(a1.p.abs().max())
+    assert torch.isfinite(a0.p).all() and float((a0.p - a1.p).abs().max()) <= 1e-2 * float(a1.p.abs().max())
     assert not torch.equal(a0.p, p_before)      # (Adam's first moment still moves the parameters)
 
 
