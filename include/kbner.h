@@ -216,12 +216,20 @@ int kbner_colsum_rows_f32(float* ws, int rows, int N, float* out, void* stream);
  * Bit-identical outputs (each output tile is computed the same way whoever computes it).  New capability: the reference has no
  * data-parallel path (flair/trainers/finetune_trainer.py:466,699-700). */
 int kbner_gemm_bf16_grouped_dyn(int layout, int nprob, const kbner_gemm_problem* probs, int* sched, void* stream);
-/* Which main loop the 256-row static launches of the three calls above use (round 4; process-wide, atomic; the A/B switch of
- * tools/gemm_pp_lab.py / tools/ab_step.sh and of tests): 1 (default) = the interleaved ring loop (gemm256f_kernel: 3 + 2 operand
- * slots, every fragment read / LDS-DMA piece / cursor operation between two MFMAs, last MFMA group held across the barrier),
- * 0 = the two-stage loop of rounds 1-3 (which the 128-row tiles and the dynamic-tile launches always run).  Bit-identical
- * outputs in both settings (same MFMA order per accumulator, same epilogue arithmetic).  kbner_gemm_get_variant returns the
- * current value. */
+/* Which main loops the static launches of the three calls above use (process-wide, atomic; the A/B switch of tools/gemm_pp_lab.py,
+ * tools/ab_step.sh, tools/wgrad_lab.py and of tests).  A bit field, default 3; bit-identical outputs in every setting (same MFMA
+ * order per accumulator, same epilogue arithmetic):
+ *   bit 0  the ring kernels: 256-row tiles on the interleaved ring loop (gemm256f_kernel, round 4: 3 + 2 operand slots, every
+ *          fragment read / LDS-DMA piece / cursor operation between two MFMAs), 128-row tiles on the deep ring (gemm128r_kernel,
+ *          round 5: 4 + 3 slots, A three K steps ahead).  Clear = the two-stage loop of rounds 1-3 for both tile heights (which the
+ *          dynamic-tile launches always run).
+ *   bit 1  ring, long-K launches (every K >= 16384, at least two tiles per CU -- the grouped weight gradients): the workgroups of
+ *          an XCD meet between tiles so that the sharers of an operand panel stay within what their L2 holds (round 5: L2 misses
+ *          of that launch 18.5 -> 13.9 GB, -0.5 ms per step).
+ *   bit 2  + a meeting every 256 K steps inside a tile (11.25 GB = the two-stage loop's traffic exactly; no faster in the step).
+ *   bit 3  128-row tiles on the two-stage loop although bit 0 is set (the deep ring's A/B).
+ *   bits 12-15  trace builds only.
+ * kbner_gemm_get_variant returns the current value. */
 int kbner_gemm_set_variant(int variant);
 int kbner_gemm_get_variant(void);
 /* Split-K for small micro-batches (a few dozen output tiles, long K): the K range is cut into `splits` problems of ONE grouped
