@@ -210,9 +210,12 @@ int kbner_gemm_bf16_grouped(int layout, int nprob, const kbner_gemm_problem* pro
 int kbner_gemm_tile_rows(int layout, int M, int N);
 /* out[n] += sum_r ws[r, n], rows = 2 * M / tile rows: the second half of KBNER_EPI_COLSUM_WS (ws is folded in place: clobbered) */
 int kbner_colsum_rows_f32(float* ws, int rows, int N, float* out, void* stream);
-/* The same launch with DYNAMIC tile scheduling: workgroups draw their tiles from 8 per-XCD counters (`sched`, device ints the
- * caller zeroed on this stream since their last use) instead of a static walk, so a workgroup the dispatcher places late -- its
- * CU was running an RCCL collective of the overlapped gradient exchange -- takes fewer tiles instead of doubling the launch time.
+/* The same launch with DYNAMIC tile scheduling, for steps whose CUs are shared with another kernel (an RCCL collective of the
+ * overlapped gradient exchange): a persistent static walk would run the share of every workgroup that finds no CU after all the
+ * others have finished -- twice the launch time with 8 CUs held (profiles/round5_cu_contention.txt).  Round 5: launches whose
+ * K loops are at least 16 steps long run the ring kernel with ONE workgroup per tile -- the hardware dispatcher hands tiles to
+ * CUs as they become free; `sched` is not touched --; shorter ones run the two-stage loop whose workgroups DRAW their tiles from
+ * the 8 per-XCD counters in `sched` (device ints the caller zeroed on this stream since their last use).  256-row tiles always.
  * Bit-identical outputs (each output tile is computed the same way whoever computes it).  New capability: the reference has no
  * data-parallel path (flair/trainers/finetune_trainer.py:466,699-700). */
 int kbner_gemm_bf16_grouped_dyn(int layout, int nprob, const kbner_gemm_problem* probs, int* sched, void* stream);
@@ -221,8 +224,8 @@ int kbner_gemm_bf16_grouped_dyn(int layout, int nprob, const kbner_gemm_problem*
  * order per accumulator, same epilogue arithmetic):
  *   bit 0  the ring kernels: 256-row tiles on the interleaved ring loop (gemm256f_kernel, round 4: 3 + 2 operand slots, every
  *          fragment read / LDS-DMA piece / cursor operation between two MFMAs), 128-row tiles on the deep ring (gemm128r_kernel,
- *          round 5: 4 + 3 slots, A three K steps ahead).  Clear = the two-stage loop of rounds 1-3 for both tile heights (which the
- *          dynamic-tile launches always run).
+ *          round 5: 4 + 3 slots, A three K steps ahead).  Clear = the two-stage loop of rounds 1-3 for both tile heights and for
+ *          every dynamic launch.
  *   bit 1  ring, long-K launches (every K >= 16384, at least two tiles per CU -- the grouped weight gradients): the workgroups of
  *          an XCD meet between tiles so that the sharers of an operand panel stay within what their L2 holds (round 5: L2 misses
  *          of that launch 18.5 -> 13.9 GB, -0.5 ms per step).

@@ -830,7 +830,8 @@ static __device__ __forceinline__ void xcd_tile_sync(int xcd) {
   const int v = __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const int target = (v | 31) + 1;
 #pragma unroll 1
-  for (int spin = 0; spin < 2048; ++spin) {   // <= ~2048 x (load round trip + 64 cycles): a few hundred us at the very most
+  for (int spin = 0; spin < 256; ++spin) {   // <= 256 x (load round trip + 64 cycles) ~ 0.3 ms at the very most; the workgroups of
+                                              // an undisturbed launch arrive within ~20 us of each other
     if (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target >= 0) break;
     __builtin_amdgcn_s_sleep(1);
   }
@@ -1343,12 +1344,15 @@ static int launch128r(const GroupArgs& ga, hipStream_t stream) {
   return e == hipSuccess ? 0 : -(int)e;
 }
 
+// one_tile_each: grid = number of tiles, every workgroup computes exactly ONE (its cursors find no next tile): the hardware
+// dispatcher then hands tiles to CUs as they become free -- the dynamic schedule of the long-K launches at N > 1 (see
+// gemm_grouped_impl), at the price of a cold prologue and an exposed epilogue per tile, which a K >= 3072 tile does not notice.
 template <bool A_KS, bool B_KS, int ABL = 0, bool MIDSYNC = false>
-static int launch256f(const GroupArgs& ga, hipStream_t stream) {
+static int launch256f(const GroupArgs& ga, hipStream_t stream, bool one_tile_each = false) {
   static std::atomic<unsigned long long> attr_done{0};
   const int r = kbner_set_max_lds_once(attr_done, reinterpret_cast<const void*>(gemm256f_kernel<A_KS, B_KS, ABL, MIDSYNC>), PP_LDS_BYTES);
   if (r) return r;
-  const int grid = ga.total_tiles < ga.ncu ? ga.total_tiles : ga.ncu;
+  const int grid = (one_tile_each || ga.total_tiles < ga.ncu) ? ga.total_tiles : ga.ncu;
   hipLaunchKernelGGL((gemm256f_kernel<A_KS, B_KS, ABL, MIDSYNC>), dim3(grid), dim3(512), PP_LDS_BYTES, stream, ga);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : -(int)e;
@@ -1502,6 +1506,20 @@ static int gemm_grouped_impl(int layout, int nprob, const kbner_gemm_problem* pr
   if (ga.pad_ && (gv & 4) && layout == 2 && min_k == max_k && min_k >= 512 * BK2) ga.pad_ |= 256 << 8;   // + every 256 K steps inside a tile
   ga.sched = sched;
   hipStream_t st = (hipStream_t)stream;
+  if (sched != nullptr && (gv & 1) && min_k >= 1024) {
+    // Dynamic scheduling (round 5): the ring kernel, ONE workgroup per tile.  No draw, no counters: the dispatcher places the
+    // 768 (weight gradients) ... 4096 workgroups on whatever CUs are free, which is exactly what a step that shares the GPU with a
+    // collective needs (tools/contention_lab.py: 8 CUs held -> static walk +45 %, this +13 %, the tile draw on the two-stage loop
+    // +10 % of a 7 % slower loop).  A tile pays a cold prologue and an exposed epilogue: undisturbed, the whole step with EVERY
+    // launch dynamic runs at 133.6 ms against 130.8 static (the draw on the two-stage loop: 140.6).  Launches with a K loop
+    // shorter than 16 steps (none in the encoder) keep the draw below.  `sched` is left untouched.
+    ga.pad_ = 0;
+    switch (layout) {
+      case 0: return launch256f<false, false>(ga, st, true);
+      case 1: return launch256f<false, true>(ga, st, true);
+      default: return launch256f<true, true>(ga, st, true);
+    }
+  }
   if (sched != nullptr) {
     switch (layout) {
       case 0: return launch256<false, false, true>(ga, st);

@@ -2,7 +2,8 @@
 """What the dynamic tile draw is FOR, measured on one GPU: the training step while `k` CUs are held by
 another kernel on a second stream -- the situation of a data-parallel step whose gradient buckets are in flight (RCCL's ring
 kernels own a few dozen workgroups) -- with the GEMMs launched (a) static, ring loop (the N = 1 path), (b) static, two-stage loop,
-(c) dynamic tile draw, two-stage loop (what N > 1 runs from the first bucket on).
+(c) dynamic tile draw on the two-stage loop (rounds 2-4's N > 1 path), (d) the ring kernel with one workgroup per tile (round 5:
+what N > 1 runs from the first bucket on -- the hardware dispatcher is the scheduler).
 A persistent 256-workgroup GEMM launch whose grid does not fit next to the squatters runs its late workgroups' whole static share
 after everybody else has finished; with the draw a late workgroup finds what is left.
 
@@ -50,7 +51,9 @@ def measure(k, cycles):
             times.append(e0.elapsed_time(e1))
     return sum(times) / len(times)
 
-modes = (("static ring (variant 3)", 3, False), ("static two-stage (variant 0)", 0, False), ("dynamic draw, two-stage", 3, "always"))
+modes = (("static ring (variant 3)", 3, False), ("static two-stage (variant 0)", 0, False),
+         ("dynamic: tile draw on the two-stage loop, every launch (variant 0)", 0, "always"),
+         ("dynamic: the ring kernel, one workgroup per tile (variant 3; what N > 1 runs)", 3, "always"))
 step(); step(); torch.cuda.synchronize()
 base = {}
 for name, variant, dyn in modes:
