@@ -2,7 +2,8 @@
 // grads, m, v laid out identically), global grad-norm reduction, and small flat utilities.
 // Pure HBM streaming: 16-byte vector accesses, 16-KiB chunks per workgroup, >> 256 workgroups; the clip
 // coefficient is read from device memory so clip_grad_norm_ + step + zero_grad are one pass with
-// no host synchronisation (algorithmic traffic 28 B/param + 2 B/param bf16 shadow + 4 B zeroing).
+// no host synchronisation (algorithmic traffic 28 B/param + 2 B/param bf16 shadow + 4 B zeroing where the caller asks for it:
+// since round 5 the engine leaves the GEMM-weight gradients for the next backward pass to overwrite, kbner/engine.py FusedAdamW).
 //
 // Replaces transformers==3.0.0 AdamW.step's per-tensor Python loop and
 // torch.nn.utils.clip_grad_norm_ (flair/trainers/finetune_trainer.py:1010,1018):
