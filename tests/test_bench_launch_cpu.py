@@ -45,3 +45,18 @@ def test_with_world_size_in_the_environment_it_does_not_relaunch():
                          capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
     assert json.loads(out.stdout.strip().splitlines()[-1])["world"] == 1
+
+
+def test_newest_traffic_profile_matches_the_default_workload():
+    """bench.py fills roofline.traffic from the newest profiles/*_hbm_traffic.json -- but only if that file was profiled at the
+    micro-batch the default run uses (the file says so); a default change without a new profile set would silently print null"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("kbner_bench_mod", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    pdir = os.path.join(ROOT, "profiles")
+    newest = sorted(f for f in os.listdir(pdir) if f.endswith("_hbm_traffic.json"))[-1]
+    tj = json.load(open(os.path.join(pdir, newest)))
+    assert int(tj.get("micro_batch", 128)) == mod.DEFAULT_MICRO_BATCH, (newest, tj.get("micro_batch"))
+    ks = [v for k, v in tj["kernels"].items() if "gemm256f_kernel" in k or "gemm256_kernel" in k]
+    assert len(ks) == 3 and all(v["launches"] > 0 for v in ks), newest
