@@ -5,6 +5,7 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rocprofv3 -L 2>/dev/null | grep -o "TCC_[A-Z0-9_]*" | sort -u > $out/tcc_counters.txt
 i=0
+# (WGRAD_VARIANTS, e.g. "0,1,3,7", reaches tools/wgrad_lab.py through the environment: which main loops to run)
 for set in "FETCH_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_BUBBLE_sum TCC_EA0_RDREQ_DRAM_sum"; do
   i=$((i+1))
   for tok in ${WGRAD_TOKENS_LIST:-65536 16384}; do
