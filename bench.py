@@ -114,6 +114,14 @@ def main():
     ap.add_argument("--dynamic-tiles", action="store_true", help="N=1: run the GEMMs with the dynamic tile scheduler the N>1 runs use (A/B)")
     ap.add_argument("--static-tiles", action="store_true", help="N>1: keep the static tile walk (A/B)")
     ap.add_argument("--gemm-shapes", action="store_true", help="print a per-shape GEMM timing table to stderr")
+    ap.add_argument("--gemm-variant", type=int, default=None, help="kbner_gemm_set_variant(<int>) before the run (include/kbner.h; A/B)")
+    # N > 1 knobs the first multi-GPU run can A/B without a code change (all echoed in dp_exchange)
+    ap.add_argument("--nccl-max-nchannels", type=int, default=None, help="N>1: NCCL_MAX_NCHANNELS for RCCL (fewer channels = fewer CUs "
+                    "held by a collective's kernels while backward runs; profiles/round5_cu_contention.txt)")
+    ap.add_argument("--nccl-min-nchannels", type=int, default=None, help="N>1: NCCL_MIN_NCHANNELS for RCCL")
+    ap.add_argument("--bucket-layers", type=int, default=4, choices=[4, 8, 12, 24], help="N>1: layers per gradient bucket (4 = one per grouped "
+                    "weight-gradient launch, 201 MB; 8 = two launches per all-reduce, 402 MB)")
+    ap.add_argument("--exchange-delay", type=int, default=0, help="N>1: issue a bucket's all-reduce only when this many later buckets are ready")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (small micro-batches, dropout)")
     ap.add_argument("--dropout", type=float, default=0.0,
                     help="train with this dropout probability at the encoder's three HF sites + WordDropout (default 0: "
@@ -170,6 +178,10 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # one process per GPU over RCCL ("nccl" IS RCCL on ROCm).  KBNER_DIST_BACKEND=gloo is a functional-test escape
         # hatch only (several ranks sharing one GPU on a 1-GPU box); never used for reported numbers.
+        if args.nccl_max_nchannels is not None:
+            os.environ["NCCL_MAX_NCHANNELS"] = str(args.nccl_max_nchannels)
+        if args.nccl_min_nchannels is not None:
+            os.environ["NCCL_MIN_NCHANNELS"] = str(args.nccl_min_nchannels)
         backend = os.environ.get("KBNER_DIST_BACKEND", "nccl")
         torch.cuda.set_device(local_rank % torch.cuda.device_count())
         if backend == "nccl":
@@ -180,6 +192,8 @@ def main():
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
 
+    if args.gemm_variant is not None:
+        ops.gemm_variant(args.gemm_variant)
     T, start, stop, x_idx = 29, 27, 28, 9  # resources/taggers/EN-English_x.pkl layout
     cfg_kw = dict(vocab_size=250002, max_position_embeddings=514)
     if args.model == "base":
@@ -219,7 +233,8 @@ def main():
         lo = a.offsets["emb.word"]
         Vv, Hh = a.shapes["emb.word"]
         reducer = dp.GradReducer(a.g, emb_range=(lo, lo + Vv * Hh), emb_width=Hh, compress_embedding=args.compress_embedding_grad,
-                                 emb_flags=a.emb_flags)
+                                 emb_flags=a.emb_flags, coalesce=args.bucket_layers // 4, delay=args.exchange_delay,
+                                 finalize=a.finalize_grads)
     touched = None
     if reducer is not None:
         import numpy as np
@@ -264,7 +279,7 @@ def main():
             args.blocking_allreduce = True
             touched = None
             tg.dynamic_tiles = False
-            reducer = dp.GradReducer(a.g, emb_range=None, emb_flags=a.emb_flags)
+            reducer = dp.GradReducer(a.g, emb_range=None, emb_flags=a.emb_flags, finalize=a.finalize_grads)
             tg.arena.g.zero_()
         losses.clear()
     for _ in range(args.warmup):
@@ -326,7 +341,7 @@ def main():
                 traffic = round(sum(v["launches"] * v["hbm_bytes_per_launch"] for v in ks) / n)
                 traffic_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch)" % cands[-1]
         roofline = {"bound": "mfma", "kernel": "gemm256f_kernel<A_KS,B_KS> (bf16 MFMA 16x16x32, 256x256x64 tiles, interleaved-ring K loop, all 3 layouts; "
-                              "gemm256_kernel = the two-stage loop, for dynamic tiles at N > 1)",
+                              "at N > 1 the same kernel with one workgroup per tile while a gradient bucket may be in flight)",
                     "achieved": round(ach, 2), "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "algorithmic_flops_per_launch": round(tot_fl / max(len(recs), 1)),
@@ -339,6 +354,28 @@ def main():
                                                                               "ms": round(v[1], 3), "launches": v[2]}
                                   for k, v in sorted(by.items())}}
 
+    # the HBM-bound kernels SURVEY.md section 8d assigns to the bandwidth roofline, timed live like the GEMMs: HIP events on the launch
+    # stream around every launch of ONE extra step (every embedding row live); algorithmic bytes per the survey / DESIGN.md section 3
+    roofline_hbm = None
+    if not args.no_roofline:
+        hrec = []
+        ops.HBM_HOOK = hrec
+        one_step()
+        torch.cuda.synchronize()
+        ops.HBM_HOOK = None
+        agg = {}
+        for name, e0, e1, nb in hrec:
+            d = agg.setdefault(name, [0.0, 0.0, 0])
+            d[0] += nb
+            d[1] += e0.elapsed_time(e1)
+            d[2] += 1
+        roofline_hbm = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "achievable_copy_GBs": 6290.0,
+                        "note": "achieved = algorithmic bytes / live HIP-event time per kernel over one step; peak 8 TB/s data sheet, "
+                                "6.29 TB/s = the guide's measured float4 copy",
+                        "kernels": {k: {"achieved": round(v[0] / (v[1] * 1e-3) / 1e9, 1), "frac": round(v[0] / (v[1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                        "launches": v[2], "ms": round(v[1], 3), "algorithmic_bytes": round(v[0])}
+                                    for k, v in sorted(agg.items()) if v[1] > 0}}
+
     # data parallel: how long the compute stream waits for / runs the part of the exchange backward could not hide
     # (HIP events around GradReducer.finish() on one extra step); None at N=1
     allreduce_ms_exposed, dp_stats = None, None
@@ -349,6 +386,26 @@ def main():
         dp_stats = dict(reducer.stats)
         if dp_fallback is not None:
             dp_stats["fallback"] = dp_fallback
+        # self-explaining SCALE line: what ran, with which knobs, and what each collective costs on its own
+        seen = torch.zeros(world, device=dev)
+        seen[rank] = 1.0
+        dist.all_reduce(seen)
+        dp_stats.update({"world": world, "ranks_seen": int(seen.sum().item()), "backend": dist.get_backend(),
+                         "rccl_version": ".".join(str(x) for x in torch.cuda.nccl.version()) if dist.get_backend() == "nccl" else None,
+                         "NCCL_MAX_NCHANNELS": os.environ.get("NCCL_MAX_NCHANNELS"), "NCCL_MIN_NCHANNELS": os.environ.get("NCCL_MIN_NCHANNELS"),
+                         "bucket_layers": args.bucket_layers, "exchange_delay": args.exchange_delay,
+                         "blocking_allreduce": bool(args.blocking_allreduce),
+                         "tile_schedule": "static" if args.static_tiles else "one workgroup per tile from the first bucket to the end of backward"})
+        if not args.blocking_allreduce:
+            # one more step with every bucket all-reduce BLOCKING and timed on the compute stream: the isolated cost of each collective
+            reducer.time_buckets = True
+            one_step()
+            torch.cuda.synchronize()
+            reducer.time_buckets = False
+            dp_stats["bucket_allreduce_us_isolated"] = [round(e0.elapsed_time(e1) * 1e3, 1) for _, e0, e1 in reducer.bucket_events]
+            dp_stats["bucket_bytes"] = [int(nb) for nb, _, _ in reducer.bucket_events]
+            dp_stats["bucket_busbw_GBs"] = [round(2 * (world - 1) / world * nb / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+                                            for nb, e0, e1 in reducer.bucket_events if e0.elapsed_time(e1) > 0]
 
     # secondary measurements of the SAME step at the other points BASELINE.md / SURVEY.md §8d name: micro-batch {1,4,16,32} x
     # accumulate 4 (the YAMLs run 1 x 4) and dropout 0.1 at every site -- N=1, default workload only, a few steps each
@@ -448,6 +505,33 @@ def main():
             tg._acts.clear()          # the training step's activation buffers are not needed any more
             torch.cuda.empty_cache()
             extra["cfg5"] = _tool("bench_stack").measure(encoders=3, lms=4, reps=3)
+            # SURVEY.md section 8d cfg 5 as specified: emissions f32[B, n', 29] ~ N(0, 1), transitions ~ N(0, 1) with the START row / STOP
+            # column at -1e12, Viterbi ALONE at the four (B, n') points incl. the real (32, 512); bytes/s against HBM as the survey asks
+            # (algorithmic bytes per sentence: 4 T n' emissions + 4 T^2 transitions + T n' backpointers + 8 n' outputs) -- a sequential
+            # 29 x 29 max-plus scan per token: latency-bound by construction, the fraction says so
+            gv = torch.Generator(device=dev).manual_seed(20220711)
+            trv = torch.randn(T, T, device=dev, generator=gv)
+            trv[start, :] = -1e12
+            trv[:, stop] = -1e12
+            va = {}
+            for Bv, nv in ((32, 16), (32, 64), (256, 32), (32, 512)):
+                emv = torch.randn(Bv, nv, T, device=dev, generator=gv)
+                lnv = torch.full((Bv,), nv, dtype=torch.int32, device=dev)
+                for _ in range(3):
+                    ops.crf_viterbi(emv, trv, lnv, start, stop)
+                torch.cuda.synchronize()
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record()
+                for _ in range(50):
+                    ops.crf_viterbi(emv, trv, lnv, start, stop)
+                ev1.record()
+                torch.cuda.synchronize()
+                sec = ev0.elapsed_time(ev1) * 1e-3 / 50
+                nbytes = Bv * (4 * T * nv + 4 * T * T + T * nv + 8 * nv)
+                va["B%d_n%d" % (Bv, nv)] = {"us": round(sec * 1e6, 1), "sentences_per_s": round(Bv / sec), "tokens_per_s": round(Bv * nv / sec),
+                                            "algorithmic_bytes": nbytes, "GBs": round(nbytes / sec / 1e9, 2),
+                                            "frac_of_hbm_peak": round(nbytes / sec / 1e9 / HBM_PEAK_GBS, 6)}
+            extra["cfg5_viterbi_alone_N01"] = va
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             extra["evaluate"] = _tool("train_throughput").evaluate_rate(sentences=512, batch=32, model="large")
         except Exception as e:  # secondary measurements never cost the headline number
@@ -474,6 +558,14 @@ def main():
         }
         if roofline is not None:
             out["roofline"] = roofline
+        if roofline_hbm is not None:
+            out["roofline_hbm"] = roofline_hbm
+        # rounds 1-4 quoted the headline at 128 sentences per launch: the same figure at top level, so that BENCH_r01..r06 compare
+        # like for like (`value` itself is at config.micro_batch)
+        r128 = (extra or {}).get("micro_batch_x_accumulate", {}).get("128x1", {})
+        if "value" in r128:
+            out["value_at_128x1"] = r128["value"]
+            out["mfma_fraction_end_to_end_at_128x1"] = r128.get("mfma_fraction_end_to_end")
         out["allreduce_ms_exposed"] = allreduce_ms_exposed
         if dp_stats is not None:
             out["dp_exchange"] = dp_stats

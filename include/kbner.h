@@ -228,10 +228,18 @@ int kbner_gemm_bf16_grouped_dyn(int layout, int nprob, const kbner_gemm_problem*
  *          every dynamic launch.
  *   bit 1  ring, long-K launches (every K >= 16384, at least two tiles per CU -- the grouped weight gradients): the workgroups of
  *          an XCD meet between tiles so that the sharers of an operand panel stay within what their L2 holds (round 5: L2 misses
- *          of that launch 18.5 -> 13.9 GB, -0.5 ms per step).
+ *          of that launch 18.5 -> 13.9 GB, -0.5 ms per step).  Assumes the 32 workgroups with equal blockIdx & 7 are co-resident
+ *          on one XCD (a 256-workgroup grid on an otherwise idle device); when they are not -- CUs masked, or held by another
+ *          stream's kernel -- the first meeting times out (bounded, ~0.3 ms) and that workgroup stops meeting for the rest of
+ *          its walk: correctness never depends on a meeting.
  *   bit 2  + a meeting every 256 K steps inside a tile (11.25 GB = the two-stage loop's traffic exactly; no faster in the step).
  *   bit 3  128-row tiles on the two-stage loop although bit 0 is set (the deep ring's A/B).
- *   bits 12-15  trace builds only.
+ *   bit 4  (round 6, NOT default) a single K = 1024 forward problem with the bias + GELU + GELU' epilogue and at least two 128 x 256
+ *          tiles per CU runs on csrc/gemm128x.hip: half-height tiles whose epilogue is spread over the NEXT tile's 16 K steps (the
+ *          previous tile's 64 accumulators stay alive beside the current ones).  Bit-identical; measured SLOWER than the 256-row
+ *          ring kernel on MI355X (1290-1340 against 1150-1225 us at 256 sentences: profiles/round6_gemm128x_lab.txt), kept as the
+ *          A/B it is.
+ *   bits 8-11  lab builds of gemm128x.hip only (-DX128_LAB).  bits 12-15  trace builds only.
  * kbner_gemm_get_variant returns the current value. */
 int kbner_gemm_set_variant(int variant);
 int kbner_gemm_get_variant(void);

@@ -371,7 +371,8 @@ class ModelFinetuner:
         emb_lo = arena.offsets["emb.word"]
         V, Hh = arena.shapes["emb.word"]
         reducer = dp.GradReducer(arena.g, emb_range=(emb_lo, emb_lo + V * Hh), emb_width=Hh, emb_flags=arena.emb_flags,
-                                 compress_embedding=bool(kwargs.get("compress_embedding_grad", False))) if W > 1 else None
+                                 compress_embedding=bool(kwargs.get("compress_embedding_grad", False)),
+                                 finalize=getattr(arena, "finalize_grads", None)) if W > 1 else None
         if W > 1 and overlap_allreduce:
             self.model.engine.dynamic_tiles = True   # GEMM tiles drawn dynamically: robust to CUs taken by the overlapped collectives
         log_line(log)

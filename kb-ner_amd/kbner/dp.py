@@ -147,8 +147,13 @@ class GradReducer:
     everything is a no-op."""
 
     def __init__(self, arena_g, emb_range=None, emb_width=None, sparse_threshold=0.5, compress_embedding=False, row_ops=None,
-                 emb_flags=None):
+                 emb_flags=None, coalesce=1, delay=0, time_buckets=False, finalize=None):
         self.g = arena_g
+        # `finalize`: the gradient owner's "make g this step's gradients" hook (kbner.engine.Arena.finalize_grads: the GEMM-weight
+        # gradients are not zeroed by the optimizer -- a rank whose step had NO backward pass would otherwise send the previous
+        # step's).  Called before the first byte of a step travels.
+        self.finalize = finalize
+        self._finalized = False
         self.emb_flags = emb_flags          # u8[V] "row has received a gradient" flags of the optimizer (kbner.engine.Arena)
         self.emb_range = emb_range          # (lo, hi) element range of emb.word inside the arena, or None
         self.emb_width = emb_width
@@ -156,6 +161,14 @@ class GradReducer:
         self.compress_embedding = compress_embedding
         self.ops = row_ops or _HipRowOps
         self.works, self.covered = [], []
+        # A/B knobs for the first multi-GPU run (bench.py --bucket-layers / --exchange-delay): `coalesce` consecutive ready ranges
+        # travel as ONE all-reduce (2 = 8-layer buckets of 402 MB instead of 4-layer ones); `delay` = a bucket is issued only when
+        # `delay` later ones have become ready (its all-reduce then starts one grouped weight-gradient launch later: fewer CUs taken
+        # from the layers right behind it); `time_buckets` = every bucket all-reduce is blocking and timed with events on the compute
+        # stream (diagnostic step: the isolated duration of each collective, nothing overlapped)
+        self.coalesce, self.delay, self.time_buckets = max(1, int(coalesce)), max(0, int(delay)), bool(time_buckets)
+        self._pending, self._held = [], []
+        self.bucket_events = []
         self.stats = {"buckets": 0, "bytes_overlapped": 0, "bytes_tail": 0, "emb_rows": None, "emb_mode": None}
 
     def _cpu_group(self):
@@ -170,6 +183,9 @@ class GradReducer:
         step's micro-batches -- known before the forward pass, so the union over ranks is agreed on the host while the GPU
         works, and only its rows of the word-embedding gradient travel in finish()."""
         self.works, self.covered = [], []
+        self._pending, self._held = [], []
+        self.bucket_events = []
+        self._finalized = False
         self.stats = {"buckets": 0, "bytes_overlapped": 0, "bytes_tail": 0, "emb_rows": None, "emb_mode": None}
         self._union = None
         if world_size() == 1 or self.emb_range is None or touched_ids is None or self.sparse_threshold <= 0:
@@ -193,13 +209,48 @@ class GradReducer:
         if union.size < self.sparse_threshold * V:
             self._union = torch.from_numpy(union.astype(np.int32)).to(self.g.device, non_blocking=True)
 
-    def bucket_ready(self, lo, hi):
-        if world_size() == 1 or hi <= lo:
-            return
-        self.works.append(dist.all_reduce(self.g[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+    def _issue(self, lo, hi):
+        if self.time_buckets:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            dist.all_reduce(self.g[lo:hi], op=dist.ReduceOp.SUM)
+            e1.record()
+            self.bucket_events.append((4 * (hi - lo), e0, e1))
+        else:
+            self.works.append(dist.all_reduce(self.g[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
         self.covered.append((lo, hi))
         self.stats["buckets"] += 1
         self.stats["bytes_overlapped"] += 4 * (hi - lo)
+
+    def _flush(self, everything=False):
+        """merge `coalesce` pending ranges into one bucket (contiguous ones; a gap starts a new bucket), hold `delay` of them back"""
+        while self._pending and (everything or len(self._pending) >= self.coalesce):
+            take, self._pending = self._pending[:self.coalesce], self._pending[self.coalesce:]
+            take.sort()
+            cur = list(take[0])
+            for lo, hi in take[1:]:
+                if lo == cur[1]:
+                    cur[1] = hi
+                else:
+                    self._held.append(tuple(cur))
+                    cur = [lo, hi]
+            self._held.append(tuple(cur))
+        while self._held and (everything or len(self._held) > self.delay):
+            self._issue(*self._held.pop(0))
+
+    def _finalize_once(self):
+        if not self._finalized:
+            self._finalized = True
+            if self.finalize is not None:
+                self.finalize()
+
+    def bucket_ready(self, lo, hi):
+        if world_size() == 1 or hi <= lo:
+            return
+        # (a bucket is announced by the backward pass that has just written it: the stale flag is already clear then, and
+        # finalize is a no-op; it matters in finish() for a step that ran no backward pass at all)
+        self._pending.append((lo, hi))
+        self._flush()
 
     def _complement(self, skip):
         """ranges of [0, n) neither reduced by a bucket nor listed in `skip`"""
@@ -247,6 +298,9 @@ class GradReducer:
         w = world_size()
         if w == 1:
             return 1.0
+        if not self.covered and not self._pending and not self._held:
+            self._finalize_once()      # no backward pass announced anything: g may still hold the previous step's weight gradients
+        self._flush(everything=True)   # buckets held back by `coalesce` / `delay`
         skip = []
         if self.emb_range is not None:
             self._exchange_embedding()

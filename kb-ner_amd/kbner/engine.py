@@ -107,6 +107,15 @@ class Arena:
         self.wgrad_overwrite_ok = False
         self.wgrad_stale = False
 
+    def finalize_grads(self):
+        """ONE place for the stale-gradient rule: make `g` what a consumer of "this step's gradients" may read.  If no backward
+        pass has overwritten the GEMM-weight gradients since the last optimizer step (wgrad_stale), they are still that step's:
+        zero them.  Called by FusedAdamW.step and by the data-parallel exchange (GradReducer.begin_exchange) -- any new consumer
+        of arena.g between an optimizer step and the next full backward pass calls it too.  Idempotent."""
+        if self.wgrad_stale:
+            self.g[:self.n_shadow].zero_()
+            self.wgrad_stale = False
+
     def _view(self, buf, name):
         off, shape = self.offsets[name], self.shapes[name]
         n = 1
@@ -260,7 +269,7 @@ class Tagger:
         self.arena = Arena(tagger_specs(cfg, num_tags), self.device, with_grad=not inference)
         # every weight gradient of the encoder is a tile of the grouped 256 x 256 launch (_wgrads): it may overwrite
         self.arena.wgrad_overwrite_ok = (not inference and cfg.hidden_size % 256 == 0 and cfg.intermediate_size % 256 == 0
-                                         and os.environ.get("KBNER_WGRAD_OVERWRITE", "1") != "0")
+                                         and os.environ.get("KBNER_WGRAD_OVERWRITE", "1") != "0")   # (A/B switch: README "Switches")
         self._acts = {}
         self._saved = None
         # Dropout (active only while `training`): the encoder's three HF sites (embeddings, attention probabilities,
@@ -905,9 +914,7 @@ class FusedAdamW:
         # GEMM-weight gradients: left in place for the next backward pass to overwrite (Arena.wgrad_overwrite_ok); if no backward
         # pass has written them since the last step they are that step's: a step without gradients sees zeros, as it always did
         keep = a.wgrad_overwrite_ok and a.n_shadow > 0
-        if a.wgrad_stale:
-            a.g[:a.n_shadow].zero_()
-            a.wgrad_stale = False
+        a.finalize_grads()
         if sparse:
             e0 = a.offsets["emb.word"]
             V, H = a.shapes["emb.word"]

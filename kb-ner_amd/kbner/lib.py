@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("KBNER_LIB") or os.path.join(_HERE, "libkbner_hip.so")  # KBNER_LIB: experiment builds only
+LIB_PATH = os.path.join(_HERE, "libkbner_hip.so")   # (lab tools point this at experiment builds before load(): tools/labenv.py)
 
 c_int, c_float, c_void_p, c_size_t = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
 U32 = ctypes.c_uint32
@@ -111,9 +111,6 @@ def load():
         fn.restype = res
         fn.argtypes = args
     _lib = lib
-    v = os.environ.get("KBNER_GEMM_VARIANT")   # A/B switch of the 256-row GEMM main loop (include/kbner.h: kbner_gemm_set_variant)
-    if v:
-        lib.kbner_gemm_set_variant(int(v))
     return lib
 
 

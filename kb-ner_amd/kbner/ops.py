@@ -287,9 +287,31 @@ def colsum(x, out, M=None):
 
 
 # ---------------------------------------------------------------- LayerNorm / embeddings
+HBM_HOOK = None  # bench.py sets this to a list: (kernel name, event, event, algorithmic bytes) per launch of an HBM-bound kernel
+
+
+class _hbm_timed:
+    """HIP events on the launch stream around one launch of an HBM-bound kernel, when bench.py asked for them (HBM_HOOK)"""
+
+    def __init__(self, name, nbytes):
+        self.name, self.nbytes, self.hook = name, nbytes, HBM_HOOK
+
+    def __enter__(self):
+        if self.hook is not None:
+            self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *exc):
+        if self.hook is not None:
+            self.e1.record()
+            self.hook.append((self.name, self.e0, self.e1, float(self.nbytes)))
+        return False
+
+
 def ln_fwd(h, gamma, beta, eps, y, mean, rstd):
     M, H = h.shape
-    L.call("kbner_ln_fwd", ptr(h), ptr(gamma), ptr(beta), eps, ptr(y), ptr(mean), ptr(rstd), M, H, stream_ptr())
+    with _hbm_timed("ln_fwd", 4 * M * H):   # read h, write y (bf16): DESIGN.md section 3
+        L.call("kbner_ln_fwd", ptr(h), ptr(gamma), ptr(beta), eps, ptr(y), ptr(mean), ptr(rstd), M, H, stream_ptr())
 
 
 _LN_WS = {}
@@ -306,8 +328,9 @@ def ln_ws(H, device):
 def ln_bwd(dy, h, mean, rstd, gamma, dh, dgamma, dbeta, dbias=None, dhm=None, drop=NO_DROP):
     """drop=(seed, thresh) with thresh != 0: also writes dhm = mask * dh / (1-p) (the dY of the GEMM behind the dropout)."""
     M, H = h.shape
-    L.call("kbner_ln_bwd", ptr(dy), ptr(h), ptr(mean), ptr(rstd), ptr(gamma), ptr(dh), ptr(dgamma), ptr(dbeta), ptr(dbias),
-           ptr(ln_ws(H, h.device)), M, H, ptr(dhm), drop[0], drop[1], stream_ptr())
+    with _hbm_timed("ln_bwd", (8 if drop[1] else 6) * M * H):   # read dy, h; write dh (+ dhm with dropout)
+        L.call("kbner_ln_bwd", ptr(dy), ptr(h), ptr(mean), ptr(rstd), ptr(gamma), ptr(dh), ptr(dgamma), ptr(dbeta), ptr(dbias),
+               ptr(ln_ws(H, h.device)), M, H, ptr(dhm), drop[0], drop[1], stream_ptr())
 
 
 def embed_ln_fwd(ids, pos_ids, word, pos, type0, gamma, beta, eps, h0, y, mean, rstd, drop=NO_DROP):
@@ -486,12 +509,16 @@ def lstm_step(gx, gxi, whh, h_in, h_out, c, out, outi, out_dir_stride):
 # ---------------------------------------------------------------- optimiser
 def grad_sqnorm(g, ws, out, accumulate=False):
     _chk(g, F32, "g")
-    L.call("kbner_grad_sqnorm", ptr(g), g.numel(), ptr(ws), ptr(out), 1 if accumulate else 0, stream_ptr())
+    with _hbm_timed("grad_sqnorm", 4 * g.numel()):
+        L.call("kbner_grad_sqnorm", ptr(g), g.numel(), ptr(ws), ptr(out), 1 if accumulate else 0, stream_ptr())
 
 
 def adamw(p, g, m, v, shadow, n_shadow, step_size, lr_wd, b1, b2, eps, gnorm_sq, max_norm, grad_scale, zero_grad=True):
-    L.call("kbner_adamw_hf", ptr(p), ptr(g), ptr(m), ptr(v), ptr(shadow), p.numel(), n_shadow, step_size, lr_wd, b1, b2, eps,
-           ptr(gnorm_sq), max_norm, grad_scale, 1 if zero_grad else 0, stream_ptr())
+    # 28 B / parameter (read g, p, m, v; write p, m, v) -- the bf16 shadow write and the gradient zeroing the
+    # kernel also does are not counted
+    with _hbm_timed("adamw_kernel", 28 * p.numel()):
+        L.call("kbner_adamw_hf", ptr(p), ptr(g), ptr(m), ptr(v), ptr(shadow), p.numel(), n_shadow, step_size, lr_wd, b1, b2, eps,
+               ptr(gnorm_sq), max_norm, grad_scale, 1 if zero_grad else 0, stream_ptr())
 
 
 U8 = torch.uint8
@@ -505,15 +532,18 @@ def mark_rows(ids, flags):
 
 def grad_sqnorm_rows(g2d, flags, ws, out, accumulate=True):
     _chk(g2d, F32, "g"); _chk(flags, U8, "flags")
-    L.call("kbner_grad_sqnorm_rows", ptr(g2d), ptr(flags), g2d.shape[0], g2d.shape[1], ptr(ws), ptr(out), 1 if accumulate else 0,
-           stream_ptr())
+    # (algorithmic bytes of the row kernels: every row counted -- bench.py times them with every row live)
+    with _hbm_timed("grad_sqnorm_rows", 4 * g2d.numel()):
+        L.call("kbner_grad_sqnorm_rows", ptr(g2d), ptr(flags), g2d.shape[0], g2d.shape[1], ptr(ws), ptr(out), 1 if accumulate else 0,
+               stream_ptr())
 
 
 def adamw_rows(p, g, m, v, flags, step_size, b1, b2, eps, gnorm_sq, max_norm, grad_scale, zero_grad=True):
     """HF AdamW (weight decay 0) on the flagged rows of an embedding table [rows, width]"""
     _chk(p, F32, "p"); _chk(flags, U8, "flags")
-    L.call("kbner_adamw_hf_rows", ptr(p), ptr(g), ptr(m), ptr(v), ptr(flags), p.shape[0], p.shape[1], step_size, b1, b2, eps,
-           ptr(gnorm_sq), max_norm, grad_scale, 1 if zero_grad else 0, stream_ptr())
+    with _hbm_timed("adamw_rows", 28 * p.numel()):
+        L.call("kbner_adamw_hf_rows", ptr(p), ptr(g), ptr(m), ptr(v), ptr(flags), p.shape[0], p.shape[1], step_size, b1, b2, eps,
+               ptr(gnorm_sq), max_norm, grad_scale, 1 if zero_grad else 0, stream_ptr())
 
 
 def f32_to_bf16(x, y):

@@ -119,6 +119,22 @@ def test_gemm_variants_bit_identical():
     assert out.count("checked M=") == 7, out[-2000:]
 
 
+def test_gemm128x_bit_identical():
+    """kbner_gemm_set_variant bit 4 (round 6, csrc/gemm128x.hip): the FFN-up forward GEMM (NT, K = 1024, bias + GELU + GELU') on
+    128 x 256 tiles whose epilogue runs under the next tile's K loop gives the same bits -- both outputs -- as the 256-row ring kernel:
+    at 4608 rows (2.25 tiles per workgroup: first-tile warm-up pass, a ragged walk, the drain epilogue) and at 16896 (8.25 tiles:
+    the ring's three slot phases at the tile boundary).  Own process (tools/gemm128x_lab.py switches the library's variant)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for sentences in (9, 33):
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "gemm128x_lab.py"), "--skip-bench", "--sentences", str(sentences)],
+                           cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        out = r.stdout.decode()
+        assert r.returncode == 0, out[-2000:]
+        assert "MISMATCH" not in out and out.count(": EQUAL") == 1, out[-2000:]
+
+
 def test_gemm_long_k_xcd_sync_is_bit_identical():
     """kbner_gemm_set_variant bits 1 / 2 (round 5: the ring kernel's workgroups re-synchronise per XCD at tile boundaries / every
     256 K steps on long-K launches, csrc/gemm256.hip xcd_tile_sync): a weight-gradient-shaped grouped TN launch (K = 32768 tokens,

@@ -3,7 +3,7 @@
 # processes on one box; per-shape GEMM table of each variant's last run in gpurun_out/r4/shapes_v<variant>.txt
 mkdir -p gpurun_out/r4
 for v in $1; do
-  KBNER_GEMM_VARIANT=$v timeout 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --gemm-shapes > gpurun_out/r4/ab_$v.json 2> gpurun_out/r4/shapes_v$v.txt
+  timeout 300 python bench.py --gemm-variant $v --steps 5 --warmup 2 --no-cpu-baseline --no-extras --gemm-shapes > gpurun_out/r4/ab_$v.json 2> gpurun_out/r4/shapes_v$v.txt
   python - <<PY
 import json
 d = json.loads([l for l in open("gpurun_out/r4/ab_$v.json") if l.startswith("{")][-1])

@@ -4,6 +4,8 @@ against s_memrealtime (100 MHz) between workgroup start and end -> cycles per K 
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "kb-ner_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import labenv; labenv.apply()   # KBNER_LIB / KBNER_GEMM_VARIANT (lab switches live in tools/, not in the product binding)
 import numpy as np, torch
 from kbner import ops, lib as L
 from kbner.lib import GEMM_NT, GEMM_NN, GEMM_TN, EPI_RMW32

@@ -5,6 +5,8 @@ kernel on every engine epilogue, then the engine-shaped per-layer mix at M token
 import argparse, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "kb-ner_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import labenv; labenv.apply()   # KBNER_LIB / KBNER_GEMM_VARIANT (lab switches live in tools/, not in the product binding)
 import torch
 from kbner import ops
 from kbner.lib import (EPI_ADD, EPI_BIAS, EPI_COLSUM, EPI_COLSUM_WS, EPI_DGELU, EPI_GELU, EPI_GELU_FWD, EPI_RMW32, EPI_STORE32,

@@ -5,6 +5,8 @@ sentences), WGRAD_VARIANTS (default "0,1"), WGRAD_REPS."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "kb-ner_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import labenv; labenv.apply()   # KBNER_LIB / KBNER_GEMM_VARIANT (lab switches live in tools/, not in the product binding)
 import torch
 from kbner import ops
 from kbner.lib import GEMM_TN, EPI_RMW32
