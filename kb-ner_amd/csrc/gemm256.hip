@@ -560,11 +560,11 @@ __global__ __launch_bounds__(512, 2) void gemm256f_kernel(const GroupArgs ga) {
   const int total = ga.total_tiles;
   const int gstep = (int)gridDim.x;
   // (ga.pad_: tile-boundary sync requested by the launcher -- long K, grid of 256; see xcd_tile_sync)
-  const int sync_rounds = (ga.pad_ && gstep == 256) ? total / 256 - 1 : 0;
+  const int sync_rounds = ((ga.pad_ & 1) && gstep == 256) ? total / 256 - 1 : 0;
   // ... and, when every problem of the launch has the same K, also every (sync_mask + 1) K steps inside each of the total / 256
   // tiles that every workgroup has (ga.pad_ >> 8 = the period; 0 = tile boundaries only)
   // (MIDSYNC: its own instantiation -- the test in the K loop costs the other layouts scalar registers they do not have)
-  const int sync_mask = (MIDSYNC && ga.pad_ && gstep == 256) ? (ga.pad_ >> 8) - 1 : -1;
+  const int sync_mask = (MIDSYNC && (ga.pad_ & 1) && gstep == 256) ? (ga.pad_ >> 8) - 1 : -1;
   const int sync_tiles = total / 256;
   bool sync_alive = true;   // (thread 0's: cleared by the first meeting that times out)
   G2_CLK(0)

@@ -18,6 +18,7 @@ ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--skip-bench", action="store_true")
 ap.add_argument("--cases", default="ffn_up")
 ap.add_argument("--base", type=int, default=3, help="variant bits of the reference launch")
+ap.add_argument("--variants", default="", help="extra kbner_gemm_set_variant values to time next to --base (e.g. 35,67,99: phased start)")
 ap.add_argument("--trace", default="", help="lab library: ablation ids built with the cycle trace (11 full, 13 no stores, 14 neither): print per-segment cycles")
 ap.add_argument("--abl", default="", help="lab library (KBNER_LIB=kb-ner_amd/kbner/_exp/libkbner_lab.so): ablation ids 1-8 to time next to the full kernel")
 a = ap.parse_args()
@@ -92,7 +93,7 @@ def main():
                     continue
                 fl = 2.0 * Mc * kw["N"] * kw["K"]
                 for rnd in range(2):
-                    for v in [a.base, a.base | 16] + [a.base | 16 | (int(k) << 8) for k in a.abl.split(",") if k]:
+                    for v in [a.base, a.base | 16] + [a.base | 16 | (int(k) << 8) for k in a.abl.split(",") if k] + [int(x) for x in a.variants.split(",") if x]:
                         bufs, _ = run(case, Mc, A, B, kw, v)
                         for _ in range(3):
                             run(case, Mc, A, B, kw, v, bufs)
