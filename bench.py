@@ -358,23 +358,27 @@ def main():
     # stream around every launch of ONE extra step (every embedding row live); algorithmic bytes per the survey / DESIGN.md section 3
     roofline_hbm = None
     if not args.no_roofline:
-        hrec = []
-        ops.HBM_HOOK = hrec
-        one_step()
-        torch.cuda.synchronize()
-        ops.HBM_HOOK = None
-        agg = {}
-        for name, e0, e1, nb in hrec:
-            d = agg.setdefault(name, [0.0, 0.0, 0])
-            d[0] += nb
-            d[1] += e0.elapsed_time(e1)
-            d[2] += 1
-        roofline_hbm = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "achievable_copy_GBs": 6290.0,
-                        "note": "achieved = algorithmic bytes / live HIP-event time per kernel over one step; peak 8 TB/s data sheet, "
-                                "6.29 TB/s = the guide's measured float4 copy",
-                        "kernels": {k: {"achieved": round(v[0] / (v[1] * 1e-3) / 1e9, 1), "frac": round(v[0] / (v[1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                        "launches": v[2], "ms": round(v[1], 3), "algorithmic_bytes": round(v[0])}
-                                    for k, v in sorted(agg.items()) if v[1] > 0}}
+        try:
+            hrec = []
+            ops.HBM_HOOK = hrec
+            one_step()
+            torch.cuda.synchronize()
+            ops.HBM_HOOK = None
+            agg = {}
+            for name, e0, e1, nb in hrec:
+                d = agg.setdefault(name, [0.0, 0.0, 0])
+                d[0] += nb
+                d[1] += e0.elapsed_time(e1)
+                d[2] += 1
+            roofline_hbm = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "achievable_copy_GBs": 6290.0,
+                            "note": "achieved = algorithmic bytes / live HIP-event time per kernel over one step; peak 8 TB/s data sheet, "
+                                    "6.29 TB/s = the guide's measured float4 copy",
+                            "kernels": {k: {"achieved": round(v[0] / (v[1] * 1e-3) / 1e9, 1), "frac": round(v[0] / (v[1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                            "launches": v[2], "ms": round(v[1], 3), "algorithmic_bytes": round(v[0])}
+                                        for k, v in sorted(agg.items()) if v[1] > 0}}
+        except Exception as e:   # noqa: BLE001
+            ops.HBM_HOOK = None
+            roofline_hbm = {"error": "%s: %s" % (type(e).__name__, e)}
 
     # data parallel: how long the compute stream waits for / runs the part of the exchange backward could not hide
     # (HIP events around GradReducer.finish() on one extra step); None at N=1
@@ -386,26 +390,34 @@ def main():
         dp_stats = dict(reducer.stats)
         if dp_fallback is not None:
             dp_stats["fallback"] = dp_fallback
-        # self-explaining SCALE line: what ran, with which knobs, and what each collective costs on its own
-        seen = torch.zeros(world, device=dev)
-        seen[rank] = 1.0
-        dist.all_reduce(seen)
-        dp_stats.update({"world": world, "ranks_seen": int(seen.sum().item()), "backend": dist.get_backend(),
-                         "rccl_version": ".".join(str(x) for x in torch.cuda.nccl.version()) if dist.get_backend() == "nccl" else None,
-                         "NCCL_MAX_NCHANNELS": os.environ.get("NCCL_MAX_NCHANNELS"), "NCCL_MIN_NCHANNELS": os.environ.get("NCCL_MIN_NCHANNELS"),
-                         "bucket_layers": args.bucket_layers, "exchange_delay": args.exchange_delay,
-                         "blocking_allreduce": bool(args.blocking_allreduce),
-                         "tile_schedule": "static" if args.static_tiles else "one workgroup per tile from the first bucket to the end of backward"})
-        if not args.blocking_allreduce:
-            # one more step with every bucket all-reduce BLOCKING and timed on the compute stream: the isolated cost of each collective
-            reducer.time_buckets = True
-            one_step()
-            torch.cuda.synchronize()
+        # self-explaining SCALE line: what ran, with which knobs, and what each collective costs on its own.  Everything here is a
+        # REPORT: nothing in this block may cost the scaling measurement (it has never run over RCCL on the builder's 1-GPU boxes)
+        try:
+            seen = torch.zeros(world, device=dev)
+            seen[rank] = 1.0
+            dist.all_reduce(seen)
+            try:
+                rccl = ".".join(str(x) for x in torch.cuda.nccl.version()) if dist.get_backend() == "nccl" else None
+            except Exception as e:   # noqa: BLE001
+                rccl = "unknown (%s)" % type(e).__name__
+            dp_stats.update({"world": world, "ranks_seen": int(seen.sum().item()), "backend": dist.get_backend(), "rccl_version": rccl,
+                             "NCCL_MAX_NCHANNELS": os.environ.get("NCCL_MAX_NCHANNELS"), "NCCL_MIN_NCHANNELS": os.environ.get("NCCL_MIN_NCHANNELS"),
+                             "bucket_layers": args.bucket_layers, "exchange_delay": args.exchange_delay,
+                             "blocking_allreduce": bool(args.blocking_allreduce),
+                             "tile_schedule": "static" if args.static_tiles else "one workgroup per tile from the first bucket to the end of backward"})
+            if not args.blocking_allreduce:
+                # one more step with every bucket all-reduce BLOCKING and timed on the compute stream: the isolated cost of each collective
+                reducer.time_buckets = True
+                one_step()
+                torch.cuda.synchronize()
+                reducer.time_buckets = False
+                dp_stats["bucket_allreduce_us_isolated"] = [round(e0.elapsed_time(e1) * 1e3, 1) for _, e0, e1 in reducer.bucket_events]
+                dp_stats["bucket_bytes"] = [int(nb) for nb, _, _ in reducer.bucket_events]
+                dp_stats["bucket_busbw_GBs"] = [round(2 * (world - 1) / world * nb / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+                                                for nb, e0, e1 in reducer.bucket_events if e0.elapsed_time(e1) > 0]
+        except Exception as e:   # noqa: BLE001
+            dp_stats["diagnostics_error"] = "%s: %s" % (type(e).__name__, e)
             reducer.time_buckets = False
-            dp_stats["bucket_allreduce_us_isolated"] = [round(e0.elapsed_time(e1) * 1e3, 1) for _, e0, e1 in reducer.bucket_events]
-            dp_stats["bucket_bytes"] = [int(nb) for nb, _, _ in reducer.bucket_events]
-            dp_stats["bucket_busbw_GBs"] = [round(2 * (world - 1) / world * nb / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
-                                            for nb, e0, e1 in reducer.bucket_events if e0.elapsed_time(e1) > 0]
 
     # secondary measurements of the SAME step at the other points BASELINE.md / SURVEY.md §8d name: micro-batch {1,4,16,32} x
     # accumulate 4 (the YAMLs run 1 x 4) and dropout 0.1 at every site -- N=1, default workload only, a few steps each

@@ -101,6 +101,14 @@ int kbner_crf_exact_kd(const float* emit, const float* trans, const int* lens, c
  * WRITTEN with d(sum_b wgt[b] loss[b]) / d emit (0 behind a sentence's end).  T <= 64. */
 int kbner_emission_kl(const float* emit, const float* teacher, const int* lens, const float* wgt, float tau, int teacher_is_prob,
                       int B, int n, int T, float* loss, float* demit, void* stream);
+/* Softmax head -- FastSequenceTagger(use_crf=False), sequence_tagger_model.py:2523-2539 (loss: token-level cross entropy of the
+ * emissions under the remove_x-narrowed mask) and :1177-1180, 1212-1218 (decode: arg-max of the emissions, confidence = its softmax
+ * probability).  kbner_softmax_ce: loss f32[B] WRITTEN per sentence (unweighted sum over its tokens below lens[b]), demit f32[B,n,T]
+ * WRITTEN with d(sum_b wgt[b] loss[b]) / d emit (0 behind a sentence's end).  kbner_softmax_decode: tags i32[B,n], conf f32[B,n],
+ * dist f32[B,n,T] (nullable: get_all_tags); behind a sentence's end tag 0 / 0.0.  T <= 64. */
+int kbner_softmax_ce(const float* emit, const int* tags, const int* lens, const float* wgt, int B, int n, int T, float* loss,
+                     float* demit, void* stream);
+int kbner_softmax_decode(const float* emit, const int* lens, int B, int n, int T, int* tags, float* conf, float* dist, void* stream);
 /* n-best Viterbi (SequenceTagger._viterbi_decode_nbest, sequence_tagger_model.py:1660-1818; called on KD teachers at
  * finetune_trainer.py:1600, distillation_trainer.py:819): decode i32 [B, n, nbest] tag indices and path_score f32 [B, nbest]
  * (softmax over the nbest end scores).  The NCRF++ decoder's conventions are kept as they are: trans indexed [from, to],

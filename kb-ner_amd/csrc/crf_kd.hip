@@ -484,6 +484,73 @@ __global__ __launch_bounds__(64) void emission_kl_kernel(const float* __restrict
   if (t == 0) loss[b] = acc * tau * tau;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Softmax head -- FastSequenceTagger(use_crf=False), the reference's "softmax student" (sequence_tagger_model.py:2523-2539: token-level
+// cross entropy of the emissions under the (remove_x-narrowed) mask; :1177-1180, 1212-1218: arg-max of the emissions, confidence =
+// softmax probability of that tag).  One wave per sentence, lane = tag (T <= 64), tokens in order: the per-sentence loss is a
+// deterministic sum, no atomics.
+//   loss[b] = sum_{i < len} (logsumexp(e_i) - e_i[tag_i]);   demit[b,i,t] = wgt[b] (softmax(e_i)_t - [t == tag_i]), 0 behind the end
+__global__ __launch_bounds__(64) void softmax_ce_kernel(const float* __restrict__ emit, const int* __restrict__ tags,
+                                                        const int* __restrict__ lens, const float* __restrict__ wgt, int n, int T,
+                                                        float* __restrict__ loss, float* __restrict__ demit) {
+  const int b = blockIdx.x, t = threadIdx.x;
+  const bool live = t < T;
+  const int len = min(max(lens[b], 0), n);
+  const float w = wgt[b];
+  const float* e = emit + (size_t)b * n * T;
+  const int* tg = tags + (size_t)b * n;
+  float* d = demit + (size_t)b * n * T;
+  float acc = 0.0f;
+  for (int i = 0; i < len; ++i) {
+    const float s = live ? e[(size_t)i * T + t] : -INFINITY;
+    const float smax = wave_max(s);
+    const float lq = s - smax - __logf(wave_sum(live ? __expf(s - smax) : 0.0f));      // log softmax(e_i)
+    const int gold = tg[i];
+    if (live) {
+      if (t == gold) acc -= lq;
+      d[(size_t)i * T + t] = w * (__expf(lq) - (t == gold ? 1.0f : 0.0f));
+    }
+  }
+  for (int i = len; i < n; ++i)
+    if (live) d[(size_t)i * T + t] = 0.0f;
+  acc = wave_sum(acc);
+  if (t == 0) loss[b] = acc;
+}
+
+// tags[b,i] = first arg-max of e_i (torch.max's choice among equal values on contiguous rows), conf[b,i] = softmax(e_i)[tags], and --
+// dist != nullptr -- the whole distribution; positions behind a sentence's end: tag 0, confidence 0, distribution 0
+__global__ __launch_bounds__(64) void softmax_decode_kernel(const float* __restrict__ emit, const int* __restrict__ lens, int n, int T,
+                                                            int* __restrict__ tags, float* __restrict__ conf,
+                                                            float* __restrict__ dist) {
+  const int b = blockIdx.x, t = threadIdx.x;
+  const bool live = t < T;
+  const int len = min(max(lens[b], 0), n);
+  const float* e = emit + (size_t)b * n * T;
+  for (int i = 0; i < n; ++i) {
+    if (i >= len) {
+      if (t == 0) {
+        tags[(size_t)b * n + i] = 0;
+        conf[(size_t)b * n + i] = 0.0f;
+      }
+      if (dist != nullptr && live) dist[((size_t)b * n + i) * T + t] = 0.0f;
+      continue;
+    }
+    const float s = live ? e[(size_t)i * T + t] : -INFINITY;
+    const float smax = wave_max(s);
+    const float ex = live ? __expf(s - smax) : 0.0f;
+    const float p = ex / wave_sum(ex);
+    const unsigned long long hit = __ballot(live && s == smax);
+    const int best = __ffsll((long long)hit) - 1;
+    const float pb = __shfl(p, best, 64);
+    if (t == 0) {
+      tags[(size_t)b * n + i] = best;
+      conf[(size_t)b * n + i] = pb;
+    }
+    if (dist != nullptr && live) dist[((size_t)b * n + i) * T + t] = p;
+  }
+}
+
 extern "C" {
 
 // Emission-level distillation term of a CRF student (see emission_kl_kernel): emit, teacher f32[B,n,T]; teacher_is_prob: the
@@ -500,6 +567,27 @@ int kbner_emission_kl(const float* emit, const float* teacher, const int* lens, 
   else
     hipLaunchKernelGGL(emission_kl_kernel<false>, dim3(B), dim3(64), 0, (hipStream_t)stream, emit, teacher, lens, wgt, tau, n, T,
                        loss, demit);
+  KBNER_LAUNCH_RET();
+}
+
+// Softmax head (use_crf = false): token-level cross entropy.  emit f32[B,n,T], tags i32[B,n] (read below lens[b] only), wgt f32[B]:
+// loss f32[B] WRITTEN per sentence (unweighted sum over its tokens), demit f32[B,n,T] WRITTEN with d(sum_b wgt[b] loss[b]) / d emit.
+int kbner_softmax_ce(const float* emit, const int* tags, const int* lens, const float* wgt, int B, int n, int T, float* loss,
+                     float* demit, void* stream) {
+  KBNER_CHECK_ARG(B >= 0 && n >= 0 && T > 0 && T <= 64);
+  if (B == 0) return 0;
+  KBNER_CHECK_ARG(emit != nullptr && tags != nullptr && lens != nullptr && wgt != nullptr && loss != nullptr && demit != nullptr);
+  hipLaunchKernelGGL(softmax_ce_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, emit, tags, lens, wgt, n, T, loss, demit);
+  KBNER_LAUNCH_RET();
+}
+
+// Softmax head, decode: tags i32[B,n] = arg-max tag per token, conf f32[B,n] = its softmax probability, dist f32[B,n,T] (nullable) =
+// the distributions (get_all_tags).
+int kbner_softmax_decode(const float* emit, const int* lens, int B, int n, int T, int* tags, float* conf, float* dist, void* stream) {
+  KBNER_CHECK_ARG(B >= 0 && n >= 0 && T > 0 && T <= 64);
+  if (B == 0 || n == 0) return 0;
+  KBNER_CHECK_ARG(emit != nullptr && lens != nullptr && tags != nullptr && conf != nullptr);
+  hipLaunchKernelGGL(softmax_decode_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, emit, lens, n, T, tags, conf, dist);
   KBNER_LAUNCH_RET();
 }
 

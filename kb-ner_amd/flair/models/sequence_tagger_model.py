@@ -63,7 +63,15 @@ class SequenceTagger(flair.nn.Model):
             if given.get(k):
                 raise NotImplementedError("%s=True is outside the MI355X hot path (XLM-R [+ frozen stack + BiLSTM] + linear + CRF)" % k)
         if not use_crf:
-            raise NotImplementedError("use_crf=False (softmax head) is not on the hot path")
+            # the softmax student of the reference (sequence_tagger_model.py:2523-2539 loss, :1177-1180 decode), round 6: the fine-tuning
+            # tagger only, with none of the losses that are defined on the CRF
+            if use_rnn:
+                raise NotImplementedError("use_crf=False is implemented for the fine-tuning tagger (use_rnn: false)")
+            crf_only = [k for k in ("multi_view_training", "distill_crf", "distill_posterior", "distill_exact", "distill_emission",
+                                    "distill_prob", "predict_posterior", "posterior_constraint", "crf_attention") if given.get(k)]
+            if crf_only:
+                raise NotImplementedError("use_crf=False (softmax head) with %s: these losses / decoders are implemented on the CRF "
+                                          "only" % ", ".join(crf_only))
         if use_rnn and rnn_layers != 1:
             raise NotImplementedError("rnn_layers > 1 is not implemented (the KB-NER / ACE configs use the default of 1)")
         # multi-view ("cooperative learning") training: the shipped *_multiview_posterior_* YAMLs set multi_view_training +
@@ -114,7 +122,7 @@ class SequenceTagger(flair.nn.Model):
         self.tag_dictionary = tag_dictionary
         self.tag_type = tag_type
         self.tagset_size = len(tag_dictionary)
-        self.use_crf = True
+        self.use_crf = bool(use_crf)
         self.use_rnn = bool(use_rnn)
         self.use_cnn = False
         self.sentence_level_loss = sentence_loss
@@ -175,6 +183,7 @@ class SequenceTagger(flair.nn.Model):
                               hidden_dropout_prob=float(getattr(hc, "hidden_dropout_prob", 0.1)),
                               attention_probs_dropout_prob=float(getattr(hc, "attention_probs_dropout_prob", 0.1)))
         self.engine = E.Tagger(cfg, self.tagset_size, self.start_idx, self.stop_idx, device=flair.device)
+        self.engine.use_crf = self.use_crf
         # dropout streams differ per data-parallel rank (each rank sees different sentences anyway)
         self.engine.seed_dropout(int(torch.initial_seed() % (2 ** 31)) + 7919 * int(os.environ.get("RANK", "0")))
         self.engine.word_dropout = float(self.use_word_dropout or 0.0)
@@ -368,7 +377,8 @@ class SequenceTagger(flair.nn.Model):
             for k, v in self._stack_state["rnn"].items():
                 yield "rnn." + k, v
             return
-        yield "transitions", self.engine.arena.param("transitions")
+        if self.use_crf:   # (the reference creates `transitions` only with use_crf, :390: a softmax student has no such parameter)
+            yield "transitions", self.engine.arena.param("transitions")
         yield "linear.weight", self.engine.arena.param("linear.weight")
         yield "linear.bias", self.engine.arena.param("linear.bias")
         for k, v in self.engine.hf_state_dict().items():
@@ -432,7 +442,7 @@ class SequenceTagger(flair.nn.Model):
         hb, db = self._device_batch(data_points)
         self._last = (hb, db)
         self.mask = torch.from_numpy(hb["keep"].astype(np.float32)).to(flair.device)
-        return self.engine.forward_loss(db, backward=False)
+        return self.engine.forward_loss(db, backward=False, weights=None if self.use_crf else self._softmax_weights(hb))
 
     def forward_backward(self, data_points, loss_scale=1.0, sentence_weights=None, grad_ready=None, multi_view=None,
                          distill_interpolation=None):
@@ -451,6 +461,17 @@ class SequenceTagger(flair.nn.Model):
         hb, db = self._device_batch(data_points)
         self._last = (hb, db)
         self.mask = torch.from_numpy(hb["keep"].astype(np.float32)).to(flair.device)
+        if not self.use_crf:
+            if distill_interpolation is not None or multi_view:
+                raise NotImplementedError("knowledge distillation / multi-view training of a softmax student (use_crf=False)")
+            if sentence_weights is not None and not self.sentence_level_loss:
+                raise NotImplementedError("a softmax student without sentence_loss normalises by the batch's token count: the "
+                                          "accumulation-group fusion's per-sentence weights do not express that (train with "
+                                          "fuse_accumulation=False)")
+            w = sentence_weights if sentence_weights is not None else self._softmax_weights(hb)
+            loss = self.engine.forward_loss(db, loss_scale=loss_scale, backward=True, weights=w, grad_ready=grad_ready)
+            self.last_loss_parts = (loss, None)
+            return loss
         if distill_interpolation is not None:
             # distill_mode (finetune_trainer.py:897-904 -> simple_forward_distillation_loss): the sentences carry teacher targets
             loss = self.engine.kd_loss(db, self._kd_batch(data_points, hb), float(distill_interpolation), float(self.temperature),
@@ -627,6 +648,12 @@ class SequenceTagger(flair.nn.Model):
         # + the ids the engine pads with (0 inside a row like the reference, the pad id for the rows up to a multiple of 256)
         return np.union1d(np.asarray(ids).ravel(), np.asarray([0, self.engine.cfg.pad_token_id]))
 
+    def _softmax_weights(self, hb):
+        """per-sentence weights of the softmax head's loss: 1 / B (sentence_loss) or 1 / (kept tokens of the batch) (:2534-2539)"""
+        B = hb["clens"].shape[0]
+        denom = float(B) if self.sentence_level_loss else float(max(1, int(hb["clens"].sum())))
+        return torch.full((B,), 1.0 / denom, dtype=torch.float32, device=flair.device)
+
     def _calculate_loss(self, features, sentences, mask):
         """CRF NLL of given emissions [B,n,T] (mean over sentences); narrows self.mask to the non-S-X tokens like the
         reference's remove_x branch does (:2448-2453)."""
@@ -638,6 +665,13 @@ class SequenceTagger(flair.nn.Model):
         # (compaction index and keep mask travelled with the batch: no host->device copy here, which would block the host until
         # the forward pass has drained and serialise evaluate()'s host / device pipeline)
         gathered = ops.gather_rows_f32(flat, db["cfeat_idx"])
+        if not self.use_crf:
+            # :2523-2539: token-level cross entropy under the narrowed mask, summed; / B with sentence_loss, / mask.sum() without
+            w = self._softmax_weights(hb)
+            per, _ = ops.softmax_ce(gathered.view(B, nc, T).contiguous(), db["ctags"], db["clens"], w)
+            self.mask = db["keep_f"]
+            self._last_compact = gathered.view(B, nc, T)
+            return (per * w).sum()
         logz, gold, _ = ops.crf_nll_fwd(gathered.view(B, nc, T).contiguous(), self.transitions, db["ctags"],
                                         db["clens"], self.start_idx, self.stop_idx)
         self.mask = db["keep_f"]
@@ -648,6 +682,20 @@ class SequenceTagger(flair.nn.Model):
         """Viterbi over the rows self.mask keeps, S-X / confidence 1 re-padded around them (:1193-1210)."""
         from kbner import ops
         B, n, T = feature.shape
+        if not self.use_crf:
+            # :1177-1180, 1212-1218: arg-max of the emissions at EVERY token of the sentence (no S-X compaction on this branch),
+            # confidence = the softmax probability of that tag; get_all_tags: the whole distribution per token
+            full = torch.tensor([len(s) for s in sentences], dtype=torch.int32, device=feature.device)
+            res = ops.softmax_decode(feature.contiguous().float(), full, want_dist=bool(get_all_tags))
+            tg, cf = res[0].cpu().numpy(), res[1].cpu().numpy()
+            dist = res[2].cpu().numpy() if get_all_tags else None
+            out, all_tags = [], []
+            for b, s in enumerate(sentences):
+                out.append([Label(self.tag_dictionary.get_item_for_index(int(tg[b, i])), float(cf[b, i])) for i in range(len(s))])
+                if get_all_tags:
+                    all_tags.append([[Label(self.tag_dictionary.get_item_for_index(k), float(dist[b, i, k])) for k in range(T)]
+                                     for i in range(len(s))])
+            return out, all_tags
         keep = self.mask.bool().cpu().numpy() if self.mask is not None else np.ones((B, n), bool)
         if getattr(self, "predict_posterior", False):
             # :1182-1192,1212-1218: marginals softmax(alpha + beta) over the WHOLE token sequence (no S-X compaction);
@@ -792,7 +840,8 @@ class SequenceTagger(flair.nn.Model):
         from kbner import ops
         features = self.forward(batch, prediction_mode=prediction_mode)
         last = getattr(self, "_last", None)
-        if last is None or features is None or getattr(self, "use_rnn", False) or getattr(self, "predict_posterior", False):
+        if (last is None or features is None or getattr(self, "use_rnn", False) or getattr(self, "predict_posterior", False)
+                or not getattr(self, "use_crf", True)):
             # posterior decoding, the stacked-embedding tagger (and test doubles that replace forward / _obtain_labels): the
             # generic synchronous path, labels -> per-token spans
             loss = None if speed_test else self._calculate_loss(features, batch, self.mask)
@@ -924,7 +973,7 @@ class SequenceTagger(flair.nn.Model):
             "linear.bias": self.engine.arena.param("linear.bias").detach().cpu().clone(),
             "transitions": self.engine.arena.param("transitions").detach().cpu().clone(),
             "tag_dictionary": self.tag_dictionary, "tag_type": self.tag_type, "hidden_size": self.hidden_size,
-            "use_crf": True, "use_rnn": False, "remove_x": self.remove_x, "sentence_loss": self.sentence_level_loss,
+            "use_crf": self.use_crf, "use_rnn": False, "remove_x": self.remove_x, "sentence_loss": self.sentence_level_loss,
             "word_dropout": self.use_word_dropout, "embedding_model_dir": getattr(self._emb, "name", None),
             "trained_epochs": self.trained_epochs,
             # loss switches, so that a model re-loaded as a student (load_pretrained) keeps training the way it was configured
@@ -939,7 +988,7 @@ class SequenceTagger(flair.nn.Model):
         from flair.embeddings import StackedEmbeddings, TransformerWordEmbeddings
         emb = TransformerWordEmbeddings(model=state["embedding_model_dir"], layers="-1", pooling_operation="first", fine_tune=True)
         model = cls(hidden_size=state["hidden_size"], embeddings=StackedEmbeddings([emb]), tag_dictionary=state["tag_dictionary"],
-                    tag_type=state["tag_type"], use_crf=True, use_rnn=False, remove_x=state["remove_x"],
+                    tag_type=state["tag_type"], use_crf=bool(state.get("use_crf", True)), use_rnn=False, remove_x=state["remove_x"],
                     sentence_loss=state["sentence_loss"], word_dropout=state.get("word_dropout", 0.0), dropout=0.0,
                     locked_dropout=0.0, temperature=state.get("temperature", 1),
                     **{k: state.get(k, False) for k in ("multi_view_training", "distill_posterior", "distill_crf", "distill_exact",

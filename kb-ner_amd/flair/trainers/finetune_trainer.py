@@ -420,6 +420,8 @@ class ModelFinetuner:
                 # (teacher annealing gives every micro-batch its own interpolation, finetune_trainer.py:885: a fused group would train
                 # all of them with the last one's -- the group is then run micro-batch by micro-batch)
                 fuse = bool(fuse_accumulation) and accum > 1 and not (self.distill_mode and self.teacher_annealing)
+                # (a softmax student without sentence_loss divides by the micro-batch's TOKEN count, :2539: not a per-sentence weight)
+                fuse = fuse and (getattr(self.model, "use_crf", True) or bool(getattr(self.model, "sentence_level_loss", False)))
                 group = []
                 for local_no, bi in enumerate(mine):
                     batch = loader[bi]

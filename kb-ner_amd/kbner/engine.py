@@ -665,9 +665,17 @@ class Tagger:
         self.last_pooled = pooled.view(B, nc, -1)   # bf16 [B, nc, H]: the same view's token representations (calculate_l2_loss)
         a = self.arena
         trans = a.param("transitions")
-        logz, gold, alpha = ops.crf_nll_fwd(em, trans, batch["ctags"], batch["clens"], self.start, self.stop)
         w = self._sentence_weights(weights, B)
         loss = torch.empty((1,), dtype=F32, device=self.device)
+        if not getattr(self, "use_crf", True):
+            # softmax head (FastSequenceTagger(use_crf=False), sequence_tagger_model.py:2523-2539): token-level cross entropy at the
+            # kept tokens, sum_b w[b] * (sum over the sentence's tokens); the caller's weights carry the / B or / token-count
+            per, demit = ops.softmax_ce(em, batch["ctags"], batch["clens"], w * loss_scale)
+            ops.wdiff_sum(per, torch.zeros_like(per), w, loss)
+            if backward:
+                self._backprop_emissions(demit, pooled, crow_idx, B, nc, R, S, grad_ready)
+            return loss[0]
+        logz, gold, alpha = ops.crf_nll_fwd(em, trans, batch["ctags"], batch["clens"], self.start, self.stop)
         ops.wdiff_sum(logz, gold, w, loss)
         if backward:
             dl = w * loss_scale

@@ -29,6 +29,8 @@ SIGNATURES = {
     "kbner_crf_pair_ws_floats": (c_size_t, [c_int, c_int, c_int]),
     "kbner_crf_pair_posterior": (c_int, [P, P, P, U32, c_float, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P]),
     "kbner_emission_kl": (c_int, [P, P, P, P, c_float, c_int, c_int, c_int, c_int, P, P, P]),
+    "kbner_softmax_ce": (c_int, [P, P, P, P, c_int, c_int, c_int, P, P, P]),
+    "kbner_softmax_decode": (c_int, [P, P, c_int, c_int, c_int, P, P, P, P]),
     "kbner_crf_exact_kd": (c_int, [P, P, P, P, P, P, P, c_float, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P]),
     "kbner_crf_viterbi_nbest_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "kbner_crf_viterbi_nbest": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P]),

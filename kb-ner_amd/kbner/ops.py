@@ -153,6 +153,28 @@ def emission_kl(emit, teacher, lens, weights, tau, teacher_is_prob=False):
     return loss, demit
 
 
+def softmax_ce(emit, tags, lens, weights):
+    """softmax head (use_crf=False): (loss f32[B] = sum over the sentence's tokens of the cross entropy, unweighted;
+    demit f32[B,n,T] = d(sum_b weights[b] loss[b]) / d emit)"""
+    _chk(emit, F32, "emit"); _chk(tags, I32, "tags"); _chk(lens, I32, "lens"); _chk(weights, F32, "weights")
+    B, n, T = emit.shape
+    loss = torch.empty((B,), dtype=F32, device=emit.device)
+    demit = torch.empty_like(emit)
+    L.call("kbner_softmax_ce", ptr(emit), ptr(tags), ptr(lens), ptr(weights), B, n, T, ptr(loss), ptr(demit), stream_ptr())
+    return loss, demit
+
+
+def softmax_decode(emit, lens, want_dist=False):
+    """softmax head decode: (tags i32[B,n], conf f32[B,n][, dist f32[B,n,T]])"""
+    _chk(emit, F32, "emit"); _chk(lens, I32, "lens")
+    B, n, T = emit.shape
+    tags = torch.empty((B, n), dtype=I32, device=emit.device)
+    conf = torch.empty((B, n), dtype=F32, device=emit.device)
+    dist = torch.empty((B, n, T), dtype=F32, device=emit.device) if want_dist else None
+    L.call("kbner_softmax_decode", ptr(emit), ptr(lens), B, n, T, ptr(tags), ptr(conf), ptr(dist), stream_ptr())
+    return (tags, conf, dist) if want_dist else (tags, conf)
+
+
 def crf_pair_posterior(emit, trans, lens, tau, start, stop, suppress=()):
     """teacher targets of `distill_exact` (finetune_trainer.py:1705-1722): (pair f32[B,n-1,T*T], start_score f32[B,T],
     end_score f32[B,T])"""

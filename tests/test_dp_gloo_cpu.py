@@ -116,12 +116,33 @@ def _worker(rank, world, port, out):
         flags_ok = bool(torch.all(flags.bool() | ~nz)) and (case != "sparse" or int(flags.sum()) <= 2 * n_touch)
         checks.append((case, red.stats["emb_mode"], float((g - want).abs().max()) <= tol * float(want.abs().max()) and flags_ok, scale,
                        red.stats["buckets"], red.stats["bytes_overlapped"]))
+    # 4b. the A/B knobs of the first multi-GPU run (round 6: bench.py --bucket-layers / --exchange-delay): ready ranges coalesced two
+    #     (and three: a non-contiguous range starts its own bucket) at a time, issue delayed by one bucket, the diagnostic blocking
+    #     mode -- and a step WITHOUT any backward pass, where the owner's finalize hook must run before anything travels
+    knob_checks = []
+    for coalesce, delay, timed in ((2, 0, False), (1, 1, False), (2, 1, False), (3, 0, False)):
+        gen = torch.Generator().manual_seed(300 + rank)
+        g = torch.randn(n, generator=gen)
+        want = g.clone()
+        dist.all_reduce(want)
+        red = dp.GradReducer(g, emb_range=None, coalesce=coalesce, delay=delay, time_buckets=timed)
+        red.begin(None)
+        for lo_, hi_ in ((4000, 5000), (3000, 4000), (1500, 2000), (1000, 1500), (0, 1000)):    # a gap between 3000 and 2000
+            red.bucket_ready(lo_, hi_)
+        red.finish()
+        knob_checks.append((coalesce, delay, float((g - want).abs().max()) <= 1e-6 * float(want.abs().max()), red.stats["buckets"]))
+    called = []
+    g = torch.full((n,), float(rank + 1))
+    red = dp.GradReducer(g, emb_range=None, finalize=lambda: (called.append(1), g[:100].zero_()))
+    red.begin(None)
+    red.finish()                     # no bucket was announced: g[:100] "still holds the previous step's gradients"
+    knob_checks.append(("finalize", len(called), bool(torch.all(g[:100] == 0.0)) and bool(torch.all(g[100:] == 3.0)), 0))
     # 5. replicas start identical: broadcast of the parameter arena from rank 0
     p = torch.full((100,), float(rank + 7))
     dp.broadcast_params_(p)
     same = bool(torch.all(p == 7.0))
     if rank == 0:
-        out.put(("reducer", checks, same))
+        out.put(("reducer", checks, same, knob_checks))
     dp.barrier()
     dist.destroy_process_group()
 
@@ -138,8 +159,12 @@ def test_dp_two_ranks_gloo():
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    tag, checks, same = res2
+    tag, checks, same, knob_checks = res2
     assert tag == "reducer" and same
+    # (coalesce, delay) -> buckets issued for five ready ranges with one gap: merged pairs / triples never span the gap
+    assert [(c[0], c[1], c[3]) for c in knob_checks[:4]] == [(2, 0, 3), (1, 1, 5), (2, 1, 3), (3, 0, 3)], knob_checks
+    assert all(c[2] for c in knob_checks), knob_checks
+    assert knob_checks[4][:2] == ("finalize", 1), knob_checks
     modes = {c[0]: c[1] for c in checks}
     assert modes == {"sparse": "sparse", "dense": "dense", "dense_bf16": "dense_bf16"}, modes
     for case, mode, ok, scale, nb, nbytes in checks:

@@ -192,6 +192,12 @@ def test_bench_contract_single_gpu():
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and "sample" in cb
+    # round 6: the HBM-bound kernels of SURVEY section 8d in the same line, timed live (LayerNorm fwd / bwd, AdamW dense + rows, the norms)
+    rh = d["roofline_hbm"]
+    assert rh["bound"] == "hbm" and rh["unit"] == "GB/s" and rh["peak"] == 8000.0, rh
+    for k in ("ln_fwd", "ln_bwd", "adamw_kernel", "grad_sqnorm"):
+        kk = rh["kernels"][k]
+        assert kk["launches"] >= 1 and kk["achieved"] > 0 and abs(kk["frac"] - kk["achieved"] / 8000.0) < 1e-3, (k, kk)
 
 
 def test_bench_two_ranks_one_gpu_functional():
@@ -206,6 +212,18 @@ def test_bench_two_ranks_one_gpu_functional():
     # the overlapped exchange ran: 12 / 4 = 3 buckets of 4 layers for the base model, the tail measured with HIP events
     assert d["dp_exchange"]["buckets"] == 3 and d["allreduce_ms_exposed"] is not None and d["allreduce_ms_exposed"] >= 0.0
     assert d["dp_exchange"]["emb_mode"] in ("sparse", "dense")
+    # round 6: the line explains itself (who ran, with which knobs, what each bucket's collective costs on its own)
+    x = d["dp_exchange"]
+    assert x["world"] == 2 and x["ranks_seen"] == 2 and x["backend"] == "gloo" and x["bucket_layers"] == 4 and x["exchange_delay"] == 0, x
+    assert "diagnostics_error" not in x and len(x["bucket_allreduce_us_isolated"]) == 3 and len(x["bucket_bytes"]) == 3, x
+    # ... and the knobs the first multi-GPU run can A/B: 8-layer buckets issued one bucket late give the same loss
+    e = _run_bench({"KBNER_DIST_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0"},
+                   ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                    "--master-port", "29532"],
+                   ["--gpus", "2", "--steps", "2", "--warmup", "1", "--model", "base", "--micro-batch", "2", "--accum", "1",
+                    "--no-roofline", "--bucket-layers", "8", "--exchange-delay", "1", "--nccl-max-nchannels", "8"])
+    assert e["dp_exchange"]["buckets"] == 2 and e["dp_exchange"]["bucket_layers"] == 8 and e["dp_exchange"]["NCCL_MAX_NCHANNELS"] == "8", e["dp_exchange"]
+    assert abs(e["loss_last"] - d["loss_last"]) < 1e-3 * abs(d["loss_last"]), (e["loss_last"], d["loss_last"])
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs: RCCL cannot put two ranks on one device")
@@ -942,3 +960,56 @@ def test_multiview_other_branches_train(tmp_path, flags):
     assert len(parts) >= 3 and all(np.isfinite(p) and p >= 0 for p in parts) and max(parts) > 0
     h = out["train_loss_history"]
     assert all(np.isfinite(x) for x in h) and h[-1] < h[0], h
+
+
+@pytest.mark.parametrize("sentence_loss", [True, False])
+def test_softmax_student_through_the_yaml_path(tmp_path, sentence_loss):
+    """use_crf: false in the YAML (the reference's softmax student, sequence_tagger_model.py:2523-2539 / :1177-1180): ConfigParser ->
+    FastSequenceTagger without a `transitions` parameter -> forward_loss == the oracle's token-level cross entropy of the tagger's
+    own emissions (remove_x narrowing, / B or / kept tokens) -> ModelFinetuner.train learns -> evaluate decodes EVERY token by arg-max
+    (no S-X re-padding on this branch) -> save / load round trip."""
+    import tiny_assets
+    from flair.config_parser import ConfigParser
+    from flair.custom_data_loader import ColumnDataLoader
+    from flair.models import FastSequenceTagger
+    from flair.trainers import ModelFinetuner
+    from flair.utils.from_params import Params
+    from oracle import crf as ocrf
+    cfg = tiny_assets.e2e_config(str(tmp_path), word_dropout=0.0, max_epochs=4, n_train=32, n_dev=8, n_test=8)
+    cfg["model"]["FastSequenceTagger"]["use_crf"] = False
+    cfg["model"]["FastSequenceTagger"]["sentence_loss"] = sentence_loss
+    cfg["train"]["fuse_accumulation"] = True     # (the trainer itself must leave the group unfused without sentence_loss)
+    with open(tmp_path / "cfg.yaml", "w") as f:
+        yaml.safe_dump(cfg, f)
+    torch.manual_seed(5)
+    cp = ConfigParser(Params.from_file(str(tmp_path / "cfg.yaml")))
+    td = cp.tag_dictionary
+    student = cp.create_student()
+    assert student.use_crf is False
+    names = [n for n, _ in student.named_parameters()]
+    assert "transitions" not in names and names[:2] == ["linear.weight", "linear.bias"]
+    dl = ColumnDataLoader(list(cp.corpus.train), 4, sentence_level_batch=True)
+    dl.assign_tags("ner", td)
+    batch = dl[2]
+    feats = student.forward(batch).float().cpu().numpy()
+    lengths = np.asarray([len(s) for s in batch])
+    tags = np.zeros(feats.shape[:2], np.int64)
+    for b, s in enumerate(batch):
+        tags[b, :len(s)] = [td.get_idx_for_item(t.get_tag("ner").value) for t in s]
+    want, _ = ocrf.softmax_calculate_loss(feats, tags, lengths, x_idx=td.get_idx_for_item("S-X"), sentence_loss=sentence_loss)
+    got = float(student.forward_loss(batch))
+    assert abs(got - want) <= 2e-3 * abs(want), (got, want)       # (two forward passes of a bf16 encoder: same weights, same batch)
+    trainer = ModelFinetuner(student, None, cp.corpus, config=cp.config, **cp.config["ModelFinetuner"])
+    out = trainer.train(cp.get_target_path, **cp.config["train"])
+    hist = out["train_loss_history"]
+    assert len(hist) == 4 and hist[-1] < 0.8 * hist[0], hist
+    lines = [l.split(" ") for l in open(cp.get_target_path / "ColumnCorpus-TINY-test.tsv").read().strip().split("\n") if l]
+    assert all(len(r) == 4 and 0.0 < float(r[3]) <= 1.0 for r in lines)
+    student.save(tmp_path / "softmax-student.pt")
+    again = FastSequenceTagger.load(tmp_path / "softmax-student.pt")
+    assert again.use_crf is False
+    dt = ColumnDataLoader(list(cp.corpus.test), 8, sentence_level_batch=True)
+    dt.assign_tags("ner", td)
+    r1, l1 = student.evaluate(dt)
+    r2, l2 = again.evaluate(dt)
+    assert r1.main_score == r2.main_score and abs(l1 - l2) <= 1e-6 * max(1.0, abs(l1))

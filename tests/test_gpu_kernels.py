@@ -1072,3 +1072,57 @@ def test_multiview_exact_and_l2_vs_reference_golden(golden_dir):
         if drep is not None:
             ref = g["c%d_drep" % c]
             assert np.abs(drep - ref).max() <= 2e-2 * np.abs(ref).max(), c
+
+
+def test_softmax_head_kernels_vs_reference_golden_and_oracle():
+    """kbner_softmax_ce / kbner_softmax_decode (the reference's softmax student, FastSequenceTagger(use_crf=False)): against
+    tests/golden/softmax_head.npz -- the reference's own _calculate_loss under autograd (remove_x and sentence_loss on / off) and
+    _obtain_labels (tags bit-exact, confidences, get_all_tags distributions) -- and against the fp64 oracle on ragged batches at the
+    path's real sizes (B = 128, n = 386 word tokens, T = 29; T = 64 = the kernels' limit; empty sentences)."""
+    import numpy as np
+    from kbner import ops
+    from oracle import crf as ocrf
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "softmax_head.npz"))
+    x_idx = int(z["x_idx"])
+    for ci in range(int(z["n_cases"])):
+        g = lambda k: z["c%d_%s" % (ci, k)]   # noqa: E731
+        feats, lengths, tags = g("feats"), g("lengths"), g("tags")
+        B, n, T = feats.shape
+        rx, sl = bool(int(g("remove_x"))), bool(int(g("sentence_loss")))
+        # the loss runs on the kept (non-S-X) tokens, compacted -- what the product's batch assembly hands the engine
+        cf, ct, clens, keep = ocrf.compact_remove_x(feats, tags, lengths, x_idx if rx else -1)
+        denom = float(B) if sl else float(keep.sum())
+        w = torch.full((B,), 1.0 / denom, device="cuda")
+        per, demit = ops.softmax_ce(torch.from_numpy(cf).cuda().contiguous(), torch.from_numpy(ct.astype(np.int32)).cuda(),
+                                    torch.from_numpy(clens.astype(np.int32)).cuda(), w)
+        loss = float((per * w).sum())
+        assert abs(loss - float(g("loss"))) <= 5e-6 * abs(float(g("loss"))), (ci, loss, float(g("loss")))
+        d = np.zeros_like(feats)
+        dm = demit.cpu().numpy()
+        for b in range(B):
+            idx = np.nonzero(keep[b])[0]
+            d[b, idx] = dm[b, :len(idx)]
+        assert float(np.abs(d - g("dfeats")).max()) <= 1e-5 * float(np.abs(g("dfeats")).max()), ci
+        tg, cfd, dist = ops.softmax_decode(torch.from_numpy(feats).cuda(), torch.from_numpy(lengths.astype(np.int32)).cuda(), want_dist=True)
+        valid = np.arange(n)[None, :] < lengths[:, None]
+        assert np.array_equal(tg.cpu().numpy()[valid], g("pred_tags")[valid]), ci           # integer work: bit-exact
+        assert float(np.abs(cfd.cpu().numpy() - g("pred_conf"))[valid].max()) <= 2e-6, ci
+        if ci < 2:
+            assert float(np.abs(dist.cpu().numpy() - g("pred_dist"))[valid].max()) <= 2e-6, ci
+        assert int(tg.cpu().numpy()[~valid].max(initial=0)) == 0 and float(cfd.cpu().numpy()[~valid].max(initial=0.0)) == 0.0
+    rng = np.random.default_rng(5)
+    for (B, n, T) in ((128, 386, 29), (7, 33, 64), (3, 5, 2)):
+        feats = (rng.standard_normal((B, n, T)) * 3.0).astype(np.float32)
+        lens = rng.integers(0, n + 1, size=B).astype(np.int32)
+        lens[0], lens[-1] = n, 0
+        tags = rng.integers(0, T, size=(B, n)).astype(np.int32)
+        w = rng.random(B).astype(np.float32)
+        per, demit = ops.softmax_ce(torch.from_numpy(feats).cuda(), torch.from_numpy(tags).cuda(), torch.from_numpy(lens).cuda(),
+                                    torch.from_numpy(w).cuda())
+        per_o, d_o = ocrf.softmax_ce(feats, tags, lens, w)
+        assert float(np.abs(per.cpu().numpy() - per_o).max()) <= 2e-5 * max(1.0, float(np.abs(per_o).max())), (B, n, T)
+        assert float(np.abs(demit.cpu().numpy() - d_o).max()) <= 2e-6, (B, n, T)
+        tg, cfd = ops.softmax_decode(torch.from_numpy(feats).cuda(), torch.from_numpy(lens).cuda())
+        tg_o, cf_o, _ = ocrf.softmax_decode(feats, lens)
+        valid = np.arange(n)[None, :] < lens[:, None]
+        assert np.array_equal(tg.cpu().numpy()[valid], tg_o[valid]) and float(np.abs(cfd.cpu().numpy() - cf_o)[valid].max()) <= 2e-6
