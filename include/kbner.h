@@ -247,7 +247,11 @@ int kbner_gemm_bf16_grouped_dyn(int layout, int nprob, const kbner_gemm_problem*
  *          previous tile's 64 accumulators stay alive beside the current ones).  Bit-identical; measured SLOWER than the 256-row
  *          ring kernel on MI355X (1290-1340 against 1150-1225 us at 256 sentences: profiles/round6_gemm128x_lab.txt), kept as the
  *          A/B it is.
- *   bits 8-11  lab builds of gemm128x.hip only (-DX128_LAB).  bits 12-15  trace builds only.
+ *   bit 5  (round 6, NOT default) the same launches on csrc/gemm128s.hip: 128 x 256 tiles with WAVE-SPECIALISED epilogues (four MFMA
+ *          waves hand the finished tile to four epilogue waves as bf16 through LDS; the pre-activation is rounded to bf16 before GELU, so
+ *          results agree with the other kernels to one rounding, not bit for bit).  Also slower on MI355X (1271-1280 us): the loop is
+ *          bound by the CU's vector-memory path, which the 128-row tile loads with 1.5 x the operand bytes.
+ *   bits 8-11  lab builds of gemm128x.hip / gemm128s.hip only (-DX128_LAB).  bits 12-15  trace builds only.
  * kbner_gemm_get_variant returns the current value. */
 int kbner_gemm_set_variant(int variant);
 int kbner_gemm_get_variant(void);

@@ -1150,7 +1150,7 @@ int kbner_gemm_bf16_grouped_dyn(int layout, int nprob, const kbner_gemm_problem*
 // (variant bit 4: a single K = 1024 problem with one of gemm128x.hip's epilogues runs on 128 x 256 tiles whose epilogue overlaps the
 // next tile's K loop -- when the launch has at least two such tiles per CU, otherwise the exposed last epilogue is all there is)
 static bool wants_128x(int layout, int nprob, const kbner_gemm_problem* probs, bool dyn, int variant) {
-  if (dyn || nprob != 1 || !(variant & 16)) return false;
+  if (dyn || nprob != 1 || !(variant & (16 | 32))) return false;
   const kbner_gemm_problem& s = probs[0];
   return kbner_can128x(layout, s.M, s.N, s.K, s.epi) && (long)(s.M / 128) * (s.N / T2) >= 2L * device_cu_count();
 }
@@ -1243,7 +1243,8 @@ static int gemm_grouped_impl(int layout, int nprob, const kbner_gemm_problem* pr
       default: return launch256<true, true, true>(ga, st);
     }
   }
-  if (TM == 128 && wants_128x(layout, nprob, probs, sched != nullptr, variant)) return kbner_launch128x(layout, ga, st);
+  if (TM == 128 && wants_128x(layout, nprob, probs, sched != nullptr, variant))
+    return (variant & 32) ? kbner_launch128s(layout, ga, st) : kbner_launch128x(layout, ga, st);
   if (TM == 128) {
     // (variant bit 3 clear = default: the deep-ring kernel; set: the two-stage loop's 128-row tiles of rounds 2-4, for the A/B)
     if ((variant & 1) && !(variant & 8)) return layout == 0 ? launch128r<false>(ga, st) : launch128r<true>(ga, st);

@@ -313,3 +313,5 @@ static __device__ __forceinline__ void glds16_quad(const void* sbase, unsigned v
 // launch is not one of its specialisations (the caller then takes the 256-row path), 0 / -hipError otherwise
 int kbner_launch128x(int layout, const GroupArgs& ga, hipStream_t stream);
 bool kbner_can128x(int layout, int M, int N, int K, int epi);
+// gemm128s.hip: the same tiles with wave-specialised epilogues (4 MFMA waves hand the tile to 4 epilogue waves through LDS)
+int kbner_launch128s(int layout, const GroupArgs& ga, hipStream_t stream);

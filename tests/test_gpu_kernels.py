@@ -1126,3 +1126,19 @@ def test_softmax_head_kernels_vs_reference_golden_and_oracle():
         tg_o, cf_o, _ = ocrf.softmax_decode(feats, lens)
         valid = np.arange(n)[None, :] < lens[:, None]
         assert np.array_equal(tg.cpu().numpy()[valid], tg_o[valid]) and float(np.abs(cfd.cpu().numpy() - cf_o)[valid].max()) <= 2e-6
+
+
+def test_gemm128s_matches_to_one_rounding():
+    """kbner_gemm_set_variant bit 5 (round 6, csrc/gemm128s.hip: wave-specialised epilogue -- four MFMA waves hand the tile to four
+    epilogue waves as bf16 through LDS): the FFN-up forward GEMM agrees with the 256-row ring kernel to ONE bf16 rounding of the
+    pre-activation (the hand-off rounds before GELU, as rounds 1-3 did): relative L2 < 4e-3 on both outputs, every element finite, at
+    2.25 and 8.25 tiles per workgroup (tools/gemm128x_lab.py --bit 32)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for sentences in (9, 33):
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "gemm128x_lab.py"), "--skip-bench", "--bit", "32", "--tol", "4e-3",
+                            "--sentences", str(sentences)], cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        out = r.stdout.decode()
+        assert r.returncode == 0, out[-2000:]
+        assert "MISMATCH" not in out and out.count(": EQUAL") == 1, out[-2000:]
