@@ -238,8 +238,8 @@ int kbner_gemm_bf16_grouped_dyn(int layout, int nprob, const kbner_gemm_problem*
  *          an XCD meet between tiles so that the sharers of an operand panel stay within what their L2 holds (round 5: L2 misses
  *          of that launch 18.5 -> 13.9 GB, -0.5 ms per step).  Assumes the 32 workgroups with equal blockIdx & 7 are co-resident
  *          on one XCD (a 256-workgroup grid on an otherwise idle device); when they are not -- CUs masked, or held by another
- *          stream's kernel -- the first meeting times out (bounded, ~0.3 ms) and that workgroup stops meeting for the rest of
- *          its walk: correctness never depends on a meeting.
+ *          stream's kernel -- a meeting times out (bounded, ~0.2 ms per tile boundary; correctness never depends on a meeting).
+ *          Dynamic launches (the ones that share CUs with a collective) never meet.
  *   bit 2  + a meeting every 256 K steps inside a tile (11.25 GB = the two-stage loop's traffic exactly; no faster in the step).
  *   bit 3  128-row tiles on the two-stage loop although bit 0 is set (the deep ring's A/B).
  *   bit 4  (round 6, NOT default) a single K = 1024 forward problem with the bias + GELU + GELU' epilogue and at least two 128 x 256

@@ -521,11 +521,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GroupArgs ga) {
 // for the other 31; the workgroup's other waves are held by the first K step's barrier.  Monotonic counters (one round = +32),
 // never reset; a timed-out wait only costs the sharing.  Grid = 256 launches only (32 workgroups per counter).
 __device__ int g2_xcd_round[8 * 32];   // one counter per XCD, 128 B apart
-// -> false when the round did not complete within the bound: the 32 workgroups of this counter are NOT all resident (CUs masked
-// or held by another stream's kernel / a collective: the meeting assumes co-residency, include/kbner.h) -- the caller then stops
-// meeting for the rest of its walk instead of spinning out the full bound (~0.3 ms) at every tile boundary of an already slower
-// launch.  The counters stay multiples of 32 per launch only if everybody arrives; a workgroup that gave up
-// leaves later rounds short, so the others time out once and give up too: the launch degrades to the unsynchronised ring.
+// -> false when the round did not complete within the bound.  (Round 6 tried what ADVICE round 5 suggested -- a workgroup whose meeting
+// timed out stops meeting for the rest of its walk, so that a launch whose 32 workgroups per counter are NOT co-resident does not
+// spin out the bound at every tile boundary -- and measured the opposite of an improvement on the launch the meeting exists for:
+// after a 1024-step tile the arrivals of an XCD's workgroups are spread over more than the bound, the early ones time out ROUTINELY,
+// and with them gone from the later meetings the L2-miss traffic of the weight-gradient launch went back from 30.2 to 34.4 GB per
+// launch, the unsynchronised level.  So every tile boundary meets again; the price in the non-co-resident case stays bounded at
+// ~0.2 ms per boundary, and dynamic launches -- the only ones that share CUs with a collective -- never meet: pad_ = 0 there.)
 static __device__ __forceinline__ bool xcd_tile_sync(int xcd) {
   int* c = g2_xcd_round + xcd * 32;
   const int v = __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -566,7 +568,6 @@ __global__ __launch_bounds__(512, 2) void gemm256f_kernel(const GroupArgs ga) {
   // (MIDSYNC: its own instantiation -- the test in the K loop costs the other layouts scalar registers they do not have)
   const int sync_mask = (MIDSYNC && (ga.pad_ & 1) && gstep == 256) ? (ga.pad_ >> 8) - 1 : -1;
   const int sync_tiles = total / 256;
-  bool sync_alive = true;   // (thread 0's: cleared by the first meeting that times out)
   G2_CLK(0)
 
   int lane_m = lane;   // opaque copy for the main loop's address arithmetic (see gemm256pp_kernel)
@@ -822,7 +823,7 @@ __global__ __launch_bounds__(512, 2) void gemm256f_kernel(const GroupArgs ga) {
     RF_TAKE_NEXT(nt == 1)
     RF_BODY(true)
     for (int t = 1; t < nt; ++t) {
-      if (MIDSYNC && sync_mask > 0 && (t & sync_mask) == 0 && tile_no < sync_tiles && tid == 0 && sync_alive) sync_alive = xcd_tile_sync(blockIdx.x & 7);
+      if (MIDSYNC && sync_mask > 0 && (t & sync_mask) == 0 && tile_no < sync_tiles && tid == 0) xcd_tile_sync(blockIdx.x & 7);
       // behind the barrier: request the first fragments of the new stage, then the group held back across the barrier
       // (group 7 of the previous step), which covers their latency
       b0[0] = RF_FB(0, 0);
@@ -878,7 +879,7 @@ __global__ __launch_bounds__(512, 2) void gemm256f_kernel(const GroupArgs ga) {
     ++tile_no;
     if (x_pi < 0) break;
     // long-K launches: meet the XCD's other workgroups before the next tile (every workgroup has at least sync_rounds + 1 tiles)
-    if (tile_no <= sync_rounds && tid == 0 && sync_alive) sync_alive = xcd_tile_sync(blockIdx.x & 7);
+    if (tile_no <= sync_rounds && tid == 0) xcd_tile_sync(blockIdx.x & 7);
     c_pi = x_pi;
     m0 = x_m;
     n0 = x_n;
