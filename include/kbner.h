@@ -231,9 +231,9 @@ int kbner_gemm_bf16_grouped_dyn(int layout, int nprob, const kbner_gemm_problem*
  * tools/ab_step.sh, tools/wgrad_lab.py and of tests).  A bit field, default 3; bit-identical outputs in every setting (same MFMA
  * order per accumulator, same epilogue arithmetic):
  *   bit 0  the ring kernels: 256-row tiles on the interleaved ring loop (gemm256f_kernel, round 4: 3 + 2 operand slots, every
- *          fragment read / LDS-DMA piece / cursor operation between two MFMAs), 128-row tiles on the deep ring (gemm128r_kernel,
- *          round 5: 4 + 3 slots, A three K steps ahead).  Clear = the two-stage loop of rounds 1-3 for both tile heights and for
- *          every dynamic launch.
+ *          fragment read / LDS-DMA piece / cursor operation between two MFMAs), 128-row tiles on the same schedule with three
+ *          48-KiB stages and one tile per workgroup (gemm128i_kernel, round 6; see bit 6).  Clear = the two-stage loop of rounds
+ *          1-3 for both tile heights and for every dynamic launch.
  *   bit 1  ring, long-K launches (every K >= 16384, at least two tiles per CU -- the grouped weight gradients): the workgroups of
  *          an XCD meet between tiles so that the sharers of an operand panel stay within what their L2 holds (round 5: L2 misses
  *          of that launch 18.5 -> 13.9 GB, -0.5 ms per step).  Assumes the 32 workgroups with equal blockIdx & 7 are co-resident
@@ -251,6 +251,9 @@ int kbner_gemm_bf16_grouped_dyn(int layout, int nprob, const kbner_gemm_problem*
  *          waves hand the finished tile to four epilogue waves as bf16 through LDS; the pre-activation is rounded to bf16 before GELU, so
  *          results agree with the other kernels to one rounding, not bit for bit).  Also slower on MI355X (1271-1280 us): the loop is
  *          bound by the CU's vector-memory path, which the 128-row tile loads with 1.5 x the operand bytes.
+ *   bit 6  128-row tiles on round 5's deep ring (gemm128r_kernel: 4 + 3 slots, A three K steps ahead, plain wait - barrier - burst -
+ *          compute loop) instead of gemm128i_kernel: the A/B of the small-batch regime (4 sentences per step: 24.2 / 25.0 against
+ *          25.1 / 25.7 us per 256-tile launch inside the step, 14.7 against 17.1 us for the 64-tile o-projection alone).
  *   bits 8-11  lab builds of gemm128x.hip / gemm128s.hip only (-DX128_LAB).  bits 12-15  trace builds only.
  * kbner_gemm_get_variant returns the current value. */
 int kbner_gemm_set_variant(int variant);

@@ -1048,6 +1048,202 @@ static int launch128r(const GroupArgs& ga, hipStream_t stream) {
   return e == hipSuccess ? 0 : -(int)e;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Round 6: the 128-row tiles on the INTERLEAVED ring.  gemm128r_kernel above hides the landing time of a stage by depth but still
+// runs the plain wait - barrier - DMA burst - compute loop; this kernel is the K loop round 6 built for csrc/gemm128x.hip -- three
+// 48-KiB stages (A 16 KiB + B 32 KiB), BOTH operands requested two K steps ahead (the constant wait is vmcnt(6): this step's own
+// pieces), every fragment read and LDS-DMA piece alone between two MFMAs, the step's last MFMA group held across the barrier --
+// as a loop over a run-time number of K steps with the ordinary epilogues behind it: one workgroup per tile (small micro-batches:
+// the YAMLs' 4 sentences per optimizer step, where every forward / dgrad GEMM is a chain of 16 K steps on at most 256 tiles).
+// Same fragment maps, MFMA order and epilogue arithmetic as the other kernels: bit-identical results.
+#define R2_A_BYTES 16384
+#define R2_B_BASE (3 * R2_A_BYTES)
+#define R2_LDS_BYTES (R2_B_BASE + 3 * TILE2_BYTES)
+
+template <bool B_KS>
+__global__ __launch_bounds__(512, 2) void gemm128i_kernel(const GroupArgs ga) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  int lane = tid & 63;
+  asm volatile("" : "+v"(lane));
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 2, wn = wid & 3;
+  GemmProblem g;
+  int m0, n0;
+  pick_tile<128>(ga, blockIdx.x, ga.total_tiles, g, m0, n0);
+  const int nt = g.K / BK2;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_void*)smem);
+  unsigned va[2], vb[4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = (wid * 2 + j) * 8 + (lane >> 3);
+    va[j] = (unsigned)(row * g.lda + (((lane & 7) ^ kc_swz(row)) << 3)) * 2u - (unsigned)j * 1024u;
+  }
+  stage_voff<B_KS, true>(g.ldb, wid, lane, vb);
+  const bf16_t* a_base = uniform_ptr(g.A + (size_t)m0 * g.lda);
+  const bf16_t* b_base = uniform_ptr(B_KS ? g.B + n0 : g.B + (size_t)n0 * g.ldb);
+  const size_t b_kstep = B_KS ? (size_t)BK2 * g.ldb : (size_t)BK2;
+  const unsigned a_dst0 = lds0 + wid * 2048, b_dst0 = lds0 + R2_B_BASE + wid * 4096;
+  unsigned laneA, laneB;
+  {
+    const int row = wm * 64 + (lane & 15);
+    laneA = lds0 + row * 128 + ((((lane >> 4)) ^ kc_swz(row)) << 4);
+    if (!B_KS) {
+      const int j = lane & 15;
+      const int brow = wn * 64 + (j >> 2) * 8 + (j & 3);
+      laneB = lds0 + R2_B_BASE + brow * 128 + ((((lane >> 4)) ^ kcb_swz(brow)) << 4);
+    } else {
+      const int p = lane & 15;
+      const int r = (lane >> 4) * 8 + (p >> 2);
+      laneB = lds0 + R2_B_BASE + r * 512 + (((wn * 4 + ((p & 3) >> 1)) ^ ks_swz(r)) << 5) + (((p & 3) & 1) << 4);
+    }
+  }
+  typedef const s8v __attribute__((address_space(3))) lds_s8v;
+  typedef s4v __attribute__((address_space(3))) lds_s4v;
+  auto tr2_ = [&](unsigned addr) -> bf16x8 {
+    const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(size_t)addr);
+    const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(size_t)(addr + 4u * 512u));
+    s8v v;
+    v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+    v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+    return __builtin_bit_cast(bf16x8, v);
+  };
+  unsigned pa0 = laneA, pa1 = laneA ^ 64u, pb0 = laneB, pb1 = laneB ^ 64u;
+  auto fa_ = [&](int ks, int mi) -> bf16x8 {
+    const s8v v = *reinterpret_cast<lds_s8v*>((size_t)((ks ? pa1 : pa0) + (unsigned)mi * 2048u));
+    return __builtin_bit_cast(bf16x8, v);
+  };
+  auto fb_ = [&](int ks, int ni) -> bf16x8 {
+    if constexpr (!B_KS) {
+      const s8v v = *reinterpret_cast<lds_s8v*>((size_t)((ks ? pb1 : pb0) + (unsigned)((ni >> 1) * 4096 + (ni & 1) * 512)));
+      return __builtin_bit_cast(bf16x8, v);
+    } else {
+      return tr2_(((ni >> 1) ? pb1 : pb0) + (unsigned)ks * 16384u + (unsigned)(ni & 1) * 8u);
+    }
+  };
+  // prologue: stages 0 and 1 (a one-step tile re-reads stage 0 into slot 1: nobody reads it)
+  {
+    const int t1 = nt > 1 ? 1 : 0;
+    glds16_pair<0>(a_base, va[0], va[1], a_dst0);
+    glds16_quad(b_base, vb[0], vb[1], vb[2], vb[3], b_dst0);
+    glds16_pair<0>(a_base + (size_t)t1 * BK2, va[0], va[1], a_dst0 + R2_A_BYTES);
+    glds16_quad(b_base + (size_t)t1 * b_kstep, vb[0], vb[1], vb[2], vb[3], b_dst0 + TILE2_BYTES);
+  }
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  pp_barrier();
+  unsigned sa_off = 0, sb_off = 0;
+  unsigned a_dst = a_dst0 + 2 * R2_A_BYTES, b_dst = b_dst0 + 2 * TILE2_BYTES;
+  f4v acc[4][4];
+  const f4v zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+  bf16x8 b0[4], b1[4], a0[2], a1[2];
+#define ISB() __builtin_amdgcn_sched_barrier(0)
+#define INOP (void)0
+#define IMF(a, b, mi, ni, Z) \
+  acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[ni], a[(mi) & 1], (Z) ? zero4 : acc[mi][ni], 0, 0, 0)
+#define IGROUP(Z, a, b, pr, f0, f1, f2, f3, f4, f5, f6, f7) \
+  IMF(a, b, 2 * (pr), 0, Z); ISB(); f0; ISB();               \
+  IMF(a, b, 2 * (pr), 1, Z); ISB(); f1; ISB();               \
+  IMF(a, b, 2 * (pr), 2, Z); ISB(); f2; ISB();               \
+  IMF(a, b, 2 * (pr), 3, Z); ISB(); f3; ISB();               \
+  IMF(a, b, 2 * (pr) + 1, 0, Z); ISB(); f4; ISB();           \
+  IMF(a, b, 2 * (pr) + 1, 1, Z); ISB(); f5; ISB();           \
+  IMF(a, b, 2 * (pr) + 1, 2, Z); ISB(); f6; ISB();           \
+  IMF(a, b, 2 * (pr) + 1, 3, Z); ISB(); f7; ISB();
+#define IPB(J) glds16_piece<J>(pb_src, vb[J], b_dst)
+#define IPA(J) glds16_piece<J>(pa_src, va[J], a_dst)
+  // groups 0-2 of a step (group 3 is held across the barrier), the wait, the barrier, the slot rotation
+#define IBODY(Z)                                                                                                    \
+  {                                                                                                                 \
+    IGROUP(Z, a0, b0, 0, a1[0] = fa_(0, 2), IPA(0), a1[1] = fa_(0, 3), IPA(1), INOP, INOP, INOP, INOP)              \
+    IGROUP(Z, a1, b0, 1, b1[0] = fb_(1, 0), a0[0] = fa_(1, 0), b1[1] = fb_(1, 1), b1[2] = fb_(1, 2), b1[3] = fb_(1, 3), \
+           a0[1] = fa_(1, 1), INOP, INOP)                                                                           \
+    IGROUP(false, a0, b1, 0, a1[0] = fa_(1, 2), INOP, a1[1] = fa_(1, 3), INOP, INOP, INOP, INOP, INOP)              \
+    a_dst = (a_dst == a_dst0 + 2 * R2_A_BYTES) ? a_dst0 : a_dst + R2_A_BYTES;                                       \
+    b_dst = (b_dst == b_dst0 + 2 * TILE2_BYTES) ? b_dst0 : b_dst + TILE2_BYTES;                                     \
+    sa_off = (sa_off == 2 * R2_A_BYTES) ? 0u : sa_off + R2_A_BYTES;                                                 \
+    sb_off = (sb_off == 2 * TILE2_BYTES) ? 0u : sb_off + TILE2_BYTES;                                               \
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                                \
+    __builtin_amdgcn_s_waitcnt(0xC07F);                                                                             \
+    pp_barrier();                                                                                                   \
+    pa0 = laneA + sa_off;                                                                                           \
+    asm volatile("" : "+v"(pa0));                                                                                   \
+    pa1 = pa0 ^ 64u;                                                                                                \
+    asm volatile("" : "+v"(pa1));                                                                                   \
+    pb0 = laneB + sb_off;                                                                                           \
+    asm volatile("" : "+v"(pb0));                                                                                   \
+    pb1 = pb0 ^ 64u;                                                                                                \
+    asm volatile("" : "+v"(pb1));                                                                                   \
+  }
+  // step 0: first fragments, the B pieces of stage 2 in a block, groups 0-2
+  {
+    const int tt = nt > 2 ? 2 : nt - 1;
+    const bf16_t* pa_src = a_base + (size_t)tt * BK2;
+    const bf16_t* pb_src = b_base + (size_t)tt * b_kstep;
+    b0[0] = fb_(0, 0); b0[1] = fb_(0, 1); b0[2] = fb_(0, 2); b0[3] = fb_(0, 3);
+    a0[0] = fa_(0, 0); a0[1] = fa_(0, 1);
+    ISB();
+    IPB(0); IPB(1); IPB(2); IPB(3);
+    ISB();
+    IBODY(true)
+  }
+#pragma unroll 1
+  for (int t = 1; t < nt; ++t) {
+    const int tt = t + 2 < nt ? t + 2 : nt - 1;
+    const bf16_t* pa_src = a_base + (size_t)tt * BK2;
+    const bf16_t* pb_src = b_base + (size_t)tt * b_kstep;
+    b0[0] = fb_(0, 0);
+    a0[0] = fa_(0, 0);
+    ISB();
+    IGROUP(false, a1, b1, 1, b0[1] = fb_(0, 1), IPB(0), b0[2] = fb_(0, 2), IPB(1), b0[3] = fb_(0, 3), IPB(2), a0[1] = fa_(0, 1), IPB(3))
+    IBODY(false)
+  }
+  IGROUP(false, a1, b1, 1, INOP, INOP, INOP, INOP, INOP, INOP, INOP, INOP)   // the last step's held group
+#undef IBODY
+#undef IPA
+#undef IPB
+#undef IGROUP
+#undef IMF
+#undef INOP
+#undef ISB
+  // the re-read pieces of the last steps may still be landing in the slots the epilogue uses as scratch
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  const int epi = g.epi;
+  int lane_e = lane;
+  asm volatile("" : "+v"(lane_e));
+  unsigned char* scr = smem + wid * 4096;
+  if (!B_KS) {
+    switch (epi) {
+      case 0: epilogue256<0, 4>(g, acc, m0, n0, wm, wn, lane_e, scr); break;
+      case EPI_BIAS: epilogue256<EPI_BIAS, 4>(g, acc, m0, n0, wm, wn, lane_e, scr); break;
+      case EPI_BIAS | EPI_GELU: epilogue256<(EPI_BIAS | EPI_GELU), 4>(g, acc, m0, n0, wm, wn, lane_e, scr); break;
+      case EPI_BIAS | EPI_GELU_FWD: epilogue256<(EPI_BIAS | EPI_GELU_FWD), 4>(g, acc, m0, n0, wm, wn, lane_e, scr); break;
+      case EPI_BIAS | EPI_ADD: epilogue256<(EPI_BIAS | EPI_ADD), 4>(g, acc, m0, n0, wm, wn, lane_e, scr); break;
+      case EPI_BIAS | EPI_ADD | EPI_DROP: epilogue256<(EPI_BIAS | EPI_ADD | EPI_DROP), 4>(g, acc, m0, n0, wm, wn, lane_e, scr); break;
+      default: epilogue256<-1, 4>(g, acc, m0, n0, wm, wn, lane_e, scr); break;
+    }
+  } else if (epi == EPI_ADD) {
+    epilogue256<EPI_ADD, 4>(g, acc, m0, n0, wm, wn, lane_e, scr);
+  } else if (epi == 0) {
+    epilogue256<0, 4>(g, acc, m0, n0, wm, wn, lane_e, scr);
+  } else {
+    epilogue256<-1, 4>(g, acc, m0, n0, wm, wn, lane_e, scr);
+  }
+}
+
+template <bool B_KS>
+static int launch128i(const GroupArgs& ga, hipStream_t stream) {
+  static std::atomic<unsigned long long> attr_done{0};
+  const int r = kbner_set_max_lds_once(attr_done, reinterpret_cast<const void*>(gemm128i_kernel<B_KS>), R2_LDS_BYTES);
+  if (r) return r;
+  hipLaunchKernelGGL((gemm128i_kernel<B_KS>), dim3(ga.total_tiles), dim3(512), R2_LDS_BYTES, stream, ga);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : -(int)e;
+}
+
 // one_tile_each: grid = number of tiles, every workgroup computes exactly ONE (its cursors find no next tile): the hardware
 // dispatcher then hands tiles to CUs as they become free -- the dynamic schedule of the long-K launches at N > 1 (see
 // gemm_grouped_impl), at the price of a cold prologue and an exposed epilogue per tile, which a K >= 3072 tile does not notice.
@@ -1248,6 +1444,8 @@ static int gemm_grouped_impl(int layout, int nprob, const kbner_gemm_problem* pr
     return (variant & 32) ? kbner_launch128s(layout, ga, st) : kbner_launch128x(layout, ga, st);
   if (TM == 128) {
     // (variant bit 3 clear = default: the deep-ring kernel; set: the two-stage loop's 128-row tiles of rounds 2-4, for the A/B)
+    // (variant bit 6 set: round 5's deep-ring kernel with the plain loop, for the A/B; clear = default: the interleaved ring, round 6)
+    if ((variant & 1) && !(variant & 8) && !(variant & 64)) return layout == 0 ? launch128i<false>(ga, st) : launch128i<true>(ga, st);
     if ((variant & 1) && !(variant & 8)) return layout == 0 ? launch128r<false>(ga, st) : launch128r<true>(ga, st);
     return layout == 0 ? launch256<false, false, false, 128>(ga, st) : launch256<false, true, false, 128>(ga, st);
   }

@@ -130,31 +130,44 @@ __global__ __launch_bounds__(256) void head_bwd_dx_kernel(const float* __restric
 
 // dw[t,h] += sum_r de[r,t] * x[r,h] ; db[t] += sum_r de[r,t]
 // grid = (ceil(H/256), ceil(R/64)); thread owns column h; 64 rows of de staged in LDS.
+// TMAX (32 for T <= 32: the 29 tags of the KB-NER dictionaries; 64 otherwise): the staged rows have a FIXED stride of TMAX floats,
+// zero-padded behind T, so that a row's tag values leave LDS as TMAX / 4 broadcast ds_read_b128 and the tag loop is straight-line code
+// (round 6: with the runtime stride T the compiler issued one ds_read_b32 per (row, tag) and waited for each -- 1856 exposed LDS
+// latencies per block, 110 us per launch whatever the batch, 0.9 % of a 4-sentence optimizer step).
+template <int TMAX>
 __global__ __launch_bounds__(256) void head_bwd_dw_kernel(const float* __restrict__ de, const bf16_t* __restrict__ x,
                                                           float* __restrict__ dw, float* __restrict__ db, int R, int H, int T) {
-  __shared__ float sde[64 * HEAD_MAXT];
+  __shared__ __attribute__((aligned(16))) float sde[64 * TMAX];
   const int h = blockIdx.x * 256 + threadIdx.x;
   const int r0 = blockIdx.y * 64;
   const int nr = min(64, R - r0);
-  for (int i = threadIdx.x; i < nr * T; i += 256) sde[i] = de[(size_t)r0 * T + i];
+  for (int i = threadIdx.x; i < 64 * TMAX; i += 256) {
+    const int r = i / TMAX, t = i % TMAX;
+    sde[i] = (r < nr && t < T) ? de[(size_t)(r0 + r) * T + t] : 0.0f;
+  }
   __syncthreads();
-  float acc[HEAD_MAXT];
+  float acc[TMAX];
 #pragma unroll
-  for (int t = 0; t < HEAD_MAXT; ++t) acc[t] = 0.0f;
+  for (int t = 0; t < TMAX; ++t) acc[t] = 0.0f;
   if (h < H) {
     for (int r = 0; r < nr; ++r) {
       const float xv = bf2f(x[(size_t)(r0 + r) * H + h]);
 #pragma unroll
-      for (int t = 0; t < HEAD_MAXT; ++t)
-        if (t < T) acc[t] += sde[r * T + t] * xv;
+      for (int t4 = 0; t4 < TMAX / 4; ++t4) {
+        const float4 d = *reinterpret_cast<const float4*>(&sde[r * TMAX + t4 * 4]);
+        acc[t4 * 4 + 0] += d.x * xv;
+        acc[t4 * 4 + 1] += d.y * xv;
+        acc[t4 * 4 + 2] += d.z * xv;
+        acc[t4 * 4 + 3] += d.w * xv;
+      }
     }
 #pragma unroll
-    for (int t = 0; t < HEAD_MAXT; ++t)
+    for (int t = 0; t < TMAX; ++t)
       if (t < T) atomicAdd(dw + (size_t)t * H + h, acc[t]);
   }
   if (blockIdx.x == 0 && threadIdx.x < T) {
     float s = 0.0f;
-    for (int r = 0; r < nr; ++r) s += sde[r * T + threadIdx.x];
+    for (int r = 0; r < nr; ++r) s += sde[r * TMAX + threadIdx.x];
     atomicAdd(db + threadIdx.x, s);
   }
 }
@@ -257,8 +270,12 @@ int kbner_head_bwd_dx(const float* de, const float* w, bf16_t* dx, int R, int H,
 int kbner_head_bwd_dw(const float* de, const bf16_t* x, float* dw, float* db, int R, int H, int T, void* stream) {
   KBNER_CHECK_ARG(R >= 0 && H > 0 && T > 0 && T <= HEAD_MAXT);
   if (R == 0) return 0;
-  hipLaunchKernelGGL(head_bwd_dw_kernel, dim3((H + 255) / 256, (R + 63) / 64), dim3(256), 0, (hipStream_t)stream, de, x, dw,
-                     db, R, H, T);
+  if (T <= 32)
+    hipLaunchKernelGGL(head_bwd_dw_kernel<32>, dim3((H + 255) / 256, (R + 63) / 64), dim3(256), 0, (hipStream_t)stream, de, x, dw,
+                       db, R, H, T);
+  else
+    hipLaunchKernelGGL(head_bwd_dw_kernel<HEAD_MAXT>, dim3((H + 255) / 256, (R + 63) / 64), dim3(256), 0, (hipStream_t)stream, de, x,
+                       dw, db, R, H, T);
   KBNER_LAUNCH_RET();
 }
 
@@ -343,7 +360,9 @@ extern "C" int kbner_colsum_rows_f32(float* ws, int rows, int N, float* out, voi
   KBNER_CHECK_ARG(ws != nullptr && out != nullptr && rows > 0 && N > 0);
   const int chunk = 16;
   const dim3 gx((N + 255) / 256);
-  if (rows > chunk && rows % chunk == 0) {
+  // (two passes only when there are enough partial rows to be worth a second launch: at 4 sentences per step the workspace has 32 rows
+  // and the second launch was half of this call's 9.6 us, 48 times per step)
+  if (rows > 4 * chunk && rows % chunk == 0) {
     hipLaunchKernelGGL(colsum_fold_kernel, dim3(gx.x, rows / chunk), dim3(1024), 0, (hipStream_t)stream, ws, chunk, 1, chunk, N,
                        (float*)nullptr);
     hipLaunchKernelGGL(colsum_fold_kernel, gx, dim3(1024), 0, (hipStream_t)stream, ws, 0, chunk, rows / chunk, N, out);

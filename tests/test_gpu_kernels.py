@@ -107,11 +107,12 @@ def test_gemm_variants_bit_identical():
     """the interleaved-ring main loop (gemm256f_kernel, variant 1 = default) against the two-stage loop of rounds 1-3 (variant 0) on
     every engine epilogue: one tile, several tiles per CU (ring wrap across tiles), K = 64 (one stage per tile), K = 128 / 192 / 320
     (ring phases 2, 0, 2 mod 3 at the tile boundary).  Same MFMA order per output element, so the results must be EQUAL, fp32
-    column sums included.  Own process (tools/gemm_pp_lab.py switches the library's variant)."""
+    column sums included.  Variant 65 = bit 6: the 128-row launches on round 5's deep ring (gemm128r_kernel) instead of round 6's
+    interleaved ring (gemm128i_kernel, the default since).  Own process (tools/gemm_pp_lab.py switches the library's variant)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "gemm_pp_lab.py"), "--skip-bench", "--variants", "0,1"], cwd=root,
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "gemm_pp_lab.py"), "--skip-bench", "--variants", "0,1,65"], cwd=root,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     out = r.stdout.decode()
     assert r.returncode == 0, out[-2000:]
@@ -119,6 +120,7 @@ def test_gemm_variants_bit_identical():
     assert out.count("checked M=") == 7, out[-2000:]
 
 
+@pytest.mark.gpu
 def test_gemm128x_bit_identical():
     """kbner_gemm_set_variant bit 4 (round 6, csrc/gemm128x.hip): the FFN-up forward GEMM (NT, K = 1024, bias + GELU + GELU') on
     128 x 256 tiles whose epilogue runs under the next tile's K loop gives the same bits -- both outputs -- as the 256-row ring kernel:
