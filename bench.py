@@ -360,6 +360,8 @@ def main():
     if not args.no_roofline:
         try:
             hrec = []
+            if tg.arena.emb_flags is not None:
+                tg.arena.emb_flags.fill_(3)   # LIVE | TOUCHED: the row kernels move their whole algorithmic bytes in this step
             ops.HBM_HOOK = hrec
             one_step()
             torch.cuda.synchronize()
@@ -501,7 +503,7 @@ def main():
             cv["%dx1" % B] = {"value": round(B / sec, 2), "ms_per_step": round(sec * 1e3, 3)}
             sec = timed_seq(mb4c, steps=8, warm=2)
             cv["1x4_fused_by_trainer"] = {"value": round(4 / sec, 2), "ms_per_step": round(sec * 1e3, 3)}
-            cv["live_rows"] = int(tg.arena.emb_flags.sum())
+            cv["live_rows"] = int((tg.arena.emb_flags != 0).sum())
             extra["corpus_vocabulary_30k"] = cv
         # BASELINE.md section 2 row 5 / SURVEY.md section 8d cfg 5 (ACE-style stack, inference): Viterbi alone and encoder + Viterbi at
         # the four (B, n') points, the whole stack (3 XLM-R-large-sized encoders + 4 character LMs + BiLSTM + CRF) at B = 32, and

@@ -304,11 +304,18 @@ int kbner_adamw_hf(float* p, float* g, float* m, float* v, kbner_bf16* shadow, s
 /* The same update restricted to the rows of an embedding table that have ever received a gradient (flags u8[rows], set by
    kbner_mark_rows from the looked-up ids): an unflagged row has g = m = v = 0, so with weight decay 0 HF AdamW leaves it
    unchanged and it is not read.  (The reference's dense optimizer.step() walks all 250 002 rows of XLM-R's word embedding,
-   46 % of the parameters, finetune_trainer.py:1018.)  kbner_grad_sqnorm_rows is the clip norm's share of those rows. */
+   46 % of the parameters, finetune_trainer.py:1018.)  kbner_grad_sqnorm_rows is the clip norm's share of those rows.
+   A flag is two bits: KBNER_ROW_LIVE = the row has ever received a gradient (its moments are non-zero, every step moves it),
+   KBNER_ROW_TOUCHED = it has received one since the last zeroing update.  kbner_mark_rows sets both; kbner_adamw_hf_rows with
+   zero_grad clears TOUCHED on the rows it zeroes.  A live row that is not touched holds g == 0 exactly: the clip norm skips it and
+   the update neither reads nor re-zeroes its gradient (same expression with g = 0: bit-identical to the dense update).  A caller
+   that writes a row's gradient by any other route sets both bits itself. */
+#define KBNER_ROW_LIVE 1
+#define KBNER_ROW_TOUCHED 2
 int kbner_mark_rows(const int* ids, int n, unsigned char* flags, int rows, void* stream);
 int kbner_grad_sqnorm_rows(const float* g, const unsigned char* flags, int rows, int width, float* ws, float* out, int accumulate,
                            void* stream);
-int kbner_adamw_hf_rows(float* p, float* g, float* m, float* v, const unsigned char* flags, int rows, int width, float step_size,
+int kbner_adamw_hf_rows(float* p, float* g, float* m, float* v, unsigned char* flags, int rows, int width, float step_size,
                         float b1, float b2, float eps, const float* gnorm_sq, float max_norm, float grad_scale, int zero_grad,
                         void* stream);
 int kbner_f32_to_bf16(const float* x, kbner_bf16* y, size_t n, void* stream);

@@ -64,13 +64,22 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
 // v are exactly 0 and (weight decay 0) the AdamW update leaves p unchanged: the row is not read at all.  XLM-R's word embedding
 // is 46 % of the parameters and a corpus touches a small part of its 250 002 rows, so with the YAMLs' 4 sentences per optimiser
 // step the dense update was 24 % of the step.  One wave per row.
+// Round 6: the flag is two bits.  Bit 0 (KBNER_ROW_LIVE): the row has EVER received a gradient -- its moments are non-zero and every
+// step moves it.  Bit 1 (KBNER_ROW_TOUCHED): it has received one SINCE THE LAST ZEROING update -- only then can g be non-zero.  A
+// live row that is not touched has g == 0 exactly (the previous update zeroed it and nothing has written since), so the update
+// neither reads nor re-zeroes its gradient (24 instead of 32 B per element moved) and the clip norm skips it altogether; the
+// arithmetic is the same expression with g = 0, so the results are the dense update's bit for bit.  With the YAMLs' 4 sentences
+// per step at most 2 048 of 250 002 rows are touched.
 __global__ __launch_bounds__(256) void adamw_rows_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
-                                                         float* __restrict__ v, const unsigned char* __restrict__ flags, int rows,
+                                                         float* __restrict__ v, unsigned char* __restrict__ flags, int rows,
                                                          int width, float step_size, float b1, float b2, float eps,
                                                          const float* __restrict__ gnorm_sq, float max_norm, float grad_scale,
                                                          int zero_grad) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows || !flags[row]) return;
+  if (row >= rows) return;
+  const unsigned fl = __builtin_amdgcn_readfirstlane((unsigned)flags[row]);
+  if (!fl) return;
+  const bool touched = (fl & 2u) != 0;
   float gs = grad_scale;
   if (gnorm_sq) {
     const float norm = sqrtf(*gnorm_sq) * grad_scale;
@@ -80,7 +89,7 @@ __global__ __launch_bounds__(256) void adamw_rows_kernel(float* __restrict__ p, 
   const size_t base = (size_t)row * width;
   for (int i = (threadIdx.x & 63) * 4; i < width; i += 256) {
     float4 pp = *reinterpret_cast<float4*>(p + base + i);
-    const float4 gg = *reinterpret_cast<const float4*>(g + base + i);
+    const float4 gg = touched ? *reinterpret_cast<const float4*>(g + base + i) : make_float4(0.f, 0.f, 0.f, 0.f);
     float4 mm = *reinterpret_cast<float4*>(m + base + i);
     float4 vv = *reinterpret_cast<float4*>(v + base + i);
     float* pa = &pp.x;
@@ -97,11 +106,12 @@ __global__ __launch_bounds__(256) void adamw_rows_kernel(float* __restrict__ p, 
     *reinterpret_cast<float4*>(p + base + i) = pp;
     *reinterpret_cast<float4*>(m + base + i) = mm;
     *reinterpret_cast<float4*>(v + base + i) = vv;
-    if (zero_grad) *reinterpret_cast<float4*>(g + base + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (zero_grad && touched) *reinterpret_cast<float4*>(g + base + i) = make_float4(0.f, 0.f, 0.f, 0.f);
   }
+  if (zero_grad && touched && (threadIdx.x & 63) == 0) flags[row] = (unsigned char)(fl & ~2u);
 }
 
-// partial[b] = sum of g^2 over the flagged rows among [b * rpb, (b+1) * rpb)
+// partial[b] = sum of g^2 over the TOUCHED rows among [b * rpb, (b+1) * rpb)
 __global__ __launch_bounds__(256) void sqnorm_rows_kernel(const float* __restrict__ g, const unsigned char* __restrict__ flags,
                                                           int rows, int width, int rpb, float* __restrict__ partial) {
   __shared__ float red[4];
@@ -109,7 +119,7 @@ __global__ __launch_bounds__(256) void sqnorm_rows_kernel(const float* __restric
   const int r1 = min(rows, (int)(blockIdx.x + 1) * rpb);
   float acc = 0.0f;
   for (int row = blockIdx.x * rpb + wid; row < r1; row += 4) {
-    if (!flags[row]) continue;
+    if (!(flags[row] & 2)) continue;   // live but untouched: g == 0, adds nothing to any partial sum
     const float* gr = g + (size_t)row * width;
     for (int i = lane * 4; i < width; i += 256) {
       const float4 x = *reinterpret_cast<const float4*>(gr + i);
@@ -122,12 +132,12 @@ __global__ __launch_bounds__(256) void sqnorm_rows_kernel(const float* __restric
   if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-// flags[ids[i]] = 1 for i < n (ids < 0 ignored): which embedding rows have ever received a gradient
+// flags[ids[i]] = LIVE | TOUCHED for i < n (ids < 0 ignored): which embedding rows have ever / now received a gradient
 __global__ __launch_bounds__(256) void mark_rows_kernel(const int* __restrict__ ids, int n, unsigned char* __restrict__ flags, int rows) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < n) {
     const int r = ids[i];
-    if (r >= 0 && r < rows) flags[r] = 1;
+    if (r >= 0 && r < rows) flags[r] = 3;
   }
 }
 
@@ -217,7 +227,7 @@ int kbner_adamw_hf(float* p, float* g, float* m, float* v, bf16_t* shadow, size_
 
 // AdamW (weight decay 0) on the flagged rows of an embedding table p/g/m/v f32[rows, width]; width % 4 == 0.  Unflagged rows are
 // not touched: exact as long as a row's flag is set (kbner_mark_rows) before its first non-zero gradient is applied.
-int kbner_adamw_hf_rows(float* p, float* g, float* m, float* v, const unsigned char* flags, int rows, int width, float step_size,
+int kbner_adamw_hf_rows(float* p, float* g, float* m, float* v, unsigned char* flags, int rows, int width, float step_size,
                         float b1, float b2, float eps, const float* gnorm_sq, float max_norm, float grad_scale, int zero_grad,
                         void* stream) {
   KBNER_CHECK_ARG(p != nullptr && g != nullptr && m != nullptr && v != nullptr && flags != nullptr);

@@ -16,6 +16,10 @@ import os
 import torch
 import torch.distributed as dist
 
+# the optimizer's embedding-row flags (include/kbner.h: KBNER_ROW_LIVE / KBNER_ROW_TOUCHED): a row whose gradient this exchange writes
+# has received one (LIVE) and may hold a non-zero one now (TOUCHED)
+ROW_LIVE, ROW_TOUCHED = 1, 2
+
 
 def is_dist():
     return dist.is_available() and dist.is_initialized()
@@ -276,7 +280,7 @@ class GradReducer:
             dist.all_reduce(rows, op=dist.ReduceOp.SUM)
             self.ops.scatter_rows(rows, idx, g2)
             if self.emb_flags is not None:      # rows other ranks touched now carry a gradient here too
-                self.emb_flags[idx.long()] = 1
+                self.emb_flags[idx.long()] = ROW_LIVE | ROW_TOUCHED
             self.stats["emb_rows"] = int(idx.numel())
             self.stats["bytes_tail"] += 4 * H * int(idx.numel())
         elif self.compress_embedding:
@@ -290,7 +294,7 @@ class GradReducer:
             dist.all_reduce(self.g[lo:hi], op=dist.ReduceOp.SUM)
             self.stats["bytes_tail"] += 4 * (hi - lo)
         if mode != "sparse" and self.emb_flags is not None:
-            self.emb_flags.fill_(1)             # dense exchange: any row may have received a gradient from another rank
+            self.emb_flags.fill_(ROW_LIVE | ROW_TOUCHED)             # dense exchange: any row may have received a gradient from another rank
         self.stats["emb_mode"] = mode
 
     def finish(self):
@@ -306,7 +310,7 @@ class GradReducer:
             self._exchange_embedding()
             skip.append(tuple(self.emb_range))
         elif self.emb_flags is not None:
-            self.emb_flags.fill_(1)             # the whole arena is reduced densely: every row may carry a gradient now
+            self.emb_flags.fill_(ROW_LIVE | ROW_TOUCHED)             # the whole arena is reduced densely: every row may carry a gradient now
         for lo, hi in self._complement(skip):
             dist.all_reduce(self.g[lo:hi], op=dist.ReduceOp.SUM)
             self.stats["bytes_tail"] += 4 * (hi - lo)

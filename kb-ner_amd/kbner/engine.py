@@ -94,8 +94,9 @@ class Arena:
         self.m = None
         self.v = None
         self.shadow = torch.zeros(max(self.n_shadow, 8), dtype=BF16, device=device)
-        # u8[V]: word-embedding rows that have ever received a gradient (set by the embedding backward and by the data-parallel
-        # row exchange).  The optimizer skips the others: their g, m, v are exactly 0 (FusedAdamW.step).
+        # u8[V]: bit 0 = the word-embedding row has EVER received a gradient, bit 1 = it has received one since the optimizer last
+        # zeroed it (both set by the embedding backward and by the data-parallel row exchange; include/kbner.h KBNER_ROW_*).  The
+        # optimizer skips rows with no bit set -- their g, m, v are exactly 0 -- and the gradient of rows without bit 1, which is.
         self.emb_flags = None
         if with_grad and "emb.word" in self.shapes:
             self.emb_flags = torch.zeros(self.shapes["emb.word"][0], dtype=torch.uint8, device=device)
@@ -900,7 +901,8 @@ class FusedAdamW:
             lo = a.offsets["emb.word"]
             V, H = a.shapes["emb.word"]
             live = (a.v[lo:lo + V * H].view(V, H) != 0).any(1) | (a.m[lo:lo + V * H].view(V, H) != 0).any(1)
-            a.emb_flags.copy_(live.to(torch.uint8))
+            # (LIVE | TOUCHED: whatever arena.g holds for these rows at this point is read by the next step)
+            a.emb_flags.copy_(live.to(torch.uint8) * 3)
 
     def lr_lambda(self):
         if self.t_total is None:

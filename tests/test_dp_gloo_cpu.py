@@ -103,7 +103,7 @@ def _worker(rank, world, port, out):
         want = g.clone()
         dist.all_reduce(want)
         flags = torch.zeros(V, dtype=torch.uint8)      # the optimizer's "row has received a gradient" flags
-        flags[touched] = 1                             # what this rank's own embedding backward marks
+        flags[touched] = 3                             # what this rank's own embedding backward marks (LIVE | TOUCHED, include/kbner.h)
         red = dp.GradReducer(g, emb_range=(lo, lo + V * H), emb_width=H, compress_embedding=compress, row_ops=_TorchRows,
                              emb_flags=flags)
         red.begin(touched.numpy())
@@ -113,7 +113,8 @@ def _worker(rank, world, port, out):
         tol = 2e-2 if compress else 1e-6
         # after the exchange every row that carries a gradient on ANY rank must be live here too (row-sparse AdamW relies on it)
         nz = (g[lo:lo + V * H].view(V, H) != 0).any(1)
-        flags_ok = bool(torch.all(flags.bool() | ~nz)) and (case != "sparse" or int(flags.sum()) <= 2 * n_touch)
+        flags_ok = bool(torch.all(flags.bool() | ~nz)) and (case != "sparse" or int((flags != 0).sum()) <= 2 * n_touch)
+        flags_ok = flags_ok and bool(torch.all((flags == 3) | (flags == 0)))   # a row the exchange wrote is live AND touched
         checks.append((case, red.stats["emb_mode"], float((g - want).abs().max()) <= tol * float(want.abs().max()) and flags_ok, scale,
                        red.stats["buckets"], red.stats["bytes_overlapped"]))
     # 4b. the A/B knobs of the first multi-GPU run (round 6: bench.py --bucket-layers / --exchange-delay): ready ranges coalesced two
@@ -207,12 +208,12 @@ def _worker_dense_fallback(rank, world, port, out):
         want = g.clone()
         dist.all_reduce(want)
         flags = torch.zeros(V, dtype=torch.uint8)
-        flags[touched] = 1
+        flags[touched] = 3
         red = dp.GradReducer(g, emb_range=(lo, lo + V * H), emb_width=H, row_ops=_TorchRows, emb_flags=flags)
         red.begin(touched.numpy())
         red.bucket_ready(0, lo)
         scale = red.finish()
-        res.append((case, red.stats["emb_mode"], red.stats["emb_rows"], int(flags.sum()), float((g - want).abs().max()), scale,
+        res.append((case, red.stats["emb_mode"], red.stats["emb_rows"], int((flags == 3).sum()), float((g - want).abs().max()), scale,
                     red.stats["bytes_tail"]))
     if rank == 0:
         out.put(res)

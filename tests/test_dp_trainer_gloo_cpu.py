@@ -96,7 +96,7 @@ def _build(folder):
             for k, t in enumerate(s):
                 wid = word_id(t.text)
                 a.g[EMB_LO + wid * H:EMB_LO + (wid + 1) * H] += w * (1.0 + 0.01 * k)     # "embedding" gradient: touched rows only
-                a.emb_flags[wid] = 1
+                a.emb_flags[wid] = 3
             a.g[:EMB_LO] += w * (len(s) * 0.001)                                          # "encoder weight" gradient, 2 buckets
             a.g[EMB_LO + V * H:] += w * 0.5
         model.calls.append((len(batch), grad_ready is not None))

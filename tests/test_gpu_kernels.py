@@ -636,7 +636,11 @@ def test_sparse_embedding_optimizer_equals_dense():
     """FusedAdamW skips word-embedding rows that never received a gradient (kbner_adamw_hf_rows / kbner_grad_sqnorm_rows /
     kbner_mark_rows).  Every one of 5 optimizer steps (different batches, clipping active) is applied twice from the SAME state --
     row-sparse on the training replica, dense on a copy: same clip norm (to the fp32 summation order), same p / m / v; rows
-    outside the ids seen so far stay bit-identical to their initial values and the live-row set equals those ids."""
+    outside the ids seen so far stay bit-identical to their initial values and the live-row set equals those ids.
+    Round 6 (two-bit flags, include/kbner.h KBNER_ROW_LIVE / KBNER_ROW_TOUCHED): a THIRD copy takes the same step with every live
+    row marked touched -- the path that reads and re-zeroes every live row's gradient, round 5's kernel -- and must agree with the
+    replica BIT FOR BIT (clip norm, p, m, v): a live row nothing has written since the last step holds g == 0, skipping its gradient
+    is the same arithmetic.  After a step no row is left touched."""
     import torch
     from kbner import batch as kb
     from kbner import engine
@@ -650,6 +654,8 @@ def test_sparse_embedding_optimizer_equals_dense():
     ref = engine.Arena(engine.tagger_specs(cfg, T), "cuda")
     ropt = engine.FusedAdamW(ref, lr=1e-3, lr_rate=10.0, t_total=50, max_norm=0.5)
     ropt.sparse_embedding = False
+    full = engine.Arena(engine.tagger_specs(cfg, T), "cuda")
+    fopt = engine.FusedAdamW(full, lr=1e-3, lr_rate=10.0, t_total=50, max_norm=0.5)
     p0 = tg.arena.param("emb.word").clone()
     seen = set()
     for step in range(5):
@@ -658,8 +664,18 @@ def test_sparse_embedding_optimizer_equals_dense():
         tg.forward_loss(kb.to_device(mb, "cuda"), loss_scale=1.0, backward=True)
         for name in ("p", "g", "m", "v"):
             getattr(ref, name).copy_(getattr(tg.arena, name))
-        ropt.t = opt.t
-        n_sparse, n_dense = float(opt.step()), float(ropt.step())
+            getattr(full, name).copy_(getattr(tg.arena, name))
+        fl = tg.arena.emb_flags
+        if step:   # live rows this batch did not touch exist from the second step on
+            assert int((fl == 1).sum()) > 0 and int((fl == 3).sum()) > 0
+        full.emb_flags.copy_((fl != 0).to(torch.uint8) * 3)
+        full.wgrad_overwrite_ok, full.wgrad_stale = tg.arena.wgrad_overwrite_ok, tg.arena.wgrad_stale
+        ropt.t = fopt.t = opt.t
+        n_sparse, n_dense, n_full = float(opt.step()), float(ropt.step()), float(fopt.step())
+        assert n_sparse == n_full, (step, n_sparse, n_full)
+        for name in ("p", "m", "v"):
+            assert torch.equal(getattr(tg.arena, name), getattr(full, name)), (step, name)
+        assert int((tg.arena.emb_flags > 1).sum()) == 0 and int((full.emb_flags > 1).sum()) == 0   # nothing left touched
         assert abs(n_sparse - n_dense) <= 2e-6 * n_dense, (step, n_sparse, n_dense)
         for name in ("p", "m", "v"):
             a, b = getattr(tg.arena, name), getattr(ref, name)

@@ -24,10 +24,12 @@ def main():
     opt = engine.FusedAdamW(tg.arena, lr=5e-6, lr_rate=10000.0, t_total=1000)
     ar = tg.arena
     if ar.emb_flags is not None:
-        ar.emb_flags.fill_(1)
+        ar.emb_flags.fill_(3)   # LIVE | TOUCHED: every row's gradient is read (the all-rows-touched case)
 
     def step():
         ar.g.normal_(0, 1e-3)
+        if ar.emb_flags is not None:
+            ar.emb_flags.fill_(3)
         ar.wgrad_stale = False      # as after a backward pass (which overwrites the GEMM-weight gradients AdamW no longer zeroes)
         opt.step()
 
@@ -36,6 +38,8 @@ def main():
     times = []
     for _ in range(a.reps):
         ar.g.normal_(0, 1e-3)
+        if ar.emb_flags is not None:
+            ar.emb_flags.fill_(3)
         ar.wgrad_stale = False
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
