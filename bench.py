@@ -95,6 +95,70 @@ def cpu_baseline(args, cfg_kw, T, tags):
                       % (nt, Bc, ncores, dt, warm, setup)}
 
 
+def id_variants(mb, n, vocab, seed):
+    """n copies of a device micro-batch that differ in their content sub-token ids (uniform in [5, vocab), <s> / </s> kept): a training
+    run never sees the same ids twice in a row, and with FusedAdamW.lazy_rows what a step costs depends on WHICH embedding rows it
+    looks up -- rows nobody has visited for k steps owe k optimizer updates (kbner/engine.py).  The structure of the batch (word
+    boundaries, tags, lengths) is untouched."""
+    import torch
+    dev = mb["ids"].device
+    g = torch.Generator(device=dev).manual_seed(int(seed))
+    S = int(mb["S"])
+    M = int(mb["R"]) * S
+    col = torch.arange(M, device=dev) % S
+    interior = (col != 0) & (col != S - 1)
+    out = []
+    for _ in range(n):
+        ids = mb["ids"].clone()
+        fresh = torch.randint(5, int(vocab), (M,), device=dev, generator=g, dtype=torch.int32)
+        ids[:M] = torch.where(interior, fresh, ids[:M])
+        v = dict(mb)
+        v["ids"] = ids
+        out.append(v)
+    return out
+
+
+def impose_row_debt(opt, tokens_per_step, seed=0):
+    """FusedAdamW.lazy_rows defers the zero-gradient updates of embedding rows until they are looked up.  A short benchmark that
+    starts with every row up to date would measure the cheap transient (nobody owes anything yet); a long run with uniform ids
+    settles where a row is visited with probability p = distinct rows per step / rows and owes j steps with P(j) = p (1 - p)^j
+    (mean 1/p - 1: 121 steps at the YAMLs' 2 048 sub-tokens per step, 1.4 at 131 072).  This writes that distribution into the
+    lazy clock (row_t = t - j, every row live), so that the timed steps do the catch-up work of the steady state: per step as
+    many row updates as the eager optimizer performs, in registers instead of through HBM.  The debt is IMPOSED, not earned: the
+    rows receive j updates more than a real run would have given them -- irrelevant on random-init weights, the cost of an update
+    does not depend on the data.  (`--warmup 600` earns it instead: DESIGN.md section 8 compares the two.)"""
+    import math
+    import torch
+    a = opt.arena
+    z = a.lazy
+    if z is None:
+        return None
+    a.materialize_rows()
+    V = a.emb_flags.numel()
+    p = 1.0 - math.exp(-float(tokens_per_step) / V)          # a row is among a step's ids with this probability
+    horizon = min(int(8.0 / p) + 1, opt.LAZY_FULL_EVERY - 1)
+    if opt.t < horizon:     # the clock starts late enough for the oldest debt: steps 1..horizon get their step sizes
+        t_keep = opt.t
+        b1, b2 = opt.betas
+        hist = torch.zeros(horizon + 1, dtype=torch.float32)
+        for s in range(1, horizon + 1):
+            opt.t = s - 1
+            hist[s] = opt.lr * opt.lr_lambda() * math.sqrt(1.0 - b2 ** s) / (1.0 - b1 ** s)
+        opt.t = horizon
+        if opt.t_total is not None:
+            opt.t_total += horizon - t_keep
+        z["hist"][:horizon + 1].copy_(hist.to(z["hist"].device))
+        z["clock"].fill_(opt.t)
+        z["last_full"] = opt.t
+    g = torch.Generator(device=a.p.device).manual_seed(int(seed) + 77)
+    u = torch.rand(V, device=a.p.device, generator=g).clamp_(1e-12, 1.0)
+    j = torch.floor(torch.log(u) / math.log1p(-p)).clamp_(0, min(horizon, opt.t - 1)).to(torch.int32)
+    a.emb_flags.fill_(1)
+    z["row_t"].copy_(opt.t - j)
+    z["dirty"] = True
+    return {"p_row_visited_per_step": round(p, 6), "mean_owed_steps": round(float(j.float().mean()), 2), "horizon": horizon}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -122,6 +186,8 @@ def main():
     ap.add_argument("--bucket-layers", type=int, default=4, choices=[4, 8, 12, 24], help="N>1: layers per gradient bucket (4 = one per grouped "
                     "weight-gradient launch, 201 MB; 8 = two launches per all-reduce, 402 MB)")
     ap.add_argument("--exchange-delay", type=int, default=0, help="N>1: issue a bucket's all-reduce only when this many later buckets are ready")
+    ap.add_argument("--eager-rows", action="store_true",
+                    help="A/B: every live word-embedding row through HBM in every optimizer step (round 5) instead of FusedAdamW.lazy_rows")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (small micro-batches, dropout)")
     ap.add_argument("--dropout", type=float, default=0.0,
                     help="train with this dropout probability at the encoder's three HF sites + WordDropout (default 0: "
@@ -218,6 +284,19 @@ def main():
     # that uses 30 000 distinct sub-tokens gets.
     if tg.arena.emb_flags is not None:
         tg.arena.emb_flags.fill_(1)
+    # N = 1: the trainer's optimizer settings (flair/trainers/finetune_trainer.py: lazy_rows) on ids that change from step to step,
+    # starting from the steady state of the deferred row updates (impose_row_debt).  N > 1 keeps round 5's fixed batches and the
+    # eager row update: the data-parallel exchange marks other ranks' rows touched, which the lazy update handles (tests), but that
+    # path has never met RCCL.
+    row_debt = None
+    micro_variants = None
+    if world == 1:
+        n_var = min(args.warmup + args.steps + 2, 1024 if B * S * accum <= 65536 else 48)
+        micro_variants = [id_variants(m, n_var, cfg.vocab_size, kb.SEED + 4242 + 17 * i) for i, m in enumerate(micro)]
+        if not args.eager_rows:
+            opt.lazy_rows_for(B * S * accum)   # what the trainer does: lazy when a step visits at most 1/8 of the table
+        row_debt = impose_row_debt(opt, B * S * accum, seed=kb.SEED)
+    step_no = [0]
 
     # data parallel: the gradient exchange of a step overlaps with its backward (kbner.dp.GradReducer): the GEMM-weight
     # gradients travel as 6 buckets of 4 layers, each all-reduced (RCCL, async) as soon as its grouped weight-gradient launch
@@ -244,7 +323,11 @@ def main():
     def one_step(time_exchange=False):
         if reducer is not None:
             reducer.begin(touched)
+        k = step_no[0]
+        step_no[0] += 1
         for i, mb in enumerate(micro):
+            if micro_variants is not None:
+                mb = micro_variants[i][k % len(micro_variants[i])]
             hook = reducer.bucket_ready if (reducer is not None and i == len(micro) - 1 and not args.blocking_allreduce) else None
             losses.append(tg.forward_loss(mb, loss_scale=1.0 / accum, backward=True, grad_ready=hook))
         scale = 1.0
@@ -360,12 +443,15 @@ def main():
     if not args.no_roofline:
         try:
             hrec = []
+            was_lazy = opt.lazy_rows
+            opt.lazy_rows = False             # the eager row kernels: every live row through HBM, the survey's 28 B per parameter
             if tg.arena.emb_flags is not None:
                 tg.arena.emb_flags.fill_(3)   # LIVE | TOUCHED: the row kernels move their whole algorithmic bytes in this step
             ops.HBM_HOOK = hrec
             one_step()
             torch.cuda.synchronize()
             ops.HBM_HOOK = None
+            opt.lazy_rows = was_lazy
             agg = {}
             for name, e0, e1, nb in hrec:
                 d = agg.setdefault(name, [0.0, 0.0, 0])
@@ -428,9 +514,18 @@ def main():
         extra = {"micro_batch_x_accumulate": {}, "unit": "sentences/sec"}
 
         def timed(tgx, optx, mbs, steps, warm=1):
+            # like the main loop: fresh ids every step, from the steady state of the deferred row updates at THIS step size
+            var = [id_variants(m, steps + warm, cfg.vocab_size, kb.SEED + 999 + 31 * i + sum(int(x["B"]) for x in mbs))
+                   for i, m in enumerate(mbs)]
+            if not args.eager_rows:
+                optx.lazy_rows_for(sum(int(x["B"]) * int(x["S"]) for x in mbs))
+            impose_row_debt(optx, sum(int(x["B"]) * int(x["S"]) for x in mbs), seed=kb.SEED + len(mbs))
+            kk = [0]
+
             def st():
-                for mb in mbs:
-                    tgx.forward_loss(mb, loss_scale=1.0 / len(mbs), backward=True)
+                for v in var:
+                    tgx.forward_loss(v[kk[0]], loss_scale=1.0 / len(mbs), backward=True)
+                kk[0] += 1
                 optx.step()
             for _ in range(warm):
                 st()
@@ -475,10 +570,13 @@ def main():
         # table): fresh optimizer state, only rows that receive a gradient are live, the other 88 % of the word-embedding table
         # (40 % of all parameters) are skipped by the clip norm and by AdamW -- exactly, their g / m / v are zero
         if tg.arena.emb_flags is not None:
+            was_lazy = opt.lazy_rows
+            opt.lazy_rows = False      # (the optimizer state is rewritten by hand below: the lazy clock restarts from it)
             tg.arena.emb_flags.zero_()
             tg.arena.m.zero_()
             tg.arena.v.zero_()
             tg.arena.g.zero_()
+            opt.lazy_rows = was_lazy
             cv = {}
             mb4c = [kb.to_device(kb.synthetic_batch(4, S, vocab=30000, T=T, x_idx=x_idx, start=start, stop=stop, seed=kb.SEED + 61 + i),
                                  dev) for i in range(8)]
@@ -569,6 +667,10 @@ def main():
             "encoder_tflops_fwd_bwd_per_sentence": round(fl_sent / 1e12, 4),
             "mfma_fraction_end_to_end": round(value / world * fl_sent / (MFMA_BF16_DENSE_PEAK_TFLOPS * 1e12), 4),
             "loss_first": round(loss_first, 4), "loss_last": round(loss_last, 4),
+            # N = 1: content ids are redrawn every step; with lazy embedding rows the run starts from the steady state of the deferred
+            # row updates (impose_row_debt: as many row updates per step as the eager optimizer performs, done in registers)
+            "optimizer": {"embedding_rows": "lazy" if opt.lazy_rows else "eager", "ids": "fresh per step" if micro_variants is not None else "fixed",
+                          "row_debt": row_debt},
         }
         if roofline is not None:
             out["roofline"] = roofline

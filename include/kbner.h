@@ -318,6 +318,23 @@ int kbner_grad_sqnorm_rows(const float* g, const unsigned char* flags, int rows,
 int kbner_adamw_hf_rows(float* p, float* g, float* m, float* v, unsigned char* flags, int rows, int width, float step_size,
                         float b1, float b2, float eps, const float* gnorm_sq, float max_norm, float grad_scale, int zero_grad,
                         void* stream);
+/* LAZY rows (round 6).  A live row that receives no gradient in a step is moved by an update that reads nothing but its own p, m, v
+   and the step's step_size; the only reader of a row is the embedding lookup of a batch that holds its id.  Instead of streaming
+   every live row through HBM in every step (24 B per element: 7 GB for XLM-R's table), kbner_adamw_hf_rows_lazy applies step `t`
+   (1-based; = clock[0] + 1) to the TOUCHED rows only -- each first brought up to step t - 1 --, zeroes their gradients, clears
+   TOUCHED, then records hist[t & (hist_len - 1)] = step_size and clock[0] = t.  kbner_adamw_rows_catchup applies to the rows
+   ids[0..n) (device i32, entries < 0 ignored, repeats allowed; NULL: all rows) the zero-gradient steps (row_t[r], clock[0]] they
+   owe: call it on a batch's ids before the lookup, and with NULL before anything else reads the table or its moments.  The k owed
+   updates are the eager kernel's k updates -- the same fp32 operations in the same order, in registers: bit-identical state.
+   row_t i32[rows] (last step applied; -1 = never live), clock i32[1], hist f32[hist_len] (a power of two; the caller runs the
+   all-rows catch-up at least once every hist_len - 1 steps), width <= 1024.  (The reference's optimizer.step() walks every
+   parameter in every step: finetune_trainer.py:1018.) */
+int kbner_adamw_hf_rows_lazy(float* p, float* g, float* m, float* v, unsigned char* flags, int* row_t, int* clock, float* hist,
+                             int hist_len, int t, int rows, int width, float step_size, float b1, float b2, float eps,
+                             const float* gnorm_sq, float max_norm, float grad_scale, void* stream);
+int kbner_adamw_rows_catchup(const int* ids, int n, float* p, float* m, float* v, const unsigned char* flags, int* row_t,
+                             const int* clock, const float* hist, int hist_len, int rows, int width, float b1, float b2, float eps,
+                             void* stream);
 int kbner_f32_to_bf16(const float* x, kbner_bf16* y, size_t n, void* stream);
 int kbner_bf16_to_f32(const kbner_bf16* x, float* y, size_t n, void* stream); /* n % 4 == 0 */
 int kbner_wdiff_sum(const float* a, const float* b, const float* w, int n, float* out, void* stream);

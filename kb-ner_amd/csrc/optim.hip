@@ -111,6 +111,165 @@ __global__ __launch_bounds__(256) void adamw_rows_kernel(float* __restrict__ p, 
   if (zero_grad && touched && (threadIdx.x & 63) == 0) flags[row] = (unsigned char)(fl & ~2u);
 }
 
+
+// ---- LAZY rows (round 6).  A live row that receives no gradient for k steps is moved by k updates that depend on nothing but
+// its own p, m, v and the steps' scalars: m <- b1 m, v <- b2 v, p <- p - step_s * m / (sqrt(v) + eps).  The dense optimizer
+// streams 24 B per element through HBM for each of them (7 GB per step for XLM-R's 250 002 x 1024 table once every row is live:
+// 1.0 ms of the YAMLs' 11-ms step); the only READER of a row is the embedding lookup of a batch that contains its id.  So the k
+// updates are applied -- the same fp32 operations in the same order, k trips through one loop in registers -- when the row is next
+// needed: by the lookup (kbner_adamw_rows_catchup on the batch's ids, before the forward pass) or by an update that brings it a
+// gradient.  row_t[r] = the last step applied to row r (-1: never live), *clock = the optimizer's step count, hist[s & mask] =
+// step s's step_size.  Bit-identical to the eager kernels (tests: test_lazy_embedding_rows_equal_eager).
+struct RowState {
+  float4 p[4], m[4], v[4];
+};
+
+__device__ __forceinline__ void adam_zero_grad_step(float& p, float& m, float& v, float step, float b1, float b2, float eps) {
+  const float gk = 0.0f;
+  m = m * b1 + (1.0f - b1) * gk;
+  v = v * b2 + (1.0f - b2) * gk * gk;
+  p -= step * (m / (sqrtf(v) + eps));
+}
+
+// one wave: the zero-gradient updates of steps (from, to] on one row of width <= 1024 held in registers
+template <int NV>
+__device__ __forceinline__ void row_catch_up(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, size_t base, int width,
+                                             int lane, int from, int to, const float* __restrict__ hist, int mask, float b1, float b2,
+                                             float eps, RowState& st, bool load) {
+  if (load) {
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+      const int i = lane * 4 + c * 256;
+      if (i < width) {
+        st.p[c] = *reinterpret_cast<const float4*>(p + base + i);
+        st.m[c] = *reinterpret_cast<const float4*>(m + base + i);
+        st.v[c] = *reinterpret_cast<const float4*>(v + base + i);
+      }
+    }
+  }
+  for (int s = from + 1; s <= to; ++s) {
+    const float step = hist[s & mask];
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+      adam_zero_grad_step(st.p[c].x, st.m[c].x, st.v[c].x, step, b1, b2, eps);
+      adam_zero_grad_step(st.p[c].y, st.m[c].y, st.v[c].y, step, b1, b2, eps);
+      adam_zero_grad_step(st.p[c].z, st.m[c].z, st.v[c].z, step, b1, b2, eps);
+      adam_zero_grad_step(st.p[c].w, st.m[c].w, st.v[c].w, step, b1, b2, eps);
+    }
+  }
+}
+
+template <int NV>
+__device__ __forceinline__ void row_store(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, size_t base, int width,
+                                          int lane, const RowState& st) {
+#pragma unroll
+  for (int c = 0; c < NV; ++c) {
+    const int i = lane * 4 + c * 256;
+    if (i < width) {
+      *reinterpret_cast<float4*>(p + base + i) = st.p[c];
+      *reinterpret_cast<float4*>(m + base + i) = st.m[c];
+      *reinterpret_cast<float4*>(v + base + i) = st.v[c];
+    }
+  }
+}
+
+// rows ids[0..n) (ids == nullptr: every row) brought to step *clock.  One WORKGROUP per entry, one column per thread: what a row
+// owes is geometric in the steady state (mean rows / distinct-ids-per-step: 121 steps at the YAMLs' 2 048 sub-tokens, the longest of
+// a step's 2 048 rows ~900), and the launch lasts as long as its longest row -- with one wave per row (16 columns per lane) that
+// was 0.9 ms, as much as the eager update it replaces; spread over 16 waves it is ~60 us.  The step sizes of up to 1024 owed steps
+// are staged in LDS at a time.  An id that occurs several times is claimed by the first workgroup to swap the clock into row_t
+// (the others find it current and leave: the claimant finishes inside this launch, the reader is a later launch).
+__global__ __launch_bounds__(1024) void adamw_rows_catchup_kernel(const int* __restrict__ ids, int n, float* __restrict__ p,
+                                                                  float* __restrict__ m, float* __restrict__ v,
+                                                                  const unsigned char* __restrict__ flags, int* __restrict__ row_t,
+                                                                  const int* __restrict__ clock, const float* __restrict__ hist,
+                                                                  int mask, int rows, int width, float b1, float b2, float eps) {
+  __shared__ int s_from;
+  __shared__ float s_step[1024];
+  const int row = ids ? ids[blockIdx.x] : (int)blockIdx.x;
+  if (row < 0 || row >= rows) return;
+  const int now = *clock;
+  if (threadIdx.x == 0) s_from = (flags[row] & 1) ? atomicExch(row_t + row, now) : now;
+  __syncthreads();
+  int from = s_from;
+  if (from < 0 || from >= now) return;   // never live (m = v = 0: no step moves it) / current / claimed by another workgroup
+  const int col = threadIdx.x;
+  const bool mine = col < width;
+  const size_t at = (size_t)row * width + col;
+  float pp = 0.f, mm = 0.f, vv = 0.f;
+  if (mine) {
+    pp = p[at];
+    mm = m[at];
+    vv = v[at];
+  }
+  while (from < now) {
+    const int cnt = min(now - from, 1024);
+    __syncthreads();
+    if ((int)threadIdx.x < cnt) s_step[threadIdx.x] = hist[(from + 1 + (int)threadIdx.x) & mask];
+    __syncthreads();
+    for (int k = 0; k < cnt; ++k) adam_zero_grad_step(pp, mm, vv, s_step[k], b1, b2, eps);
+    from += cnt;
+  }
+  if (mine) {
+    p[at] = pp;
+    m[at] = mm;
+    v[at] = vv;
+  }
+}
+
+// step t of the optimizer on the TOUCHED rows (the others wait for their next reader): whatever a row still owes up to t - 1,
+// then the update proper with its gradient, which is zeroed; row_t <- t, TOUCHED cleared.  Workgroup 0 also advances the clock.
+__global__ __launch_bounds__(256) void adamw_rows_lazy_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                              float* __restrict__ v, unsigned char* __restrict__ flags,
+                                                              int* __restrict__ row_t, const float* __restrict__ hist, int mask, int t,
+                                                              int rows, int width, float step_size, float b1, float b2, float eps,
+                                                              const float* __restrict__ gnorm_sq, float max_norm, float grad_scale) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const unsigned fl = __builtin_amdgcn_readfirstlane((unsigned)flags[row]);
+  if (!(fl & 2u)) return;
+  float gs = grad_scale;
+  if (gnorm_sq) {
+    const float norm = sqrtf(*gnorm_sq) * grad_scale;
+    const float coef = max_norm / (norm + 1e-6f);
+    if (coef < 1.0f) gs *= coef;
+  }
+  const size_t base = (size_t)row * width;
+  const int from = __builtin_amdgcn_readfirstlane(row_t[row]);
+  RowState st;
+  row_catch_up<4>(p, m, v, base, width, lane, from < 0 ? t - 1 : from, t - 1, hist, mask, b1, b2, eps, st, true);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int i = lane * 4 + c * 256;
+    if (i < width) {
+      const float4 gg = *reinterpret_cast<const float4*>(g + base + i);
+      float* pa = &st.p[c].x;
+      const float* ga = &gg.x;
+      float* ma = &st.m[c].x;
+      float* va = &st.v[c].x;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float gk = ga[k] * gs;
+        ma[k] = ma[k] * b1 + (1.0f - b1) * gk;
+        va[k] = va[k] * b2 + (1.0f - b2) * gk * gk;
+        pa[k] -= step_size * (ma[k] / (sqrtf(va[k]) + eps));
+      }
+      *reinterpret_cast<float4*>(g + base + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  row_store<4>(p, m, v, base, width, lane, st);
+  if (lane == 0) {
+    row_t[row] = t;
+    flags[row] = (unsigned char)(fl & ~2u);
+  }
+}
+
+__global__ void rows_clock_kernel(int* __restrict__ clock, float* __restrict__ hist, int mask, int t, float step_size) {
+  hist[t & mask] = step_size;
+  *clock = t;
+}
+
 // partial[b] = sum of g^2 over the TOUCHED rows among [b * rpb, (b+1) * rpb)
 __global__ __launch_bounds__(256) void sqnorm_rows_kernel(const float* __restrict__ g, const unsigned char* __restrict__ flags,
                                                           int rows, int width, int rpb, float* __restrict__ partial) {
@@ -118,12 +277,19 @@ __global__ __launch_bounds__(256) void sqnorm_rows_kernel(const float* __restric
   const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int r1 = min(rows, (int)(blockIdx.x + 1) * rpb);
   float acc = 0.0f;
-  for (int row = blockIdx.x * rpb + wid; row < r1; row += 4) {
-    if (!(flags[row] & 2)) continue;   // live but untouched: g == 0, adds nothing to any partial sum
-    const float* gr = g + (size_t)row * width;
-    for (int i = lane * 4; i < width; i += 256) {
-      const float4 x = *reinterpret_cast<const float4*>(gr + i);
-      acc += (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w);
+  // the flags of this wave's rows (blockIdx.x * rpb + wid + 4 j) 64 at a time, then only the touched ones in ascending order --
+  // a live row nothing has written since the last step holds g == 0 and adds nothing to any partial sum
+  for (int j0 = 0; blockIdx.x * rpb + wid + 4 * j0 < r1; j0 += 64) {
+    const int myrow = blockIdx.x * rpb + wid + 4 * (j0 + lane);
+    unsigned long long todo = __ballot(myrow < r1 && (flags[myrow] & 2));
+    while (todo) {
+      const int j = __builtin_ctzll(todo);
+      todo &= todo - 1;
+      const float* gr = g + (size_t)(blockIdx.x * rpb + wid + 4 * (j0 + j)) * width;
+      for (int i = lane * 4; i < width; i += 256) {
+        const float4 x = *reinterpret_cast<const float4*>(gr + i);
+        acc += (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w);
+      }
     }
   }
   acc = wave_sum(acc);
@@ -235,6 +401,37 @@ int kbner_adamw_hf_rows(float* p, float* g, float* m, float* v, unsigned char* f
   if (rows == 0) return 0;
   hipLaunchKernelGGL(adamw_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, p, g, m, v, flags, rows, width,
                      step_size, b1, b2, eps, gnorm_sq, max_norm, grad_scale, zero_grad);
+  KBNER_LAUNCH_RET();
+}
+
+// Lazy variant of kbner_adamw_hf_rows (see the kernels): step `t` (1-based, = *clock + 1) on the touched rows, then hist[t & mask]
+// <- step_size, *clock <- t.  hist holds mask + 1 floats (a power of two); the caller brings every row up to date
+// (kbner_adamw_rows_catchup with ids == nullptr) at least once every `mask` steps.  width <= 1024.
+int kbner_adamw_hf_rows_lazy(float* p, float* g, float* m, float* v, unsigned char* flags, int* row_t, int* clock, float* hist,
+                             int hist_len, int t, int rows, int width, float step_size, float b1, float b2, float eps,
+                             const float* gnorm_sq, float max_norm, float grad_scale, void* stream) {
+  KBNER_CHECK_ARG(p != nullptr && g != nullptr && m != nullptr && v != nullptr && flags != nullptr && row_t != nullptr);
+  KBNER_CHECK_ARG(clock != nullptr && hist != nullptr && hist_len >= 2 && (hist_len & (hist_len - 1)) == 0 && t >= 1);
+  KBNER_CHECK_ARG(rows >= 0 && width > 0 && width % 4 == 0 && width <= 1024);
+  if (rows > 0)
+    hipLaunchKernelGGL(adamw_rows_lazy_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, p, g, m, v, flags, row_t, hist,
+                       hist_len - 1, t, rows, width, step_size, b1, b2, eps, gnorm_sq, max_norm, grad_scale);
+  hipLaunchKernelGGL(rows_clock_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, clock, hist, hist_len - 1, t, step_size);
+  KBNER_LAUNCH_RET();
+}
+
+// rows ids[0..n) (device i32; entries < 0 ignored; nullptr: all `rows` rows) brought to step *clock: what the eager kernel would
+// have done to them in every step since row_t.  Before every embedding lookup of a table under kbner_adamw_hf_rows_lazy.
+int kbner_adamw_rows_catchup(const int* ids, int n, float* p, float* m, float* v, const unsigned char* flags, int* row_t,
+                             const int* clock, const float* hist, int hist_len, int rows, int width, float b1, float b2, float eps,
+                             void* stream) {
+  KBNER_CHECK_ARG(p != nullptr && m != nullptr && v != nullptr && flags != nullptr && row_t != nullptr && clock != nullptr);
+  KBNER_CHECK_ARG(hist != nullptr && hist_len >= 2 && (hist_len & (hist_len - 1)) == 0 && rows > 0 && width > 0 && width % 4 == 0 &&
+                  width <= 1024 && n >= 0);
+  const int cnt = ids ? n : rows;
+  if (cnt == 0) return 0;
+  hipLaunchKernelGGL(adamw_rows_catchup_kernel, dim3(cnt), dim3(1024), 0, (hipStream_t)stream, ids, cnt, p, m, v, flags, row_t, clock, hist,
+                     hist_len - 1, rows, width, b1, b2, eps);
   KBNER_LAUNCH_RET();
 }
 

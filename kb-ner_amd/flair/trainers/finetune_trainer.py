@@ -352,6 +352,10 @@ class ModelFinetuner:
         opt = FusedAdamW(arena, lr=learning_rate, lr_rate=float(lr_rate), eps=1e-6, weight_decay=0.0, max_norm=5.0,
                          t_total=t_total, warmup=warmup)
         self.optimizer = opt
+        # word-embedding rows that receive no gradient in a step are updated when the encoder next looks them up instead of being
+        # streamed through HBM every step (FusedAdamW.lazy_rows: the same updates, bit for bit; state_dict / save materialize)
+        if bool(getattr(self, "lazy_embedding_rows", True)) and hasattr(opt, "lazy_rows_for"):
+            opt.lazy_rows_for(mini_batch_size * accum * W * 512)   # sub-tokens per step at most: 512 per sentence
         rng = random.Random(20220711)  # rank-shared shuffle of the batch order
         order = list(range(len(loader)))  # batch order as a permutation of the loader's (fixed) batches: checkpointable
         if self.optimizer_state is not None:   # resume (finetune_trainer.py:573,690): Adam moments, step count, RNG streams

@@ -107,6 +107,29 @@ class Arena:
         # wgrad_stale: g[:n_shadow] holds the PREVIOUS step's gradients (set by FusedAdamW.step, cleared by encoder_backward).
         self.wgrad_overwrite_ok = False
         self.wgrad_stale = False
+        # FusedAdamW.lazy_rows: the state of the lazily updated word-embedding table (row_t i32[V], clock i32[1], hist f32[cap], b1,
+        # b2, eps) or None.  While it is set a row of emb.word / its moments may lag behind the optimizer's step count: the encoder
+        # forward brings the rows it looks up to date (catch_up_rows), every other reader calls materialize_rows() first.
+        self.lazy = None
+
+    def _emb_rows(self, buf):
+        lo = self.offsets["emb.word"]
+        V, H = self.shapes["emb.word"]
+        return buf[lo:lo + V * H].view(V, H)
+
+    def catch_up_rows(self, ids):
+        """before an embedding lookup of `ids` (i32, device): the zero-gradient optimizer steps those rows still owe"""
+        z = self.lazy
+        if z is not None:
+            ops.adamw_rows_catchup(ids, self._emb_rows(self.p), self._emb_rows(self.m), self._emb_rows(self.v), self.emb_flags,
+                                   z["row_t"], z["clock"], z["hist"], z["b1"], z["b2"], z["eps"])
+
+    def materialize_rows(self):
+        """every row brought to the optimizer's step count: p / m / v are the eager optimizer's (before reading them elsewhere)"""
+        z = self.lazy
+        if z is not None and z["dirty"]:
+            self.catch_up_rows(None)
+            z["dirty"] = False
 
     def finalize_grads(self):
         """ONE place for the stale-gradient rule: make `g` what a consumer of "this step's gradients" may read.  If no backward
@@ -342,6 +365,7 @@ class Tagger:
     def load_hf_state_dict(self, sd, prefix=""):
         """Load encoder weights given under HF names (e.g. from XLMRobertaModel.state_dict())."""
         nm = hf_name_map(self.cfg)
+        self.arena.materialize_rows()
         for hf, (mine, sl) in nm.items():
             t = sd[prefix + hf].to(device=self.device, dtype=F32)
             dst = self.arena.param(mine)
@@ -351,6 +375,7 @@ class Tagger:
         self.arena.refresh_shadow()
 
     def hf_state_dict(self):
+        self.arena.materialize_rows()
         out = {}
         for hf, (mine, sl) in hf_name_map(self.cfg).items():
             t = self.arena.param(mine)
@@ -358,6 +383,7 @@ class Tagger:
         return out
 
     def set_param(self, name, value):
+        self.arena.materialize_rows()
         self.arena.param(name).copy_(torch.as_tensor(value).to(device=self.device, dtype=F32))
         if self.arena.offsets[name] < self.arena.n_shadow:
             self.arena.refresh_shadow()
@@ -424,9 +450,10 @@ class Tagger:
         st = ac.infer_graph
         if st is None:
             st = ac.infer_graph = {"calls": 0, "graph": None, "ids": torch.empty_like(ids), "pos": torch.empty_like(pos_ids),
-                                   "mb": torch.empty_like(maskbias), "variant": ops.gemm_variant()}
+                                   "mb": torch.empty_like(maskbias), "variant": ops.gemm_variant(), "lazy": self.arena.lazy is not None}
         if (st["graph"] is False or st["ids"].shape != ids.shape or st["mb"].shape != maskbias.shape
-                or st["variant"] != ops.gemm_variant() or torch.cuda.is_current_stream_capturing()):
+                or st["variant"] != ops.gemm_variant() or st.get("lazy", False) != (self.arena.lazy is not None)
+                or torch.cuda.is_current_stream_capturing()):
             return self._encoder_forward(ids, pos_ids, maskbias, B, S, False)
         st["ids"].copy_(ids)
         st["pos"].copy_(pos_ids)
@@ -472,6 +499,7 @@ class Tagger:
         Mp = ac.Mp
         eps = cfg.layer_norm_eps
         d_emb, d_layers = self._site_seeds()
+        a.catch_up_rows(ids)   # FusedAdamW.lazy_rows: the looked-up rows owe the zero-gradient steps since they were last touched
         ops.embed_ln_fwd(ids, pos_ids, a.param("emb.word"), a.param("emb.pos"), a.param("emb.type")[0], a.param("emb.ln.g"),
                          a.param("emb.ln.b"), eps, ac.h0, ac.x[0], ac.emb_mean, ac.emb_rstd, drop=d_emb)
         for l in range(L):
@@ -880,11 +908,62 @@ class FusedAdamW:
         self.norm_sq = torch.zeros(1, dtype=F32, device=arena.device)
         self.split = arena.offsets["transitions"]
         self.sparse_embedding = True   # skip word-embedding rows that never received a gradient (exact; see step())
+        self._lazy_rows = False
+
+    # lazy_rows (opt-in; the trainer and bench.py switch it on).  A live embedding row that receives no gradient in a step is
+    # moved by an update that reads nothing but its own p / m / v: instead of streaming all live rows through HBM every step
+    # (24 B per element: 1.0 ms of the YAML regime's 11-ms step once every row of XLM-R's table is live) the step updates the rows
+    # that DID receive a gradient, and the others are brought up to date -- the same fp32 operations in the same order, in
+    # registers -- when the encoder next looks them up (Arena.catch_up_rows) or a later step touches them.  Bit-identical to the
+    # eager update; every reader of emb.word / its moments other than the encoder forward calls Arena.materialize_rows() first
+    # (hf_state_dict, set_param, load_hf_state_dict, state_dict and load_state_dict here do).
+    LAZY_HIST = 8192          # steps of step_size history (a power of two) ...
+    LAZY_FULL_EVERY = 4096    # ... and every this many steps all rows are brought up to date: bounds a row's catch-up loop
+
+    @property
+    def lazy_rows(self):
+        return self._lazy_rows
+
+    @lazy_rows.setter
+    def lazy_rows(self, on):
+        a = self.arena
+        on = bool(on) and a.emb_flags is not None and a.p.is_cuda and a.shapes["emb.word"][1] <= 1024
+        if on == self._lazy_rows:
+            return
+        if on:
+            dev = a.p.device
+            z = a.__dict__.get("_lazy_bufs")
+            if z is None:   # allocated once per arena: a captured forward pass (encoder_forward's HIP graph) holds these pointers
+                z = a._lazy_bufs = {"row_t": torch.empty(a.emb_flags.numel(), dtype=torch.int32, device=dev),
+                                    "clock": torch.empty(1, dtype=torch.int32, device=dev),
+                                    "hist": torch.zeros(self.LAZY_HIST, dtype=F32, device=dev)}
+            z["row_t"].copy_(torch.where(a.emb_flags != 0, self.t, -1).to(torch.int32))   # live rows are current, the others never moved
+            z["clock"].fill_(self.t)
+            z.update({"b1": self.betas[0], "b2": self.betas[1], "eps": self.eps, "dirty": False, "last_full": self.t})
+            a.lazy = z
+        else:
+            a.materialize_rows()
+            a.lazy["row_t"].fill_(-1)   # a captured catch-up launch that is replayed from now on finds nothing to do
+            a.lazy = None
+        self._lazy_rows = on
+
+    def lazy_rows_for(self, tokens_per_step):
+        """lazy_rows where it pays: when a step looks up a small part of the table (at most an eighth of its rows -- the YAMLs' 4
+        sentences: 0.8 %).  With 256 sentences per step 41 % of the rows are visited, each owing 1.4 steps: the per-row catch-up
+        launches then cost what the eager update's extra bytes do (255.9 against 255.3 ms per step)."""
+        a = self.arena
+        self.lazy_rows = a.emb_flags is not None and 8 * int(tokens_per_step) <= a.emb_flags.numel()
+        return self.lazy_rows
+
+    def materialize(self):
+        """arena.p / m / v are the eager optimizer's after this (no-op unless lazy_rows)"""
+        self.arena.materialize_rows()
 
     def state_dict(self):
         """what a resume needs (the reference stores optimizer.state_dict(), finetune_trainer.py:1261-1277): the step count and
         the two Adam moment arenas (host copies; 2 x 2.24 GB for XLM-R-large, like the reference's exp_avg / exp_avg_sq)"""
         a = self.arena
+        a.materialize_rows()
         return {"t": self.t, "n": a.n, "m": a.m.detach().cpu(), "v": a.v.detach().cpu()}
 
     def load_state_dict(self, sd):
@@ -892,6 +971,8 @@ class FusedAdamW:
         if int(sd["n"]) != a.n:
             raise ValueError("optimizer state holds %d elements, the arena %d" % (int(sd["n"]), a.n))
         a.ensure_state()
+        lazy = self._lazy_rows
+        self.lazy_rows = False          # (the restored moments are every row's: the lazy clock restarts from them below)
         a.m.copy_(sd["m"].to(a.device))
         a.v.copy_(sd["v"].to(a.device))
         self.t = int(sd["t"])
@@ -903,6 +984,8 @@ class FusedAdamW:
             live = (a.v[lo:lo + V * H].view(V, H) != 0).any(1) | (a.m[lo:lo + V * H].view(V, H) != 0).any(1)
             # (LIVE | TOUCHED: whatever arena.g holds for these rows at this point is read by the next step)
             a.emb_flags.copy_(live.to(torch.uint8) * 3)
+        if lazy:
+            self.lazy_rows = True
 
     def lr_lambda(self):
         if self.t_total is None:
@@ -948,7 +1031,19 @@ class FusedAdamW:
                       lr * bc, lr * self.wd, b1, b2, self.eps, self.norm_sq, self.max_norm, grad_scale,
                       not (keep and hi <= a.n_shadow))
         a.wgrad_stale = keep
-        if sparse:
+        z = a.lazy if self._lazy_rows else None
+        if z is not None and not sparse:      # (weight decay switched on / the sparse path switched off under a lazy table)
+            self.lazy_rows = False
+            z = None
+        if sparse and z is not None:
+            ops.adamw_rows_lazy(rows(a.p), rows(a.g), rows(a.m), rows(a.v), a.emb_flags, z["row_t"], z["clock"], z["hist"],
+                                self.t, self.lr * lam * bc, b1, b2, self.eps, self.norm_sq, self.max_norm, grad_scale)
+            z["dirty"] = True
+            if self.t - z["last_full"] >= self.LAZY_FULL_EVERY:
+                a.materialize_rows()
+                z["last_full"] = self.t
+        elif sparse:
             ops.adamw_rows(rows(a.p), rows(a.g), rows(a.m), rows(a.v), a.emb_flags, self.lr * lam * bc, b1, b2, self.eps,
                            self.norm_sq, self.max_norm, grad_scale, True)
         return self.norm_sq
+

@@ -69,6 +69,9 @@ SIGNATURES = {
     "kbner_mark_rows": (c_int, [P, c_int, P, c_int, P]),
     "kbner_grad_sqnorm_rows": (c_int, [P, P, c_int, c_int, P, P, c_int, P]),
     "kbner_adamw_hf_rows": (c_int, [P, P, P, P, P, c_int, c_int, c_float, c_float, c_float, c_float, P, c_float, c_float, c_int, P]),
+    "kbner_adamw_hf_rows_lazy": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float, P, c_float,
+                                          c_float, P]),
+    "kbner_adamw_rows_catchup": (c_int, [P, c_int, P, P, P, P, P, P, P, c_int, c_int, c_int, c_float, c_float, c_float, P]),
     "kbner_adamw_hf": (c_int, [P, P, P, P, P, c_size_t, c_size_t, c_float, c_float, c_float, c_float, c_float, P, c_float,
                                c_float, c_int, P]),
     "kbner_f32_to_bf16": (c_int, [P, P, c_size_t, P]),

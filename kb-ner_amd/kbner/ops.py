@@ -568,6 +568,22 @@ def adamw_rows(p, g, m, v, flags, step_size, b1, b2, eps, gnorm_sq, max_norm, gr
                ptr(gnorm_sq), max_norm, grad_scale, 1 if zero_grad else 0, stream_ptr())
 
 
+def adamw_rows_lazy(p, g, m, v, flags, row_t, clock, hist, t, step_size, b1, b2, eps, gnorm_sq, max_norm, grad_scale):
+    """step t on the TOUCHED rows only (each first brought up to t - 1), then hist[t] <- step_size, clock <- t (include/kbner.h)"""
+    _chk(p, F32, "p"); _chk(flags, U8, "flags"); _chk(row_t, I32, "row_t"); _chk(clock, I32, "clock"); _chk(hist, F32, "hist")
+    L.call("kbner_adamw_hf_rows_lazy", ptr(p), ptr(g), ptr(m), ptr(v), ptr(flags), ptr(row_t), ptr(clock), ptr(hist), hist.numel(), int(t),
+           p.shape[0], p.shape[1], step_size, b1, b2, eps, ptr(gnorm_sq), max_norm, grad_scale, stream_ptr())
+
+
+def adamw_rows_catchup(ids, p, m, v, flags, row_t, clock, hist, b1, b2, eps):
+    """rows `ids` (i32, device; None: every row) of a lazily updated table brought to step clock[0]"""
+    _chk(p, F32, "p"); _chk(flags, U8, "flags"); _chk(row_t, I32, "row_t"); _chk(clock, I32, "clock"); _chk(hist, F32, "hist")
+    if ids is not None:
+        _chk(ids, I32, "ids")
+    L.call("kbner_adamw_rows_catchup", ptr(ids), ids.numel() if ids is not None else 0, ptr(p), ptr(m), ptr(v), ptr(flags), ptr(row_t),
+           ptr(clock), ptr(hist), hist.numel(), p.shape[0], p.shape[1], b1, b2, eps, stream_ptr())
+
+
 def f32_to_bf16(x, y):
     L.call("kbner_f32_to_bf16", ptr(x), ptr(y), x.numel(), stream_ptr())
 
