@@ -157,6 +157,12 @@ int kbner_ln_bwd_ws_floats(int H);
 int kbner_ln_bwd(const kbner_bf16* dy, const kbner_bf16* h, const float* mean, const float* rstd, const float* gamma,
                  kbner_bf16* dh, float* dgamma, float* dbeta, float* dbias, float* ws, int M, int H, kbner_bf16* dhm,
                  uint32_t drop_seed, uint32_t drop_thresh, void* stream);
+/* Small batches: kbner_ln_bwd with dgamma == NULL (dbeta / dbias ignored) leaves its kbner_ln_bwd_blocks(M) partial rows in `ws` instead
+ * of reducing them with a launch of its own; kbner_ln_colreduce_batched then adds the column sums of up to 64 such workspaces to their
+ * gradients in ONE launch (49 LayerNorm backward passes per encoder backward pass at 4.7 us each otherwise).  items: HOST memory,
+ * n records of five 64-bit words: ws, dgamma, dbeta, dbias (device pointers; dbias may be 0), number of partial rows. */
+int kbner_ln_bwd_blocks(int M);
+int kbner_ln_colreduce_batched(const long long* items, int n, int H, void* stream);
 /* word[ids] + pos[pos_ids] + type[0] -> h0 (saved) -> LayerNorm -> dropout -> y (BertEmbeddings.forward) */
 int kbner_embed_ln_fwd(const int* ids, const int* pos_ids, const float* word, const float* pos, const float* type0,
                        const float* gamma, const float* beta, float eps, kbner_bf16* h0, kbner_bf16* y, float* mean,
@@ -218,6 +224,9 @@ int kbner_gemm_bf16_grouped(int layout, int nprob, const kbner_gemm_problem* pro
 int kbner_gemm_tile_rows(int layout, int M, int N);
 /* out[n] += sum_r ws[r, n], rows = 2 * M / tile rows: the second half of KBNER_EPI_COLSUM_WS (ws is folded in place: clobbered) */
 int kbner_colsum_rows_f32(float* ws, int rows, int N, float* out, void* stream);
+/* the same single-pass fold for up to 64 workspaces of one width in one launch.  items: HOST memory, n records of three 64-bit words:
+ * ws, out (device pointers), number of rows.  out[c] += sum_r ws[r, c]; ws is left as it is. */
+int kbner_colsum_rows_f32_batched(const long long* items, int n, int N, void* stream);
 /* The same launch with DYNAMIC tile scheduling, for steps whose CUs are shared with another kernel (an RCCL collective of the
  * overlapped gradient exchange): a persistent static walk would run the share of every workgroup that finds no CU after all the
  * others have finished -- twice the launch time with 8 CUs held (profiles/round5_cu_contention.txt).  Round 5: launches whose

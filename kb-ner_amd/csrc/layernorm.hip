@@ -400,6 +400,43 @@ __global__ __launch_bounds__(256) void ln_colreduce_kernel(const float* __restri
   }
 }
 
+// The same reduction for up to LN_BATCH_MAX LayerNorms in ONE launch (blockIdx.z picks the item): with a few sentences per step
+// every ln_bwd's own reduce launch is a 4.7-us kernel at the launch floor, 49 times per backward pass; the partial rows of a whole
+// pass are kept (one workspace per LayerNorm) and reduced together at its end.  The descriptors travel as kernel arguments.
+#define LN_BATCH_MAX 64
+struct LnPartialItem {
+  const float* ws;
+  float* dgamma;
+  float* dbeta;
+  float* dbias;
+  long long nblocks;
+};
+struct LnPartialBatch {
+  LnPartialItem it[LN_BATCH_MAX];
+};
+__global__ __launch_bounds__(256) void ln_colreduce_batched_kernel(const LnPartialBatch batch, int H) {
+  __shared__ float red[4][64];
+  const LnPartialItem& q = batch.it[blockIdx.z];
+  const float* __restrict__ ws = q.ws;
+  const int nblocks = (int)q.nblocks;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + tx;  // over 3*H
+  const int per = (nblocks + gridDim.y - 1) / gridDim.y;
+  const int b0 = blockIdx.y * per, b1 = min(nblocks, b0 + per);
+  float acc = 0.0f;
+  if (i < 3 * H) {
+#pragma unroll 8
+    for (int b = b0 + ty; b < b1; b += 4) acc += ws[(size_t)b * 3 * H + i];
+  }
+  red[ty][tx] = acc;
+  __syncthreads();
+  if (ty == 0 && i < 3 * H) {
+    const int k = i / H, col = i % H;
+    float* out = k == 0 ? q.dgamma : (k == 1 ? q.dbeta : q.dbias);
+    if (out != nullptr) atomicAdd(out + col, (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]));
+  }
+}
+
 #define LN_BWD_MAXBLOCKS 1024
 
 static inline int ln_grid(int M) {
@@ -455,8 +492,35 @@ int kbner_ln_bwd(const bf16_t* dy, const bf16_t* h, const float* mean, const flo
   else
     hipLaunchKernelGGL((ln_bwd_kernel<2, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, h, mean, rstd, gamma, dh,
                        dgamma, dbeta, dbias, nullptr, nullptr, nullptr, nullptr, ws, M, H, dhm, drop_seed, drop_thresh);
-  hipLaunchKernelGGL(ln_colreduce_kernel, dim3((3 * H + 63) / 64, 8), dim3(256), 0, (hipStream_t)stream, ws, grid, H, dgamma, dbeta,
-                     dbias);
+  // (dgamma == NULL: the partial rows stay in ws -- kbner_ln_bwd_blocks(M) of them -- for kbner_ln_colreduce_batched)
+  if (dgamma != nullptr)
+    hipLaunchKernelGGL(ln_colreduce_kernel, dim3((3 * H + 63) / 64, 8), dim3(256), 0, (hipStream_t)stream, ws, grid, H, dgamma, dbeta,
+                       dbias);
+  KBNER_LAUNCH_RET();
+}
+
+// how many partial rows (of 3 H floats) kbner_ln_bwd leaves in its workspace for M rows
+int kbner_ln_bwd_blocks(int M) {
+  int grid = ln_grid(M);
+  return grid > LN_BWD_MAXBLOCKS ? LN_BWD_MAXBLOCKS : grid;
+}
+
+// items (HOST memory, n <= 64 records of 5 x 64 bits: ws, dgamma, dbeta, dbias -- device pointers, dbias may be 0 -- and the number of
+// partial rows): dgamma / dbeta / dbias += the column sums of each item's partial rows, all in one launch.
+int kbner_ln_colreduce_batched(const long long* items, int n, int H, void* stream) {
+  KBNER_CHECK_ARG(items != nullptr && n >= 0 && n <= LN_BATCH_MAX && H > 0);
+  if (n == 0) return 0;
+  LnPartialBatch b;
+  for (int i = 0; i < n; ++i) {
+    b.it[i].ws = reinterpret_cast<const float*>(items[5 * i]);
+    b.it[i].dgamma = reinterpret_cast<float*>(items[5 * i + 1]);
+    b.it[i].dbeta = reinterpret_cast<float*>(items[5 * i + 2]);
+    b.it[i].dbias = reinterpret_cast<float*>(items[5 * i + 3]);
+    b.it[i].nblocks = items[5 * i + 4];
+    KBNER_CHECK_ARG(b.it[i].ws != nullptr && b.it[i].dgamma != nullptr && b.it[i].dbeta != nullptr && b.it[i].nblocks > 0);
+  }
+  for (int i = n; i < LN_BATCH_MAX; ++i) b.it[i] = b.it[0];
+  hipLaunchKernelGGL(ln_colreduce_batched_kernel, dim3((3 * H + 63) / 64, 8, n), dim3(256), 0, (hipStream_t)stream, b, H);
   KBNER_LAUNCH_RET();
 }
 

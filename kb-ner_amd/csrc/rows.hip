@@ -372,6 +372,48 @@ extern "C" int kbner_colsum_rows_f32(float* ws, int rows, int N, float* out, voi
   KBNER_LAUNCH_RET();
 }
 
+// The single-pass fold for up to COLSUM_BATCH_MAX workspaces of one width in ONE launch (blockIdx.y picks the item): the FFN-up bias
+// gradients of all layers at the end of a small-batch backward pass instead of one 4.8-us launch per layer.  Same summation order
+// per column as the single pass above.
+#define COLSUM_BATCH_MAX 64
+struct ColsumItem {
+  const float* ws;
+  float* out;
+  long long rows;
+};
+struct ColsumBatch {
+  ColsumItem it[COLSUM_BATCH_MAX];
+};
+__global__ __launch_bounds__(1024) void colsum_fold_batched_kernel(const ColsumBatch batch, int N) {
+  __shared__ float part[4][256];
+  const ColsumItem& q = batch.it[blockIdx.y];
+  const int tx = threadIdx.x & 255, ty = threadIdx.x >> 8;
+  const int n = blockIdx.x * 256 + tx;
+  const int count = (int)q.rows;
+  float acc = 0.0f;
+  if (n < N)
+    for (int i = ty; i < count; i += 4) acc += q.ws[(size_t)i * N + n];
+  part[ty][tx] = acc;
+  __syncthreads();
+  if (ty == 0 && n < N) q.out[n] += (part[0][tx] + part[1][tx]) + (part[2][tx] + part[3][tx]);
+}
+
+// items (HOST memory, n <= 64 records of 3 x 64 bits: ws, out -- device pointers -- and the number of rows): out[c] += sum_r ws[r, c]
+extern "C" int kbner_colsum_rows_f32_batched(const long long* items, int n, int N, void* stream) {
+  KBNER_CHECK_ARG(items != nullptr && n >= 0 && n <= COLSUM_BATCH_MAX && N > 0);
+  if (n == 0) return 0;
+  ColsumBatch b;
+  for (int i = 0; i < n; ++i) {
+    b.it[i].ws = reinterpret_cast<const float*>(items[3 * i]);
+    b.it[i].out = reinterpret_cast<float*>(items[3 * i + 1]);
+    b.it[i].rows = items[3 * i + 2];
+    KBNER_CHECK_ARG(b.it[i].ws != nullptr && b.it[i].out != nullptr && b.it[i].rows > 0);
+  }
+  for (int i = n; i < COLSUM_BATCH_MAX; ++i) b.it[i] = b.it[0];
+  hipLaunchKernelGGL(colsum_fold_batched_kernel, dim3((N + 255) / 256, n), dim3(1024), 0, (hipStream_t)stream, b, N);
+  KBNER_LAUNCH_RET();
+}
+
 // fp32 row scatter (data-parallel exchange of the touched word-embedding gradient rows, kbner/dp.py): dst[idx[r],:] = rows[r,:];
 // indices unique, 16-byte accesses (W % 4 == 0)
 __global__ __launch_bounds__(256) void scatter_rows_f32_kernel(const float4* __restrict__ rows, const int* __restrict__ idx,

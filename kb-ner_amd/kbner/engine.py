@@ -261,6 +261,8 @@ class _Acts:
         self.dhm = self.dh1m = None
         self.splitk_ws = None  # f32 [4, Mp, H] split-K slabs, allocated on first use (small micro-batches only)
         self.colsum_ws = None  # f32 [2 * Mp/256, F] column-sum lines of the FFN-down dgrad epilogue (EPI_COLSUM_WS)
+        self.defer_ln_ws = None     # small batches: one partial-sum workspace per LayerNorm / per FFN-up bias (Tagger.encoder_backward)
+        self.colsum_ws_all = None
 
     def drop_buffers(self):
         """masked copies of dh / dh1 (the dY of the two GEMMs whose outputs were dropped); allocated on first training use"""
@@ -412,6 +414,7 @@ class Tagger:
         return ac
 
     SPLITK_MAX_TILES = 64  # outputs with at most this many 256x256 tiles split a long K (small micro-batches)
+    DEFER_REDUCE_MAX_TOKENS = 16384  # micro-batches up to this many (padded) sub-tokens batch their column-sum reductions (encoder_backward)
 
     def _long_k_gemm(self, layout, A, W, Mp, N, K, C, ac, bias=None, addend=None, drop=ops.NO_DROP):
         """C = bf16(dropout(A.W + bias) + addend) for the three K >= 3H GEMMs of a layer (FFN-down forward, its two dgrad
@@ -542,6 +545,17 @@ class Tagger:
         pending = []
         dropping = any(d[1][1] for d in d_layers)
         dhm_ring, dh1m_ring = ac.drop_buffers() if dropping else (ac.dh, ac.dh1)
+        # DEFER_REDUCE_MAX_TOKENS: below it every LayerNorm backward keeps its partial column sums in a workspace of its own and the
+        # FFN-up bias gradients their epilogue lines; both are reduced for the whole pass at its end (ops.ln_colreduce_batched /
+        # colsum_rows_f32_batched) instead of by 3 L launches of ~4.7 us
+        defer = Mp <= self.DEFER_REDUCE_MAX_TOKENS and ops.HBM_HOOK is None
+        ln_items, cs_items, defer_ln, ln_blocks = [], [], None, 0
+        if defer:
+            ln_blocks = ops.ln_bwd_blocks(Mp)
+            if ac.defer_ln_ws is None:
+                ac.defer_ln_ws = torch.empty((2 * L, ln_blocks * 3 * H), dtype=F32, device=self.device)
+                ac.colsum_ws_all = torch.empty((L, 2 * (Mp // 128), F_), dtype=F32, device=self.device)
+            defer_ln = ac.defer_ln_ws
         for l in range(L - 1, -1, -1):
             p = "l%d." % l
             r = l % WGRAD_GROUP
@@ -552,7 +566,10 @@ class Tagger:
             dh1m = dh1m_ring[r] if d_o[1] else dh1
             # LN2 backward; fused: d ffn2.bias = column sums of dh
             ops.ln_bwd(dx, ac.h2[l], ac.st2[l][0], ac.st2[l][1], a.param(p + "ln2.g"), dh, a.grad(p + "ln2.g"),
-                       a.grad(p + "ln2.b"), a.grad(p + "ffn2.bias"), dhm=dhm if d_f[1] else None, drop=d_f)
+                       a.grad(p + "ln2.b"), a.grad(p + "ffn2.bias"), dhm=dhm if d_f[1] else None, drop=d_f,
+                       defer_ws=defer_ln[2 * l + 1] if defer else None)
+            if defer:
+                ln_items.append((defer_ln[2 * l + 1], a.grad(p + "ln2.g"), a.grad(p + "ln2.b"), a.grad(p + "ffn2.bias"), ln_blocks))
             # FFN down dgrad: dpre = (dh W2) * gelu'(pre)   (the derivative itself was saved by the forward epilogue)
             # (its column sums = d ffn1.bias are accumulated by the same epilogue when the 256^2 kernel runs)
             fused = ops.uses_256(Mp, F_, occupancy=True)
@@ -563,16 +580,23 @@ class Tagger:
                     ac.colsum_ws = torch.empty((2 * (Mp // 128), F_), dtype=F32, device=self.device)
                 # ops.gemm reports the tile height of the kernel that ran (256 under dynamic tile draw, the static kernel's pick --
                 # also when the scheduler ring is used up -- otherwise): it decides how many workspace lines hold partial sums
+                cws = ac.colsum_ws_all[l] if defer else ac.colsum_ws
                 trows = ops.gemm(GEMM_NN, dhm, a.bf(p + "ffn2.weight"), Mp, F_, H, C=dpre, aux=ac.dact[l],
-                                 epi=EPI_DGELU | EPI_COLSUM | EPI_COLSUM_WS, colsum=ac.colsum_ws, occupancy=True)
-                ops.colsum_rows_f32(ac.colsum_ws, 2 * (Mp // trows), a.grad(p + "ffn1.bias"))
+                                 epi=EPI_DGELU | EPI_COLSUM | EPI_COLSUM_WS, colsum=cws, occupancy=True)
+                if defer and 2 * (Mp // trows) <= 64:
+                    cs_items.append((cws, a.grad(p + "ffn1.bias"), 2 * (Mp // trows)))
+                else:
+                    ops.colsum_rows_f32(cws, 2 * (Mp // trows), a.grad(p + "ffn1.bias"))
             else:
                 ops.gemm(GEMM_NN, dhm, a.bf(p + "ffn2.weight"), Mp, F_, H, C=dpre, aux=ac.dact[l], epi=EPI_DGELU, occupancy=True)
                 ops.colsum(dpre, a.grad(p + "ffn1.bias"))
             self._long_k_gemm(GEMM_NN, dpre, a.bf(p + "ffn1.weight"), Mp, H, F_, ac.dx1, ac, addend=dh)
             # LN1 backward; fused: d o.bias
             ops.ln_bwd(ac.dx1, ac.h1[l], ac.st1[l][0], ac.st1[l][1], a.param(p + "ln1.g"), dh1, a.grad(p + "ln1.g"),
-                       a.grad(p + "ln1.b"), a.grad(p + "o.bias"), dhm=dh1m if d_o[1] else None, drop=d_o)
+                       a.grad(p + "ln1.b"), a.grad(p + "o.bias"), dhm=dh1m if d_o[1] else None, drop=d_o,
+                       defer_ws=defer_ln[2 * l] if defer else None)
+            if defer:
+                ln_items.append((defer_ln[2 * l], a.grad(p + "ln1.g"), a.grad(p + "ln1.b"), a.grad(p + "o.bias"), ln_blocks))
             # attention output projection
             ops.gemm(GEMM_NN, dh1m, a.bf(p + "o.weight"), Mp, H, H, C=ac.dctx, occupancy=True)
             # attention core (+ d qkv.bias = column sums of dqkv, accumulated inside the kernels)
@@ -595,6 +619,12 @@ class Tagger:
                     ops.sched_active(True)   # a collective is in flight from here to the end of this backward pass
             dx = ac.dx
         a.wgrad_stale = False   # every GEMM-weight gradient has been written by this pass
+        # small batches: the column-sum reductions of the pass (2 L LayerNorm partials -> gamma / beta / bias gradients, L FFN-up bias
+        # workspaces) in two launches instead of 3 L
+        for k in range(0, len(ln_items), 64):
+            ops.ln_colreduce_batched(ln_items[k:k + 64], H)
+        for k in range(0, len(cs_items), 64):
+            ops.colsum_rows_f32_batched(cs_items[k:k + 64], F_)
         ops.embed_ln_bwd(dx, ac.h0, ac.emb_mean, ac.emb_rstd, a.param("emb.ln.g"), ids, pos_ids, a.grad("emb.ln.g"),
                          a.grad("emb.ln.b"), a.grad("emb.word"), a.grad("emb.pos"), a.grad("emb.type")[0], drop=d_emb)
         if a.emb_flags is not None:

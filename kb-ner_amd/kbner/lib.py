@@ -55,6 +55,9 @@ SIGNATURES = {
                                 P, c_int, c_int, c_int, c_float, U32, U32, P]),
     "kbner_gemm_bf16_grouped": (c_int, [c_int, c_int, P, P]),
     "kbner_colsum_rows_f32": (c_int, [P, c_int, c_int, P, P]),
+    "kbner_colsum_rows_f32_batched": (c_int, [P, c_int, c_int, P]),
+    "kbner_ln_bwd_blocks": (c_int, [c_int]),
+    "kbner_ln_colreduce_batched": (c_int, [P, c_int, c_int, P]),
     "kbner_gemm_tile_rows": (c_int, [c_int, c_int, c_int]),
     "kbner_gemm_bf16_grouped_dyn": (c_int, [c_int, c_int, P, P, P]),
     "kbner_gemm_set_variant": (c_int, [c_int]),

@@ -347,12 +347,41 @@ def ln_ws(H, device):
     return _LN_WS[key]
 
 
-def ln_bwd(dy, h, mean, rstd, gamma, dh, dgamma, dbeta, dbias=None, dhm=None, drop=NO_DROP):
-    """drop=(seed, thresh) with thresh != 0: also writes dhm = mask * dh / (1-p) (the dY of the GEMM behind the dropout)."""
+def ln_bwd(dy, h, mean, rstd, gamma, dh, dgamma, dbeta, dbias=None, dhm=None, drop=NO_DROP, defer_ws=None):
+    """drop=(seed, thresh) with thresh != 0: also writes dhm = mask * dh / (1-p) (the dY of the GEMM behind the dropout).
+    defer_ws (f32, >= ln_bwd_blocks(M) * 3 H): the per-block partial column sums stay there instead of being reduced into dgamma /
+    dbeta / dbias by a launch of their own -- the caller reduces a whole backward pass's worth with ln_colreduce_batched."""
     M, H = h.shape
     with _hbm_timed("ln_bwd", (8 if drop[1] else 6) * M * H):   # read dy, h; write dh (+ dhm with dropout)
-        L.call("kbner_ln_bwd", ptr(dy), ptr(h), ptr(mean), ptr(rstd), ptr(gamma), ptr(dh), ptr(dgamma), ptr(dbeta), ptr(dbias),
-               ptr(ln_ws(H, h.device)), M, H, ptr(dhm), drop[0], drop[1], stream_ptr())
+        if defer_ws is not None:
+            L.call("kbner_ln_bwd", ptr(dy), ptr(h), ptr(mean), ptr(rstd), ptr(gamma), ptr(dh), None, None, None,
+                   ptr(defer_ws), M, H, ptr(dhm), drop[0], drop[1], stream_ptr())
+        else:
+            L.call("kbner_ln_bwd", ptr(dy), ptr(h), ptr(mean), ptr(rstd), ptr(gamma), ptr(dh), ptr(dgamma), ptr(dbeta), ptr(dbias),
+                   ptr(ln_ws(H, h.device)), M, H, ptr(dhm), drop[0], drop[1], stream_ptr())
+
+
+def ln_bwd_blocks(M):
+    return int(L.load().kbner_ln_bwd_blocks(int(M)))
+
+
+def _host_items(records):
+    import ctypes
+    flat = [int(x) for r in records for x in r]
+    return (ctypes.c_longlong * len(flat))(*flat)
+
+
+def ln_colreduce_batched(records, H):
+    """records: (ws, dgamma, dbeta, dbias or None, partial rows) per LayerNorm -- one launch adds all their column sums"""
+    items = _host_items([(w.data_ptr(), dg.data_ptr(), db.data_ptr(), dbi.data_ptr() if dbi is not None else 0, nb)
+                         for w, dg, db, dbi, nb in records])
+    L.call("kbner_ln_colreduce_batched", items, len(records), H, stream_ptr())
+
+
+def colsum_rows_f32_batched(records, N):
+    """records: (ws f32[rows, N], out f32[N], rows): out += column sums, every record in one launch"""
+    items = _host_items([(w.data_ptr(), o.data_ptr(), rows) for w, o, rows in records])
+    L.call("kbner_colsum_rows_f32_batched", items, len(records), N, stream_ptr())
 
 
 def embed_ln_fwd(ids, pos_ids, word, pos, type0, gamma, beta, eps, h0, y, mean, rstd, drop=NO_DROP):

@@ -690,6 +690,44 @@ def test_sparse_embedding_optimizer_equals_dense():
     assert float((tg.arena.param("emb.word")[~dead] - p0[~dead]).abs().max()) > 0
 
 
+def test_deferred_column_sum_reductions_give_the_same_gradients():
+    """Tagger.encoder_backward below DEFER_REDUCE_MAX_TOKENS (round 6): the 2 L LayerNorm backward passes keep their per-block partial
+    sums and the L FFN-up bias gradients their epilogue lines, all reduced by two launches at the end of the pass
+    (kbner_ln_colreduce_batched / kbner_colsum_rows_f32_batched) instead of 3 L launches along the way.  Same gradients as the
+    immediate route: the FFN-up bias gradients bit for bit (same single-pass order), the LayerNorm / o / ffn2-bias gradients to the
+    order of their 8 fp32 atomics per entry; two micro-batches accumulate."""
+    import torch
+    from kbner import batch as kb
+    from kbner import engine
+    T, start, stop, x_idx = 29, 27, 28, 9
+    cfg = engine.EncoderConfig(vocab_size=600, hidden_size=256, num_hidden_layers=3, num_attention_heads=4, intermediate_size=1024,
+                               max_position_embeddings=520, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    tgs = []
+    for limit in (0, 16384):
+        tg = engine.Tagger(cfg, T, start, stop, device="cuda")
+        tg.init_random(seed=21)
+        tg.DEFER_REDUCE_MAX_TOKENS = limit
+        tgs.append(tg)
+    for k in range(2):
+        mb = kb.to_device(kb.synthetic_batch(4, 512, vocab=600, T=T, x_idx=x_idx, start=start, stop=stop, seed=700 + k), "cuda")
+        for tg in tgs:
+            tg.forward_loss(mb, loss_scale=0.5, backward=True)
+    torch.cuda.synchronize()
+    a0, a1 = tgs[0].arena, tgs[1].arena
+    assert tgs[1].acts(4, 512).defer_ln_ws is not None and tgs[0].acts(4, 512).defer_ln_ws is None
+    from kbner import ops
+    assert ops.uses_256(2048, 1024, occupancy=True)          # the FFN-up bias gradients take the epilogue-workspace route
+    for name in a0.offsets:
+        g0, g1 = a0.grad(name), a1.grad(name)
+        assert torch.isfinite(g1).all(), name
+        if name.endswith("ffn1.bias"):
+            assert torch.equal(g0, g1) and float(g0.abs().max()) > 0, name
+        else:
+            assert float((g0 - g1).abs().max()) <= 2e-5 * max(float(g0.abs().max()), 1e-6), (name, float((g0 - g1).abs().max()))
+    for name in ("l1.ln1.g", "l0.ln2.b", "l2.o.bias", "l1.ffn2.bias"):
+        assert float(a1.grad(name).abs().max()) > 0, name
+
+
 def test_lazy_embedding_rows_equal_eager():
     """FusedAdamW.lazy_rows (round 6; kbner_adamw_hf_rows_lazy / kbner_adamw_rows_catchup): a live embedding row that gets no gradient
     is not streamed through HBM every step -- the zero-gradient updates it owes are applied, same fp32 operations in the same order,
