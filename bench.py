@@ -296,6 +296,7 @@ def main():
         if not args.eager_rows:
             opt.lazy_rows_for(B * S * accum)   # what the trainer does: lazy when a step visits at most 1/8 of the table
         row_debt = impose_row_debt(opt, B * S * accum, seed=kb.SEED)
+    rows_mode = "lazy" if opt.lazy_rows else "eager"    # (of the timed run: the secondary measurements choose per step size)
     step_no = [0]
 
     # data parallel: the gradient exchange of a step overlaps with its backward (kbner.dp.GradReducer): the GEMM-weight
@@ -669,7 +670,7 @@ def main():
             "loss_first": round(loss_first, 4), "loss_last": round(loss_last, 4),
             # N = 1: content ids are redrawn every step; with lazy embedding rows the run starts from the steady state of the deferred
             # row updates (impose_row_debt: as many row updates per step as the eager optimizer performs, done in registers)
-            "optimizer": {"embedding_rows": "lazy" if opt.lazy_rows else "eager", "ids": "fresh per step" if micro_variants is not None else "fixed",
+            "optimizer": {"embedding_rows": rows_mode, "ids": "fresh per step" if micro_variants is not None else "fixed",
                           "row_debt": row_debt},
         }
         if roofline is not None:
