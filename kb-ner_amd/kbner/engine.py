@@ -939,6 +939,12 @@ class FusedAdamW:
         self.split = arena.offsets["transitions"]
         self.sparse_embedding = True   # skip word-embedding rows that never received a gradient (exact; see step())
         self._lazy_rows = False
+        if getattr(arena, "lazy", None) is not None:
+            # an earlier optimizer of this arena left its table lazy: bring every row up to date and retire that clock -- this
+            # optimizer's (eager until lazy_rows is set) would otherwise step rows that still owe the old one
+            arena.materialize_rows()
+            arena.lazy["row_t"].fill_(-1)
+            arena.lazy = None
 
     # lazy_rows (opt-in; the trainer and bench.py switch it on).  A live embedding row that receives no gradient in a step is
     # moved by an update that reads nothing but its own p / m / v: instead of streaming all live rows through HBM every step

@@ -800,6 +800,22 @@ def test_lazy_embedding_rows_equal_eager():
     assert tb.arena.lazy is None
     for name in ("p", "m", "v"):
         assert torch.equal(getattr(ta.arena, name), getattr(tb.arena, name)), ("off", name)
+    # a SECOND optimizer on an arena whose first one left the table lazy (trainer.train called twice): the stale rows are brought up
+    # to date and the old clock retired before the new optimizer steps anything
+    ob.lazy_rows = True
+    for k in range(2):
+        mb = kb.to_device(kb.synthetic_batch(3, 128, vocab=300, T=T, x_idx=x_idx, start=start, stop=stop, seed=1200 + k), "cuda")
+        la = float(ta.forward_loss(mb, loss_scale=1.0, backward=True))
+        lb = float(tb.forward_loss(mb, loss_scale=1.0, backward=True))
+        assert la == lb
+        tb.arena.g.copy_(ta.arena.g)
+        oa.step(), ob.step()
+    assert tb.arena.lazy is not None and tb.arena.lazy["dirty"]
+    ob2 = engine.FusedAdamW(tb.arena, lr=1e-3, lr_rate=10.0, t_total=40, warmup=3, max_norm=0.5)
+    assert tb.arena.lazy is None and not ob2.lazy_rows
+    torch.cuda.synchronize()
+    for name in ("p", "m", "v"):
+        assert torch.equal(getattr(ta.arena, name), getattr(tb.arena, name)), ("second optimizer", name)
 
 
 def test_weight_gradients_overwrite_instead_of_zeroing():
