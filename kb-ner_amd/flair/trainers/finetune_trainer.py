@@ -354,7 +354,11 @@ class ModelFinetuner:
         self.optimizer = opt
         # word-embedding rows that receive no gradient in a step are updated when the encoder next looks them up instead of being
         # streamed through HBM every step (FusedAdamW.lazy_rows: the same updates, bit for bit; state_dict / save materialize)
-        if bool(getattr(self, "lazy_embedding_rows", True)) and hasattr(opt, "lazy_rows_for"):
+        # (trainer.lazy_embedding_rows: True = where it pays, a step that visits at most an eighth of the table; "always"; False)
+        lazy_sw = getattr(self, "lazy_embedding_rows", True)
+        if lazy_sw == "always" and hasattr(opt, "lazy_rows"):
+            opt.lazy_rows = True
+        elif bool(lazy_sw) and hasattr(opt, "lazy_rows_for"):
             opt.lazy_rows_for(mini_batch_size * accum * W * 512)   # sub-tokens per step at most: 512 per sentence
         rng = random.Random(20220711)  # rank-shared shuffle of the batch order
         order = list(range(len(loader)))  # batch order as a permutation of the loader's (fixed) batches: checkpointable

@@ -226,6 +226,55 @@ def test_bench_two_ranks_one_gpu_functional():
     assert abs(e["loss_last"] - d["loss_last"]) < 1e-3 * abs(d["loss_last"]), (e["loss_last"], d["loss_last"])
 
 
+def test_trainer_two_ranks_one_gpu_equals_accumulation(tmp_path):
+    """The drop-in trainer itself under data parallelism, with the REAL engine (tests/test_dp_trainer_gloo_cpu.py checks its control
+    flow on host stand-ins): two ranks of `ModelFinetuner.train` on one GPU (gloo collectives on device tensors), mini_batch_size 2,
+    against ONE process that accumulates the same two micro-batches per step.  Same shuffled batch order (rank-shared RNG), same
+    number of optimizer steps, the mean gradient either way (overlapped bucket all-reduce + sparse embedding-row exchange + 1/W in
+    AdamW against loss / accumulate), sharded evaluation with summed counters: the final parameters, Adam moments, loss and dev-score
+    histories agree.  Lazy embedding rows are forced on in both runs: rows a rank never looked up receive gradients from the other
+    rank's batches (the exchange marks them touched) and are caught up inside the update."""
+    import subprocess
+    import sys
+    import tiny_assets
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = tmp_path
+    cfg = tiny_assets.e2e_config(str(d), word_dropout=0.0, max_epochs=2, shuffle=True, n_train=32, n_dev=8, n_test=8, accum=1,
+                                 mini_batch_size=2, save_finetuned_embedding=False)
+    with open(d / "cfg.yaml", "w") as f:
+        yaml.safe_dump(cfg, f)
+    worker = os.path.join(root, "tests", "dp_trainer_gpu_worker.py")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r1 = subprocess.run([sys.executable, worker, str(d / "cfg.yaml"), str(d / "w1.pt"), "2"], cwd=root, env=env,
+                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert r1.returncode == 0, r1.stdout.decode()[-3000:]
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                         "127.0.0.1", "--master-port", "29541", worker, str(d / "cfg.yaml"), str(d / "w2.pt"), "1"], cwd=root, env=env,
+                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert r2.returncode == 0, r2.stdout.decode()[-3000:]
+    a, b = torch.load(d / "w1.pt"), torch.load(d / "w2.pt")
+    assert a["world"] == 1 and b["world"] == 2 and a["t"] == b["t"] == 2 * 8, (a["t"], b["t"])   # 16 batches of 2 -> 8 steps per epoch
+    # (the tiny vocabulary makes the exchange dense -- more than half of the rows are touched per step --, which flags every row;
+    #  rows that never receive a gradient keep m = v = 0 and do not move either way)
+    assert 0 < a["live_rows"] <= b["live_rows"]
+    # the clip norm of the mean gradient, step by step: the first step starts from identical parameters -- equal to fp32 summation
+    # order; later steps inherit what Adam makes of that noise (an entry whose gradient is ~0 moves by +-lr whatever its sign)
+    na, nb = np.asarray(a["clip_norms"]), np.asarray(b["clip_norms"])
+    assert na.shape == nb.shape == (16,) and abs(na[0] - nb[0]) < 1e-5 * na[0], (na[:3], nb[:3])
+    assert np.abs(na - nb).max() < 5e-3 * na.max(), (na, nb)
+    for k, tol in (("p", 5e-3), ("m", 2e-2)):
+        x, y = a[k].double(), b[k].double()
+        rel = float((x - y).norm() / x.norm())
+        assert rel < tol, (k, rel)
+    # the reference's epoch loss is the mean of loss / accumulate over the micro-batches (finetune_trainer.py:1003-1004, 1070): the
+    # accumulating twin reports half of what the two ranks report
+    la, lb = np.asarray(a["train_loss_history"]), np.asarray(b["train_loss_history"])
+    assert la.shape == lb.shape == (2,) and np.abs(2.0 * la - lb).max() < 5e-3 * np.abs(lb).max(), (la, lb)
+    assert np.allclose(a["dev_score_history"], b["dev_score_history"], atol=10.0), (a["dev_score_history"], b["dev_score_history"])
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs: RCCL cannot put two ranks on one device")
 def test_bench_two_ranks_rccl():
     """the real thing whenever the box has two GPUs: one process per GPU over RCCL (backend nccl), overlapped bucketed exchange,
