@@ -186,6 +186,8 @@ def main():
     ap.add_argument("--bucket-layers", type=int, default=4, choices=[4, 8, 12, 24], help="N>1: layers per gradient bucket (4 = one per grouped "
                     "weight-gradient launch, 201 MB; 8 = two launches per all-reduce, 402 MB)")
     ap.add_argument("--exchange-delay", type=int, default=0, help="N>1: issue a bucket's all-reduce only when this many later buckets are ready")
+    ap.add_argument("--splitk-finish-kernel", action="store_true",
+                    help="A/B (small micro-batches): fold split-K slabs with kbner_splitk_finish instead of inside the LayerNorm kernels")
     ap.add_argument("--eager-rows", action="store_true",
                     help="A/B: every live word-embedding row through HBM in every optimizer step (round 5) instead of FusedAdamW.lazy_rows")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (small micro-batches, dropout)")
@@ -271,6 +273,8 @@ def main():
         tg.train(True)
         tg.word_dropout = args.dropout
         tg.seed_dropout(kb.SEED + 7919 * rank)
+    if args.splitk_finish_kernel:
+        tg.FUSE_SPLITK_LN = False
     B, S, accum = args.micro_batch, args.seq_len, args.accum
     # each rank gets its own shard of synthetic sentences (weak scaling: per-GPU work fixed)
     micro = [kb.to_device(kb.synthetic_batch(B, S, vocab=cfg.vocab_size, T=T, x_idx=x_idx, start=start, stop=stop,

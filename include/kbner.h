@@ -157,6 +157,16 @@ int kbner_ln_bwd_ws_floats(int H);
 int kbner_ln_bwd(const kbner_bf16* dy, const kbner_bf16* h, const float* mean, const float* rstd, const float* gamma,
                  kbner_bf16* dh, float* dgamma, float* dbeta, float* dbias, float* ws, int M, int H, kbner_bf16* dhm,
                  uint32_t drop_seed, uint32_t drop_thresh, void* stream);
+/* kbner_ln_fwd / kbner_ln_bwd whose input row is FOLDED from the fp32 slabs of a split-K GEMM (ws f32 [splits][M, H], the grouped
+ * KBNER_EPI_STORE32 launch) on the way in: bf16(dropout(sum_s ws[s] + bias) + addend) -- kbner_splitk_finish's arithmetic, the same
+ * bits -- without that launch and without reading its output back.  Forward: the folded row is also stored to `h` (the backward pass
+ * reads it).  Backward: the incoming gradient is sum_s dy_ws[s] + dy_add; dgamma == NULL defers the column sums as for kbner_ln_bwd. */
+int kbner_ln_fwd_slabs(const float* ws, int splits, const float* bias, const kbner_bf16* addend, int ldadd, uint32_t drop_seed,
+                       uint32_t drop_thresh, kbner_bf16* h, const float* gamma, const float* beta, float eps, kbner_bf16* y, float* mean,
+                       float* rstd, int M, int H, void* stream);
+int kbner_ln_bwd_slabs(const float* dy_ws, int splits, const kbner_bf16* dy_add, int ldadd, const kbner_bf16* h, const float* mean,
+                       const float* rstd, const float* gamma, kbner_bf16* dh, float* dgamma, float* dbeta, float* dbias, float* ws, int M,
+                       int H, kbner_bf16* dhm, uint32_t drop_seed, uint32_t drop_thresh, void* stream);
 /* Small batches: kbner_ln_bwd with dgamma == NULL (dbeta / dbias ignored) leaves its kbner_ln_bwd_blocks(M) partial rows in `ws` instead
  * of reducing them with a launch of its own; kbner_ln_colreduce_batched then adds the column sums of up to 64 such workspaces to their
  * gradients in ONE launch (49 LayerNorm backward passes per encoder backward pass at 4.7 us each otherwise).  items: HOST memory,

@@ -107,6 +107,44 @@ static __host__ __device__ __forceinline__ float drop_scale(uint32_t thresh) {
   return 4294967296.0f / (4294967296.0f - (float)thresh);
 }
 
+// bf16(dropout(sum_s ws[s][m, n..n+8) + bias) + addend), eight consecutive columns, packed: the fold of split-K slabs (f32 [splits][M, N],
+// `slab` = M * N).  ONE definition for kbner_splitk_finish (csrc/rows.hip) and for the LayerNorm kernels that read the slabs directly
+// (csrc/layernorm.hip: kbner_ln_fwd_slabs / kbner_ln_bwd_slabs): every route gives the same bits.
+static __device__ __forceinline__ uint4 splitk_fold8_pack(const float* __restrict__ ws, int splits, size_t slab, const float* __restrict__ bias,
+                                                          const bf16_t* __restrict__ addend, int ldadd, int m, int n, int N,
+                                                          uint32_t drop_seed, uint32_t drop_thresh) {
+  const size_t i = (size_t)m * N + n;
+  float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < splits; ++s) {
+    const float4 a = *reinterpret_cast<const float4*>(ws + s * slab + i);
+    const float4 b = *reinterpret_cast<const float4*>(ws + s * slab + i + 4);
+    v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+    v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+  }
+  if (bias) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] += bias[n + r];
+  }
+  if (drop_thresh) {
+    const uint32_t rk = drop_rowkey(drop_seed, (uint32_t)m);
+    const float ds = drop_scale(drop_thresh);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = drop_keep(rk, drop_colkey(drop_seed, (uint32_t)(n + r)), drop_thresh) ? v[r] * ds : 0.0f;
+  }
+  if (addend) {
+    const uint4 u = *reinterpret_cast<const uint4*>(addend + (size_t)m * ldadd + n);
+    const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      v[2 * r] += __uint_as_float(w[r] << 16);
+      v[2 * r + 1] += __uint_as_float(w[r] & 0xffff0000u);
+    }
+  }
+  uint4 o;
+  o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]); o.z = pack2bf(v[4], v[5]); o.w = pack2bf(v[6], v[7]);
+  return o;
+}
+
 // GELU, erf form (HF hidden_act="gelu"), and its derivative.  erf by Abramowitz-Stegun 7.1.26
 // (|error| <= 1.5e-7, far below the bf16 rounding of the stored result) so the GEMM epilogue costs
 // one v_rcp + one v_exp + a 5-term Horner per element instead of libm erff; exp(-x^2/2) is shared

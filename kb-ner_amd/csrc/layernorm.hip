@@ -181,6 +181,49 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
   }
 }
 
+// The same with the input row FOLDED from split-K slabs on the way in (round 6, small micro-batches): h = bf16(dropout(sum_s ws[s] +
+// bias) + addend) is what kbner_splitk_finish would have written -- splitk_fold8_pack, the same bits --; it is stored (the backward
+// pass reads it) and normalised without the launch and the read-back in between.  M <= a few thousand rows: one row per wave.
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_fwd_slabs_kernel(const float* __restrict__ ws, int splits, const float* __restrict__ bias,
+                                                           const bf16_t* __restrict__ addend, int ldadd, uint32_t drop_seed,
+                                                           uint32_t drop_thresh, bf16_t* __restrict__ h, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps, bf16_t* __restrict__ y,
+                                                           float* __restrict__ mean_o, float* __restrict__ rstd_o, int M, int H) {
+  const int lane = threadIdx.x % 64;
+  const int wave = blockIdx.x * 4 + threadIdx.x / 64;
+  const int nwave = gridDim.x * 4;
+  const size_t slab = (size_t)M * H;
+  RowF<NCH> g, b;
+  load_row_f32<NCH>(gamma, H, lane, g);
+  load_row_f32<NCH>(beta, H, lane, b);
+  for (int r = wave; r < M; r += nwave) {
+    RowRaw<NCH> raw;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int h0 = (lane + 64 * c) * 8;
+      raw.v[c] = make_uint4(0u, 0u, 0u, 0u);
+      if (h0 < H) {
+        raw.v[c] = splitk_fold8_pack(ws, splits, slab, bias, addend, ldadd, r, h0, H, drop_seed, drop_thresh);
+        *reinterpret_cast<uint4*>(h + (size_t)r * H + h0) = raw.v[c];
+      }
+    }
+    RowF<NCH> x;
+    unpack_row<NCH>(raw, x);
+    float mean, rstd;
+    row_stats<NCH>(x, H, eps, mean, rstd);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x.v[c][j] = (x.v[c][j] - mean) * rstd * g.v[c][j] + b.v[c][j];
+    store_row_bf16<NCH>(y + (size_t)r * H, H, lane, x);
+    if (lane == 0) {
+      mean_o[r] = mean;
+      rstd_o[r] = rstd;
+    }
+  }
+}
+
 // word[ids] + pos[pos_ids] + type[0] -> h0 (bf16, saved) -> LayerNorm -> y
 template <int NCH>
 __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int* __restrict__ ids, const int* __restrict__ pos_ids,
@@ -250,7 +293,7 @@ static __device__ __forceinline__ void flush_row_atomic(float* __restrict__ dst,
 
 // Backward.  EMBED: additionally scatter-add dh into the embedding-table gradients (fp32 atomics:
 // token ids repeat) and accumulate sum_rows dh into dtype0 through the dbias path.
-template <int NCH, bool EMBED>
+template <int NCH, bool EMBED, bool SLABS = false>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ h,
                                                      const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
                                                      const float* __restrict__ gamma, bf16_t* __restrict__ dh,
@@ -258,7 +301,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                                                      float* __restrict__ dbias, const int* __restrict__ ids,
                                                      const int* __restrict__ pos_ids, float* __restrict__ dword,
                                                      float* __restrict__ dpos, float* __restrict__ ws, int M, int H,
-                                                     bf16_t* __restrict__ dhm, uint32_t drop_seed, uint32_t drop_thresh) {
+                                                     bf16_t* __restrict__ dhm, uint32_t drop_seed, uint32_t drop_thresh,
+                                                     const float* __restrict__ dy_ws = nullptr, int dy_splits = 0,
+                                                     const bf16_t* __restrict__ dy_add = nullptr, int dy_ldadd = 0) {
+  // SLABS (round 6, small micro-batches; a separate instantiation, the other one is untouched): the incoming gradient row is folded from the split-K slabs of the GEMM that
+  // produced it -- bf16(sum_s dy_ws[s] + dy_add), kbner_splitk_finish's bits (splitk_fold8_pack) -- instead of read from `dy`.
   // Dropout replay (drop_thresh != 0): EMBED -> the incoming dy is masked first (y = drop(LN(h0)));
   // otherwise -> the GEMM whose (dropped) output fed this LayerNorm's input gets dhm = mask * dh as its dY, the
   // residual branch keeps the unmasked dh, and the GEMM's bias gradient (dbias) sums the masked rows.
@@ -281,9 +328,22 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
   // one row ahead: the loads of row r + nwave are in flight while row r is reduced and stored
   RowRaw<NCH> xraw, draw;
   float mean_n = 0.0f, rstd_n = 0.0f;
+  const size_t dy_slab = (size_t)M * H;
+  auto load_dy = [&](int row, RowRaw<NCH>& out) {
+    if constexpr (!SLABS) {
+      load_row_raw<NCH>(dy + (size_t)row * H, H, lane, out);
+    } else {
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int h0 = (lane + 64 * c) * 8;
+        out.v[c] = (h0 < H) ? splitk_fold8_pack(dy_ws, dy_splits, dy_slab, nullptr, dy_add, dy_ldadd, row, h0, H, 0u, 0u)
+                            : make_uint4(0u, 0u, 0u, 0u);
+      }
+    }
+  };
   if (wave < M) {
     load_row_raw<NCH>(h + (size_t)wave * H, H, lane, xraw);
-    load_row_raw<NCH>(dy + (size_t)wave * H, H, lane, draw);
+    load_dy(wave, draw);
     mean_n = mean_i[wave];
     rstd_n = rstd_i[wave];
   }
@@ -295,7 +355,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
     const int rn = r + nwave;
     if (rn < M) {
       load_row_raw<NCH>(h + (size_t)rn * H, H, lane, xraw);
-      load_row_raw<NCH>(dy + (size_t)rn * H, H, lane, draw);
+      load_dy(rn, draw);
       mean_n = mean_i[rn];
       rstd_n = rstd_i[rn];
     }
@@ -493,6 +553,45 @@ int kbner_ln_bwd(const bf16_t* dy, const bf16_t* h, const float* mean, const flo
     hipLaunchKernelGGL((ln_bwd_kernel<2, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, h, mean, rstd, gamma, dh,
                        dgamma, dbeta, dbias, nullptr, nullptr, nullptr, nullptr, ws, M, H, dhm, drop_seed, drop_thresh);
   // (dgamma == NULL: the partial rows stay in ws -- kbner_ln_bwd_blocks(M) of them -- for kbner_ln_colreduce_batched)
+  if (dgamma != nullptr)
+    hipLaunchKernelGGL(ln_colreduce_kernel, dim3((3 * H + 63) / 64, 8), dim3(256), 0, (hipStream_t)stream, ws, grid, H, dgamma, dbeta,
+                       dbias);
+  KBNER_LAUNCH_RET();
+}
+
+// kbner_ln_fwd / kbner_ln_bwd with the input row folded from split-K slabs (ws f32 [splits][M, H]) instead of read as bf16: what
+// kbner_splitk_finish would have written, without its launch.  Forward: h (the folded row, bf16) is stored as well.
+int kbner_ln_fwd_slabs(const float* ws, int splits, const float* bias, const bf16_t* addend, int ldadd, uint32_t drop_seed,
+                       uint32_t drop_thresh, bf16_t* h, const float* gamma, const float* beta, float eps, bf16_t* y, float* mean,
+                       float* rstd, int M, int H, void* stream) {
+  KBNER_CHECK_ARG(M >= 0 && H > 0 && H % 8 == 0 && H <= 64 * 8 * LN_MAXCH && ws != nullptr && splits >= 1 && splits <= 16);
+  KBNER_CHECK_ARG(h != nullptr && y != nullptr && (addend == nullptr || ldadd % 8 == 0));
+  if (M == 0) return 0;
+  if (H <= 512)
+    hipLaunchKernelGGL(ln_fwd_slabs_kernel<1>, dim3(ln_grid(M)), dim3(256), 0, (hipStream_t)stream, ws, splits, bias, addend, ldadd,
+                       drop_seed, drop_thresh, h, gamma, beta, eps, y, mean, rstd, M, H);
+  else
+    hipLaunchKernelGGL(ln_fwd_slabs_kernel<2>, dim3(ln_grid(M)), dim3(256), 0, (hipStream_t)stream, ws, splits, bias, addend, ldadd,
+                       drop_seed, drop_thresh, h, gamma, beta, eps, y, mean, rstd, M, H);
+  KBNER_LAUNCH_RET();
+}
+
+int kbner_ln_bwd_slabs(const float* dy_ws, int splits, const bf16_t* dy_add, int ldadd, const bf16_t* h, const float* mean,
+                       const float* rstd, const float* gamma, bf16_t* dh, float* dgamma, float* dbeta, float* dbias, float* ws, int M,
+                       int H, bf16_t* dhm, uint32_t drop_seed, uint32_t drop_thresh, void* stream) {
+  KBNER_CHECK_ARG(M >= 0 && H > 0 && H % 8 == 0 && H <= 64 * 8 * LN_MAXCH && ws != nullptr && dy_ws != nullptr);
+  KBNER_CHECK_ARG(splits >= 1 && splits <= 16 && (dy_add == nullptr || ldadd % 8 == 0) && (drop_thresh == 0 || dhm != nullptr));
+  if (M == 0) return 0;
+  int grid = ln_grid(M);
+  if (grid > LN_BWD_MAXBLOCKS) grid = LN_BWD_MAXBLOCKS;
+  if (H <= 512)
+    hipLaunchKernelGGL((ln_bwd_kernel<1, false, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)nullptr, h, mean, rstd,
+                       gamma, dh, dgamma, dbeta, dbias, nullptr, nullptr, nullptr, nullptr, ws, M, H, dhm, drop_seed, drop_thresh, dy_ws,
+                       splits, dy_add, ldadd);
+  else
+    hipLaunchKernelGGL((ln_bwd_kernel<2, false, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)nullptr, h, mean, rstd,
+                       gamma, dh, dgamma, dbeta, dbias, nullptr, nullptr, nullptr, nullptr, ws, M, H, dhm, drop_seed, drop_thresh, dy_ws,
+                       splits, dy_add, ldadd);
   if (dgamma != nullptr)
     hipLaunchKernelGGL(ln_colreduce_kernel, dim3((3 * H + 63) / 64, 8), dim3(256), 0, (hipStream_t)stream, ws, grid, H, dgamma, dbeta,
                        dbias);

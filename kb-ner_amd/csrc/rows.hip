@@ -531,35 +531,7 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
   const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 8;  // 8 consecutive columns per thread
   if (i >= (size_t)M * N) return;
   const int m = (int)(i / N), n = (int)(i % N);
-  float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int s = 0; s < splits; ++s) {
-    const float4 a = *reinterpret_cast<const float4*>(ws + s * slab + i);
-    const float4 b = *reinterpret_cast<const float4*>(ws + s * slab + i + 4);
-    v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
-    v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
-  }
-  if (bias) {
-#pragma unroll
-    for (int r = 0; r < 8; ++r) v[r] += bias[n + r];
-  }
-  if (drop_thresh) {
-    const uint32_t rk = drop_rowkey(drop_seed, (uint32_t)m);
-    const float ds = drop_scale(drop_thresh);
-#pragma unroll
-    for (int r = 0; r < 8; ++r) v[r] = drop_keep(rk, drop_colkey(drop_seed, (uint32_t)(n + r)), drop_thresh) ? v[r] * ds : 0.0f;
-  }
-  if (addend) {
-    const uint4 u = *reinterpret_cast<const uint4*>(addend + (size_t)m * ldadd + n);
-    const uint32_t w[4] = {u.x, u.y, u.z, u.w};
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      v[2 * r] += __uint_as_float(w[r] << 16);
-      v[2 * r + 1] += __uint_as_float(w[r] & 0xffff0000u);
-    }
-  }
-  uint4 o;
-  o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]); o.z = pack2bf(v[4], v[5]); o.w = pack2bf(v[6], v[7]);
-  *reinterpret_cast<uint4*>(C + (size_t)m * ldc + n) = o;
+  *reinterpret_cast<uint4*>(C + (size_t)m * ldc + n) = splitk_fold8_pack(ws, splits, slab, bias, addend, ldadd, m, n, N, drop_seed, drop_thresh);
 }
 
 extern "C" int kbner_splitk_finish(const float* ws, int splits, const float* bias, const bf16_t* addend, int ldadd, bf16_t* C, int ldc,

@@ -414,9 +414,10 @@ class Tagger:
         return ac
 
     SPLITK_MAX_TILES = 64  # outputs with at most this many 256x256 tiles split a long K (small micro-batches)
+    FUSE_SPLITK_LN = True  # the LayerNorm behind a split-K GEMM folds the fp32 slabs itself (no kbner_splitk_finish launch)
     DEFER_REDUCE_MAX_TOKENS = 16384  # micro-batches up to this many (padded) sub-tokens batch their column-sum reductions (encoder_backward)
 
-    def _long_k_gemm(self, layout, A, W, Mp, N, K, C, ac, bias=None, addend=None, drop=ops.NO_DROP):
+    def _long_k_gemm(self, layout, A, W, Mp, N, K, C, ac, bias=None, addend=None, drop=ops.NO_DROP, finish=True):
         """C = bf16(dropout(A.W + bias) + addend) for the three K >= 3H GEMMs of a layer (FFN-down forward, its two dgrad
         siblings).  With a small micro-batch the [Mp, H] output has a few dozen tiles, each a serial chain of K/64 DMA
         round trips (86 us at K=4096 whatever Mp): K is then cut over up to 4 workgroups per tile (ops.gemm_splitk)."""
@@ -430,7 +431,10 @@ class Tagger:
         if splits:
             if ac.splitk_ws is None:
                 ac.splitk_ws = torch.empty((4, Mp, N), dtype=F32, device=self.device)
-            ops.gemm_splitk(layout, A, W, Mp, N, K, splits, ac.splitk_ws, C, bias=bias, addend=addend, drop=drop)
+            fold_later = not finish and self.FUSE_SPLITK_LN and ops.GEMM_HOOK is None and ops.HBM_HOOK is None
+            ops.gemm_splitk(layout, A, W, Mp, N, K, splits, ac.splitk_ws, C, bias=bias, addend=addend, drop=drop, finish=not fold_later)
+            if fold_later:
+                return ac.splitk_ws, splits      # the LayerNorm that consumes C folds the slabs itself (C is NOT written)
         else:
             epi = (EPI_BIAS if bias is not None else 0) | (EPI_ADD if addend is not None else 0)
             ops.gemm(layout, A, W, Mp, N, K, C=C, bias=bias, addend=addend, epi=epi, drop=drop, occupancy=True)
@@ -523,9 +527,13 @@ class Tagger:
             else:
                 ops.gemm(GEMM_NT, ac.x1[l], a.bf(p + "ffn1.weight"), Mp, F_, H, C=ac.act[l],
                          bias=a.param(p + "ffn1.bias"), epi=EPI_BIAS | EPI_GELU_FWD, occupancy=True)
-            self._long_k_gemm(GEMM_NT, ac.act[l], a.bf(p + "ffn2.weight"), Mp, H, F_, ac.h2[l], ac, bias=a.param(p + "ffn2.bias"),
-                              addend=ac.x1[l], drop=d_f)
-            ops.ln_fwd(ac.h2[l], a.param(p + "ln2.g"), a.param(p + "ln2.b"), eps, ac.x[l + 1], ac.st2[l][0], ac.st2[l][1])
+            slabs = self._long_k_gemm(GEMM_NT, ac.act[l], a.bf(p + "ffn2.weight"), Mp, H, F_, ac.h2[l], ac, bias=a.param(p + "ffn2.bias"),
+                                      addend=ac.x1[l], drop=d_f, finish=False)
+            if slabs is not None:   # small micro-batches: h2 = fold of the split-K slabs, written by the LayerNorm kernel itself
+                ops.ln_fwd_slabs(slabs[0], slabs[1], a.param(p + "ffn2.bias"), ac.x1[l], d_f, ac.h2[l], a.param(p + "ln2.g"),
+                                 a.param(p + "ln2.b"), eps, ac.x[l + 1], ac.st2[l][0], ac.st2[l][1])
+            else:
+                ops.ln_fwd(ac.h2[l], a.param(p + "ln2.g"), a.param(p + "ln2.b"), eps, ac.x[l + 1], ac.st2[l][0], ac.st2[l][1])
         self._enc_saved = (ids, pos_ids, maskbias, B, S, d_emb, d_layers) if need_grad else None
         return ac.x[L]
 
@@ -550,6 +558,7 @@ class Tagger:
         # colsum_rows_f32_batched) instead of by 3 L launches of ~4.7 us
         defer = Mp <= self.DEFER_REDUCE_MAX_TOKENS and ops.HBM_HOOK is None
         ln_items, cs_items, defer_ln, ln_blocks = [], [], None, 0
+        dx_slabs = None     # (split-K slabs, slices, residual) standing in for `dx` when the producing GEMM left its fold to LN2 backward
         if defer:
             ln_blocks = ops.ln_bwd_blocks(Mp)
             if ac.defer_ln_ws is None:
@@ -567,7 +576,8 @@ class Tagger:
             # LN2 backward; fused: d ffn2.bias = column sums of dh
             ops.ln_bwd(dx, ac.h2[l], ac.st2[l][0], ac.st2[l][1], a.param(p + "ln2.g"), dh, a.grad(p + "ln2.g"),
                        a.grad(p + "ln2.b"), a.grad(p + "ffn2.bias"), dhm=dhm if d_f[1] else None, drop=d_f,
-                       defer_ws=defer_ln[2 * l + 1] if defer else None)
+                       defer_ws=defer_ln[2 * l + 1] if defer else None, dy_slabs=dx_slabs)
+            dx_slabs = None
             if defer:
                 ln_items.append((defer_ln[2 * l + 1], a.grad(p + "ln2.g"), a.grad(p + "ln2.b"), a.grad(p + "ffn2.bias"), ln_blocks))
             # FFN down dgrad: dpre = (dh W2) * gelu'(pre)   (the derivative itself was saved by the forward epilogue)
@@ -590,11 +600,13 @@ class Tagger:
             else:
                 ops.gemm(GEMM_NN, dhm, a.bf(p + "ffn2.weight"), Mp, F_, H, C=dpre, aux=ac.dact[l], epi=EPI_DGELU, occupancy=True)
                 ops.colsum(dpre, a.grad(p + "ffn1.bias"))
-            self._long_k_gemm(GEMM_NN, dpre, a.bf(p + "ffn1.weight"), Mp, H, F_, ac.dx1, ac, addend=dh)
+            dx1_slabs = self._long_k_gemm(GEMM_NN, dpre, a.bf(p + "ffn1.weight"), Mp, H, F_, ac.dx1, ac, addend=dh, finish=False)
+            if dx1_slabs is not None:
+                dx1_slabs = (dx1_slabs[0], dx1_slabs[1], dh)
             # LN1 backward; fused: d o.bias
             ops.ln_bwd(ac.dx1, ac.h1[l], ac.st1[l][0], ac.st1[l][1], a.param(p + "ln1.g"), dh1, a.grad(p + "ln1.g"),
                        a.grad(p + "ln1.b"), a.grad(p + "o.bias"), dhm=dh1m if d_o[1] else None, drop=d_o,
-                       defer_ws=defer_ln[2 * l] if defer else None)
+                       defer_ws=defer_ln[2 * l] if defer else None, dy_slabs=dx1_slabs)
             if defer:
                 ln_items.append((defer_ln[2 * l], a.grad(p + "ln1.g"), a.grad(p + "ln1.b"), a.grad(p + "o.bias"), ln_blocks))
             # attention output projection
@@ -603,7 +615,11 @@ class Tagger:
             ops.attn_bwd(ac.qkv[l], ac.ctx[l], ac.dctx, maskbias, ac.lse[l], ac.dws, dqkv, B, S, H, A, drop=d_att,
                          dbias=a.grad(p + "qkv.bias"), ctx_lo=ac.ctx_lo[l] if self.ATTN_RESIDUAL else None)
             # QKV projection
-            self._long_k_gemm(GEMM_NN, dqkv, a.bf(p + "qkv.weight"), Mp, H, 3 * H, ac.dx, ac, addend=dh1)
+            # (the next layer's LN2 backward folds this GEMM's slabs itself -- the first launch of that layer, before anything
+            #  else writes the slab buffer; layer 0's gradient goes to the embedding LayerNorm as bf16)
+            dx_slabs = self._long_k_gemm(GEMM_NN, dqkv, a.bf(p + "qkv.weight"), Mp, H, 3 * H, ac.dx, ac, addend=dh1, finish=l == 0)
+            if dx_slabs is not None:
+                dx_slabs = (dx_slabs[0], dx_slabs[1], dh1)
             # weight gradients dW += dY^T X are deferred and launched for WGRAD_GROUP layers at once
             # (no split-K, no atomics; the dY buffers rotate so they stay live until the group is flushed)
             pending += [(dhm, ac.act[l], H, F_, p + "ffn2.weight"), (dpre, ac.x1[l], F_, H, p + "ffn1.weight"),

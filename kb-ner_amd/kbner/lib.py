@@ -57,6 +57,8 @@ SIGNATURES = {
     "kbner_colsum_rows_f32": (c_int, [P, c_int, c_int, P, P]),
     "kbner_colsum_rows_f32_batched": (c_int, [P, c_int, c_int, P]),
     "kbner_ln_bwd_blocks": (c_int, [c_int]),
+    "kbner_ln_fwd_slabs": (c_int, [P, c_int, P, P, c_int, U32, U32, P, P, P, c_float, P, P, P, c_int, c_int, P]),
+    "kbner_ln_bwd_slabs": (c_int, [P, c_int, P, c_int, P, P, P, P, P, P, P, P, P, c_int, c_int, P, U32, U32, P]),
     "kbner_ln_colreduce_batched": (c_int, [P, c_int, c_int, P]),
     "kbner_gemm_tile_rows": (c_int, [c_int, c_int, c_int]),
     "kbner_gemm_bf16_grouped_dyn": (c_int, [c_int, c_int, P, P, P]),

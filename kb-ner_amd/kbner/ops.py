@@ -347,11 +347,27 @@ def ln_ws(H, device):
     return _LN_WS[key]
 
 
-def ln_bwd(dy, h, mean, rstd, gamma, dh, dgamma, dbeta, dbias=None, dhm=None, drop=NO_DROP, defer_ws=None):
+def ln_fwd_slabs(ws, splits, bias, addend, drop, h, gamma, beta, eps, y, mean, rstd):
+    """ln_fwd of h = bf16(dropout(sum_s ws[s] + bias) + addend) -- the fold kbner_splitk_finish does, same bits -- which is also stored"""
+    M, H = h.shape
+    _chk(ws, F32, "ws")
+    L.call("kbner_ln_fwd_slabs", ptr(ws), splits, ptr(bias), ptr(addend), addend.shape[1] if addend is not None else 0, drop[0], drop[1],
+           ptr(h), ptr(gamma), ptr(beta), eps, ptr(y), ptr(mean), ptr(rstd), M, H, stream_ptr())
+
+
+def ln_bwd(dy, h, mean, rstd, gamma, dh, dgamma, dbeta, dbias=None, dhm=None, drop=NO_DROP, defer_ws=None, dy_slabs=None):
     """drop=(seed, thresh) with thresh != 0: also writes dhm = mask * dh / (1-p) (the dY of the GEMM behind the dropout).
     defer_ws (f32, >= ln_bwd_blocks(M) * 3 H): the per-block partial column sums stay there instead of being reduced into dgamma /
     dbeta / dbias by a launch of their own -- the caller reduces a whole backward pass's worth with ln_colreduce_batched."""
     M, H = h.shape
+    if dy_slabs is not None:   # (ws f32[splits, M, H], splits, addend): dy = bf16(sum_s ws[s] + addend), folded on the way in
+        sws, splits, sadd = dy_slabs
+        _chk(sws, F32, "dy_slabs")
+        deferred = defer_ws is not None
+        L.call("kbner_ln_bwd_slabs", ptr(sws), splits, ptr(sadd), sadd.shape[1] if sadd is not None else 0, ptr(h), ptr(mean), ptr(rstd),
+               ptr(gamma), ptr(dh), None if deferred else ptr(dgamma), None if deferred else ptr(dbeta), None if deferred else ptr(dbias),
+               ptr(defer_ws if deferred else ln_ws(H, h.device)), M, H, ptr(dhm), drop[0], drop[1], stream_ptr())
+        return
     with _hbm_timed("ln_bwd", (8 if drop[1] else 6) * M * H):   # read dy, h; write dh (+ dhm with dropout)
         if defer_ws is not None:
             L.call("kbner_ln_bwd", ptr(dy), ptr(h), ptr(mean), ptr(rstd), ptr(gamma), ptr(dh), None, None, None,
@@ -518,9 +534,10 @@ def gemm(layout, A, B, M, N, K, C=None, C32=None, bias=None, addend=None, aux=No
     return 128
 
 
-def gemm_splitk(layout, A, B, M, N, K, splits, ws, C, bias=None, addend=None, drop=NO_DROP):
+def gemm_splitk(layout, A, B, M, N, K, splits, ws, C, bias=None, addend=None, drop=NO_DROP, finish=True):
     """C = bf16(dropout(A.B + bias) + addend) with K cut into `splits` problems of one grouped launch (fp32 slabs in ws
-    f32[splits, M, N]) + the finish pass.  For NT / NN layouts whose output has too few tiles to fill the chip."""
+    f32[splits, M, N]) + the finish pass.  For NT / NN layouts whose output has too few tiles to fill the chip.
+    finish=False: the slabs only -- the consumer folds them itself (ln_fwd_slabs / ln_bwd(dy_slabs=...))."""
     if layout not in (L.GEMM_NT, L.GEMM_NN) or K % (64 * splits) or M % 256 or N % 256:
         raise L.KbnerError("gemm_splitk: unsupported shape / layout")
     _chk(ws, F32, "ws")
@@ -530,6 +547,8 @@ def gemm_splitk(layout, A, B, M, N, K, splits, ws, C, bias=None, addend=None, dr
         b_off = s * Ks if layout == L.GEMM_NT else s * Ks * B.shape[1]   # NT: B[N,K] rows; NN: Bmem[K,N] rows
         probs.append(make_problem(A, B, M, N, Ks, C32=ws[s], epi=L.EPI_STORE32, a_off=s * Ks, b_off=b_off))
     gemm_grouped(layout, probs)
+    if not finish:
+        return
     L.call("kbner_splitk_finish", ptr(ws), splits, ptr(bias), ptr(addend), addend.shape[1] if addend is not None else 0, ptr(C),
            C.shape[1], M, N, drop[0], drop[1], stream_ptr())
 

@@ -728,6 +728,97 @@ def test_deferred_column_sum_reductions_give_the_same_gradients():
         assert float(a1.grad(name).abs().max()) > 0, name
 
 
+def test_layernorm_folds_splitk_slabs_bit_identically():
+    """kbner_ln_fwd_slabs / kbner_ln_bwd_slabs (round 6: the LayerNorm behind a split-K GEMM sums the fp32 K slices itself) against
+    kbner_splitk_finish followed by kbner_ln_fwd / kbner_ln_bwd: the folded row (stored by the forward kernel), the normalised output,
+    mean, rstd, dh, the dropout branch dhm and the per-block partial column sums must be EQUAL -- both routes go through
+    splitk_fold8_pack.  2 / 3 / 4 slices, with and without bias / residual / dropout, H = 1024 and 256 (both row layouts), row counts
+    with several rows per wave."""
+    import torch
+    from kbner import ops
+    from kbner import lib as L
+    dev, BF = "cuda", torch.bfloat16
+    torch.manual_seed(9)
+    for (M, H, splits) in ((2048, 1024, 4), (512, 256, 3), (8192, 1024, 2)):
+        ws = torch.randn(splits, M, H, device=dev) * 0.7
+        bias = torch.randn(H, device=dev)
+        add = (torch.randn(M, H, device=dev) * 0.5).to(BF)
+        gamma, beta = torch.rand(H, device=dev) + 0.5, torch.randn(H, device=dev) * 0.1
+        for kw in (dict(bias=bias, addend=add, drop=ops.NO_DROP), dict(bias=bias, addend=add, drop=(5, ops.drop_thresh(0.1))),
+                   dict(bias=None, addend=None, drop=ops.NO_DROP), dict(bias=None, addend=add, drop=ops.NO_DROP)):
+            # ---- forward
+            h0 = torch.zeros(M, H, dtype=BF, device=dev)
+            L.call("kbner_splitk_finish", L.ptr(ws), splits, L.ptr(kw["bias"]), L.ptr(kw["addend"]), H if kw["addend"] is not None else 0,
+                   L.ptr(h0), H, M, H, kw["drop"][0], kw["drop"][1], L.stream_ptr())
+            y0, m0, r0 = torch.empty_like(h0), torch.empty(M, device=dev), torch.empty(M, device=dev)
+            ops.ln_fwd(h0, gamma, beta, 1e-5, y0, m0, r0)
+            h1, y1, m1, r1 = torch.zeros_like(h0), torch.empty_like(h0), torch.empty(M, device=dev), torch.empty(M, device=dev)
+            ops.ln_fwd_slabs(ws, splits, kw["bias"], kw["addend"], kw["drop"], h1, gamma, beta, 1e-5, y1, m1, r1)
+            torch.cuda.synchronize()
+            assert torch.equal(h0, h1) and torch.equal(y0, y1) and torch.equal(m0, m1) and torch.equal(r0, r1), (M, H, splits, sorted(kw))
+            if kw["bias"] is not None or kw["drop"][1]:
+                continue
+            # ---- backward (no bias / dropout inside the fold: the dgrad GEMMs have a residual at most)
+            hx = (torch.randn(M, H, device=dev) * 0.8).to(BF)
+            outs = []
+            for route in (0, 1):
+                for ln_drop in (ops.NO_DROP, (11, ops.drop_thresh(0.1))):
+                    dh = torch.zeros(M, H, dtype=BF, device=dev)
+                    dhm = torch.zeros(M, H, dtype=BF, device=dev) if ln_drop[1] else None
+                    part = torch.zeros(ops.ln_bwd_blocks(M) * 3 * H, device=dev)
+                    if route == 0:
+                        ops.ln_bwd(h0, hx, m0, r0, gamma, dh, None, None, None, dhm=dhm, drop=ln_drop, defer_ws=part)
+                    else:
+                        ops.ln_bwd(None, hx, m0, r0, gamma, dh, None, None, None, dhm=dhm, drop=ln_drop, defer_ws=part,
+                                   dy_slabs=(ws, splits, kw["addend"]))
+                    outs.append((dh, dhm, part))
+            torch.cuda.synchronize()
+            for k in range(2):
+                a, b = outs[k], outs[2 + k]
+                assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2]) and float(a[2].abs().max()) > 0, (M, H, splits, k)
+                assert (a[1] is None and b[1] is None) or torch.equal(a[1], b[1])
+            # the immediate (non-deferred) reduction of the slab route
+            dg, db, dbi = (torch.zeros(H, device=dev) for _ in range(3))
+            dg0, db0, dbi0 = (torch.zeros(H, device=dev) for _ in range(3))
+            dh = torch.zeros(M, H, dtype=BF, device=dev)
+            ops.ln_bwd(None, hx, m0, r0, gamma, dh, dg, db, dbi, dy_slabs=(ws, splits, kw["addend"]))
+            ops.ln_bwd(h0, hx, m0, r0, gamma, dh, dg0, db0, dbi0)
+            torch.cuda.synchronize()
+            for x, y in ((dg, dg0), (db, db0), (dbi, dbi0)):
+                assert float((x - y).abs().max()) <= 2e-5 * float(y.abs().max()) and float(y.abs().max()) > 0
+
+
+def test_fused_splitk_layernorm_step_equals_the_finish_route():
+    """Tagger.FUSE_SPLITK_LN at the YAML regime's shapes (4 sentences x 512 sub-tokens, H = 1024: the three K >= 3 H GEMMs of a layer
+    split their K): losses and every GEMM-weight gradient EQUAL to the route through kbner_splitk_finish, the atomically summed
+    gradients to fp32 order."""
+    import torch
+    from kbner import batch as kb
+    from kbner import engine
+    T, start, stop, x_idx = 29, 27, 28, 9
+    cfg = engine.EncoderConfig(vocab_size=600, hidden_size=1024, num_hidden_layers=2, num_attention_heads=16, intermediate_size=4096,
+                               max_position_embeddings=520, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    tgs = []
+    for fuse in (False, True):
+        tg = engine.Tagger(cfg, T, start, stop, device="cuda")
+        tg.init_random(seed=31)
+        tg.FUSE_SPLITK_LN = fuse
+        tgs.append(tg)
+    losses = []
+    for k in range(2):
+        mb = kb.to_device(kb.synthetic_batch(4, 512, vocab=600, T=T, x_idx=x_idx, start=start, stop=stop, seed=800 + k), "cuda")
+        losses.append([float(tg.forward_loss(mb, loss_scale=0.5, backward=True)) for tg in tgs])
+    torch.cuda.synchronize()
+    assert all(a == b for a, b in losses), losses
+    assert tgs[0].acts(4, 512).splitk_ws is not None            # the split-K route was taken
+    a0, a1 = tgs[0].arena, tgs[1].arena
+    ns = a0.n_shadow
+    assert torch.equal(a0.g[:ns], a1.g[:ns]) and float(a0.g[:ns].abs().max()) > 0
+    for name in a0.offsets:
+        g0, g1 = a0.grad(name), a1.grad(name)
+        assert float((g0 - g1).abs().max()) <= 2e-5 * max(float(g0.abs().max()), 1e-6), name
+
+
 def test_lazy_embedding_rows_equal_eager():
     """FusedAdamW.lazy_rows (round 6; kbner_adamw_hf_rows_lazy / kbner_adamw_rows_catchup): a live embedding row that gets no gradient
     is not streamed through HBM every step -- the zero-gradient updates it owes are applied, same fp32 operations in the same order,
