@@ -909,6 +909,58 @@ def test_lazy_embedding_rows_equal_eager():
         assert torch.equal(getattr(ta.arena, name), getattr(tb.arena, name)), ("second optimizer", name)
 
 
+def test_lazy_rows_checkpoint_resume():
+    """A checkpoint taken from a LAZY optimizer (state_dict() + the encoder's hf_state_dict(): both materialize the table first) and
+    loaded into a fresh tagger + lazy optimizer continues exactly like the uninterrupted run: the restored rows are all current,
+    the lazy clock restarts at the restored step count, and rows that go unvisited after the restart are caught up with the step
+    sizes recorded after it."""
+    import torch
+    from kbner import batch as kb
+    from kbner import engine
+    T, start, stop, x_idx = 29, 27, 28, 9
+    cfg = engine.EncoderConfig(vocab_size=3000, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                               max_position_embeddings=130, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+
+    def make():
+        tg = engine.Tagger(cfg, T, start, stop, device="cuda")
+        tg.init_random(seed=17)
+        opt = engine.FusedAdamW(tg.arena, lr=1e-3, lr_rate=10.0, t_total=30, warmup=2, max_norm=0.5)
+        opt.lazy_rows = True
+        return tg, opt
+
+    def batch(k):
+        return kb.to_device(kb.synthetic_batch(3, 128, vocab=(400, 2500, 400, 400, 2500, 400, 2500, 400)[k], T=T, x_idx=x_idx, start=start,
+                                               stop=stop, seed=900 + k), "cuda")
+    ta, oa = make()
+    grads = []
+    for k in range(8):
+        ta.forward_loss(batch(k), backward=True)
+        grads.append(ta.arena.g.clone())          # the resumed twin replays these (the embedding scatter's atomics are not reproducible)
+        oa.step()
+        if k == 3:
+            sd_opt = oa.state_dict()
+            sd_enc = {n: v.clone() for n, v in ta.hf_state_dict().items()}
+            head = {n: ta.arena.param(n).clone() for n in ("linear.weight", "linear.bias", "transitions")}
+            flags = ta.arena.emb_flags.clone()
+    oa.materialize()
+    tb, ob = make()
+    tb.load_hf_state_dict(sd_enc)
+    for n, v in head.items():
+        tb.set_param(n, v)
+    ob.load_state_dict(sd_opt)
+    assert ob.lazy_rows and ob.t == 4 and int(tb.arena.lazy["clock"][0]) == 4
+    assert torch.equal((tb.arena.emb_flags != 0), (flags != 0))       # the live rows are rebuilt from the moments
+    for k in range(4, 8):
+        lb = float(tb.forward_loss(batch(k), backward=True))
+        tb.arena.g.copy_(grads[k])
+        ob.step()
+        assert lb == lb
+    ob.materialize()
+    torch.cuda.synchronize()
+    for name in ("p", "m", "v"):
+        assert torch.equal(getattr(ta.arena, name), getattr(tb.arena, name)), name
+
+
 def test_weight_gradients_overwrite_instead_of_zeroing():
     """round 5: with every weight gradient a tile of the grouped 256 x 256 launch (H, F multiples of 256) FusedAdamW.step leaves
     g[:n_shadow] in place and the next backward pass's first weight-gradient launch OVERWRITES it (KBNER_EPI_STORE32), later
