@@ -221,11 +221,18 @@ __global__ __launch_bounds__(1024) void adamw_rows_catchup_kernel(const int* __r
 // then the update proper with its gradient, which is zeroed; row_t <- t, TOUCHED cleared.  Workgroup 0 also advances the clock.
 __global__ __launch_bounds__(256) void adamw_rows_lazy_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                               float* __restrict__ v, unsigned char* __restrict__ flags,
-                                                              int* __restrict__ row_t, const float* __restrict__ hist, int mask, int t,
+                                                              int* __restrict__ row_t, float* __restrict__ hist, int mask, int t,
                                                               int rows, int width, float step_size, float b1, float b2, float eps,
-                                                              const float* __restrict__ gnorm_sq, float max_norm, float grad_scale) {
+                                                              const float* __restrict__ gnorm_sq, float max_norm, float grad_scale,
+                                                              int* __restrict__ clock) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
+  // the clock advances with this launch: nothing in it reads `clock` (the step index is the argument t) or hist[t] (a row owes
+  // steps up to t - 1 at most); readers are later launches
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    hist[t & mask] = step_size;
+    *clock = t;
+  }
   if (row >= rows) return;
   const unsigned fl = __builtin_amdgcn_readfirstlane((unsigned)flags[row]);
   if (!(fl & 2u)) return;
@@ -415,8 +422,9 @@ int kbner_adamw_hf_rows_lazy(float* p, float* g, float* m, float* v, unsigned ch
   KBNER_CHECK_ARG(rows >= 0 && width > 0 && width % 4 == 0 && width <= 1024);
   if (rows > 0)
     hipLaunchKernelGGL(adamw_rows_lazy_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, p, g, m, v, flags, row_t, hist,
-                       hist_len - 1, t, rows, width, step_size, b1, b2, eps, gnorm_sq, max_norm, grad_scale);
-  hipLaunchKernelGGL(rows_clock_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, clock, hist, hist_len - 1, t, step_size);
+                       hist_len - 1, t, rows, width, step_size, b1, b2, eps, gnorm_sq, max_norm, grad_scale, clock);
+  else
+    hipLaunchKernelGGL(rows_clock_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, clock, hist, hist_len - 1, t, step_size);
   KBNER_LAUNCH_RET();
 }
 

@@ -88,6 +88,32 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const bf16_t* __restrict_
   }
 }
 
+// The same for FEW rows (round 6: a 4-sentence step has ~64 kept tokens): one wave per (row, tag) instead of one wave per row walking
+// the T tags one after the other -- 29 dependent load + reduce rounds on 16 workgroups were 33 us of latency for 2 MFLOP.
+__global__ __launch_bounds__(256) void head_fwd_rt_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ out, int R, int H,
+                                                          int T) {
+  const int lane = threadIdx.x % 64;
+  const int id = blockIdx.x * 4 + threadIdx.x / 64;
+  if (id >= R * T) return;
+  const int r = id / T, t = id % T;
+  float acc = 0.0f;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int h0 = (lane + 64 * c) * 8;
+    if (h0 < H) {
+      float xv[8];
+      unpack8(*reinterpret_cast<const uint4*>(x + (size_t)r * H + h0), xv);
+      const float4 a = *reinterpret_cast<const float4*>(w + (size_t)t * H + h0);
+      const float4 b = *reinterpret_cast<const float4*>(w + (size_t)t * H + h0 + 4);
+      // (the same expression and chunk order as head_fwd_kernel: the same bits)
+      acc += xv[0] * a.x + xv[1] * a.y + xv[2] * a.z + xv[3] * a.w + xv[4] * b.x + xv[5] * b.y + xv[6] * b.z + xv[7] * b.w;
+    }
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) out[(size_t)r * T + t] = acc + bias[t];
+}
+
 // dx[r,h] = sum_t de[r,t] * w[t,h]        (one wave per row; bf16 out)
 __global__ __launch_bounds__(256) void head_bwd_dx_kernel(const float* __restrict__ de, const float* __restrict__ w,
                                                           bf16_t* __restrict__ dx, int R, int H, int T) {
@@ -134,14 +160,15 @@ __global__ __launch_bounds__(256) void head_bwd_dx_kernel(const float* __restric
 // zero-padded behind T, so that a row's tag values leave LDS as TMAX / 4 broadcast ds_read_b128 and the tag loop is straight-line code
 // (round 6: with the runtime stride T the compiler issued one ds_read_b32 per (row, tag) and waited for each -- 1856 exposed LDS
 // latencies per block, 110 us per launch whatever the batch, 0.9 % of a 4-sentence optimizer step).
-template <int TMAX>
+// RB rows per block: 64, or 16 when there are few rows (round 6: 64 kept tokens on 4 workgroups were 64 dependent rounds each, 31 us).
+template <int TMAX, int RB = 64>
 __global__ __launch_bounds__(256) void head_bwd_dw_kernel(const float* __restrict__ de, const bf16_t* __restrict__ x,
                                                           float* __restrict__ dw, float* __restrict__ db, int R, int H, int T) {
-  __shared__ __attribute__((aligned(16))) float sde[64 * TMAX];
+  __shared__ __attribute__((aligned(16))) float sde[RB * TMAX];
   const int h = blockIdx.x * 256 + threadIdx.x;
-  const int r0 = blockIdx.y * 64;
-  const int nr = min(64, R - r0);
-  for (int i = threadIdx.x; i < 64 * TMAX; i += 256) {
+  const int r0 = blockIdx.y * RB;
+  const int nr = min(RB, R - r0);
+  for (int i = threadIdx.x; i < RB * TMAX; i += 256) {
     const int r = i / TMAX, t = i % TMAX;
     sde[i] = (r < nr && t < T) ? de[(size_t)(r0 + r) * T + t] : 0.0f;
   }
@@ -253,7 +280,9 @@ int kbner_scatter_rows(const bf16_t* dout, const int* idx, bf16_t* dsrc, int R, 
 int kbner_head_fwd(const bf16_t* x, const float* w, const float* bias, float* out, int R, int H, int T, void* stream) {
   KBNER_CHECK_ARG(R >= 0 && H > 0 && H % 8 == 0 && H <= 8192 && T > 0 && T <= HEAD_MAXT);
   if (R == 0) return 0;
-  if (H <= 1024)
+  if (H <= 1024 && R <= 512)
+    hipLaunchKernelGGL(head_fwd_rt_kernel, dim3((R * T + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, w, bias, out, R, H, T);
+  else if (H <= 1024)
     hipLaunchKernelGGL(head_fwd_kernel, dim3(rows_grid(R)), dim3(256), 0, (hipStream_t)stream, x, w, bias, out, R, H, T);
   else   // the BiLSTM tagger head of config 5: 2 x 1024 (padded) hidden columns
     hipLaunchKernelGGL(head_fwd_wide_kernel, dim3(rows_grid(R)), dim3(256), 0, (hipStream_t)stream, x, w, bias, out, R, H, T);
@@ -270,7 +299,10 @@ int kbner_head_bwd_dx(const float* de, const float* w, bf16_t* dx, int R, int H,
 int kbner_head_bwd_dw(const float* de, const bf16_t* x, float* dw, float* db, int R, int H, int T, void* stream) {
   KBNER_CHECK_ARG(R >= 0 && H > 0 && T > 0 && T <= HEAD_MAXT);
   if (R == 0) return 0;
-  if (T <= 32)
+  if (T <= 32 && R <= 512)
+    hipLaunchKernelGGL((head_bwd_dw_kernel<32, 16>), dim3((H + 255) / 256, (R + 15) / 16), dim3(256), 0, (hipStream_t)stream, de, x, dw,
+                       db, R, H, T);
+  else if (T <= 32)
     hipLaunchKernelGGL(head_bwd_dw_kernel<32>, dim3((H + 255) / 256, (R + 63) / 64), dim3(256), 0, (hipStream_t)stream, de, x, dw,
                        db, R, H, T);
   else
