@@ -549,7 +549,7 @@ def main():
         # the fused form the drop-in trainer uses for the YAMLs' 1 x 4 (one weighted batch of 4: same loss and gradient)
         mb4 = [kb.to_device(kb.synthetic_batch(4, S, vocab=cfg.vocab_size, T=T, x_idx=x_idx, start=start, stop=stop,
                                                seed=kb.SEED + 60), dev)]
-        sec = timed(tg, opt, mb4, steps=6)
+        sec = timed(tg, opt, mb4, steps=40, warm=5)    # (0.45 s: six 10-ms steps were a noisy sample of the YAML regime's number)
         extra["micro_batch_x_accumulate"]["1x4_fused_by_trainer"] = {"value": round(4 / sec, 2), "ms_per_step": round(sec * 1e3, 3)}
         # rounds 1-4's headline point, 128 sentences per launch (52 GB of saved activations): the fixed per-step costs (optimizer,
         # launch tails) amortise over half the sentences -- kept for continuity with BENCH_r01..r04

@@ -180,6 +180,13 @@ int kbner_embed_ln_fwd(const int* ids, const int* pos_ids, const float* word, co
 int kbner_embed_ln_bwd(const kbner_bf16* dy, const kbner_bf16* h0, const float* mean, const float* rstd, const float* gamma,
                        const int* ids, const int* pos_ids, float* dgamma, float* dbeta, float* dword, float* dpos,
                        float* dtype0, float* ws, int M, int H, uint32_t drop_seed, uint32_t drop_thresh, void* stream);
+/* the same with the optimizer's embedding-row flags (u8 per row of dword; KBNER_ROW_LIVE | KBNER_ROW_TOUCHED below) set by the kernel
+ * for every row it adds a gradient to -- what a kbner_mark_rows launch on `ids` does --, and, like kbner_ln_bwd, with dgamma == NULL
+ * leaving the partial column sums in `ws` for kbner_ln_colreduce_batched.  row_flags may be NULL. */
+int kbner_embed_ln_bwd_mark(const kbner_bf16* dy, const kbner_bf16* h0, const float* mean, const float* rstd, const float* gamma,
+                            const int* ids, const int* pos_ids, float* dgamma, float* dbeta, float* dword, float* dpos,
+                            float* dtype0, float* ws, unsigned char* row_flags, int M, int H, uint32_t drop_seed, uint32_t drop_thresh,
+                            void* stream);
 
 /* ---------------- dropout (torch.nn.Dropout inside transformers' BertEmbeddings / BertSelfAttention / BertSelfOutput /
  * BertOutput, active while ModelFinetuner trains: finetune_trainer.py:938 model.train()) ----------------

@@ -303,7 +303,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                                                      float* __restrict__ dpos, float* __restrict__ ws, int M, int H,
                                                      bf16_t* __restrict__ dhm, uint32_t drop_seed, uint32_t drop_thresh,
                                                      const float* __restrict__ dy_ws = nullptr, int dy_splits = 0,
-                                                     const bf16_t* __restrict__ dy_add = nullptr, int dy_ldadd = 0) {
+                                                     const bf16_t* __restrict__ dy_add = nullptr, int dy_ldadd = 0,
+                                                     unsigned char* __restrict__ row_flags = nullptr) {
   // SLABS (round 6, small micro-batches; a separate instantiation, the other one is untouched): the incoming gradient row is folded from the split-K slabs of the GEMM that
   // produced it -- bf16(sum_s dy_ws[s] + dy_add), kbner_splitk_finish's bits (splitk_fold8_pack) -- instead of read from `dy`.
   // Dropout replay (drop_thresh != 0): EMBED -> the incoming dy is masked first (y = drop(LN(h0)));
@@ -395,6 +396,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
     if (EMBED) {
       float* stage = &red[0][wid][0];   // free until the column-sum reduction after the row loop
       flush_row_atomic<NCH>(dword + (size_t)ids[r] * H, H, lane, d, stage);
+      // EMBED: the optimizer's row flags (KBNER_ROW_LIVE | KBNER_ROW_TOUCHED, include/kbner.h) of the rows this pass writes
+      if (row_flags != nullptr && lane == 0) row_flags[ids[r]] = 3;
       // Position rows repeat B times per step (514 rows shared by every sentence): with the grid a multiple of the sentence
       // length a wave's successive rows r, r + nwave, ... are the SAME position of different sentences, so their
       // gradients are summed in registers and flushed once per run of equal ids instead of once per token
@@ -623,9 +626,10 @@ int kbner_ln_colreduce_batched(const long long* items, int n, int H, void* strea
   KBNER_LAUNCH_RET();
 }
 
-int kbner_embed_ln_bwd(const bf16_t* dy, const bf16_t* h0, const float* mean, const float* rstd, const float* gamma,
-                       const int* ids, const int* pos_ids, float* dgamma, float* dbeta, float* dword, float* dpos,
-                       float* dtype0, float* ws, int M, int H, uint32_t drop_seed, uint32_t drop_thresh, void* stream) {
+static int embed_ln_bwd_impl(const bf16_t* dy, const bf16_t* h0, const float* mean, const float* rstd, const float* gamma,
+                             const int* ids, const int* pos_ids, float* dgamma, float* dbeta, float* dword, float* dpos,
+                             float* dtype0, float* ws, int M, int H, uint32_t drop_seed, uint32_t drop_thresh, unsigned char* row_flags,
+                             void* stream) {
   KBNER_CHECK_ARG(M >= 0 && H > 0 && H % 8 == 0 && H <= 64 * 8 * LN_MAXCH && ws != nullptr);
   if (M == 0) return 0;
   int grid = ln_grid(M);
@@ -633,14 +637,33 @@ int kbner_embed_ln_bwd(const bf16_t* dy, const bf16_t* h0, const float* mean, co
   if (H <= 512)
     hipLaunchKernelGGL((ln_bwd_kernel<1, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, h0, mean, rstd, gamma,
                        (bf16_t*)nullptr, dgamma, dbeta, dtype0, ids, pos_ids, dword, dpos, ws, M, H, (bf16_t*)nullptr, drop_seed,
-                       drop_thresh);
+                       drop_thresh, (const float*)nullptr, 0, (const bf16_t*)nullptr, 0, row_flags);
   else
     hipLaunchKernelGGL((ln_bwd_kernel<2, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, h0, mean, rstd, gamma,
                        (bf16_t*)nullptr, dgamma, dbeta, dtype0, ids, pos_ids, dword, dpos, ws, M, H, (bf16_t*)nullptr, drop_seed,
-                       drop_thresh);
-  hipLaunchKernelGGL(ln_colreduce_kernel, dim3((3 * H + 63) / 64, 8), dim3(256), 0, (hipStream_t)stream, ws, grid, H, dgamma, dbeta,
-                     dtype0);
+                       drop_thresh, (const float*)nullptr, 0, (const bf16_t*)nullptr, 0, row_flags);
+  // (dgamma == NULL: the partial rows stay in ws for kbner_ln_colreduce_batched, as for kbner_ln_bwd)
+  if (dgamma != nullptr)
+    hipLaunchKernelGGL(ln_colreduce_kernel, dim3((3 * H + 63) / 64, 8), dim3(256), 0, (hipStream_t)stream, ws, grid, H, dgamma, dbeta,
+                       dtype0);
   KBNER_LAUNCH_RET();
+}
+
+int kbner_embed_ln_bwd(const bf16_t* dy, const bf16_t* h0, const float* mean, const float* rstd, const float* gamma,
+                       const int* ids, const int* pos_ids, float* dgamma, float* dbeta, float* dword, float* dpos,
+                       float* dtype0, float* ws, int M, int H, uint32_t drop_seed, uint32_t drop_thresh, void* stream) {
+  return embed_ln_bwd_impl(dy, h0, mean, rstd, gamma, ids, pos_ids, dgamma, dbeta, dword, dpos, dtype0, ws, M, H, drop_seed, drop_thresh,
+                           nullptr, stream);
+}
+
+// the same + the optimizer's embedding-row flags set by the kernel itself (row_flags u8[rows of dword], may be NULL): every row this
+// pass adds a gradient to becomes KBNER_ROW_LIVE | KBNER_ROW_TOUCHED -- what a kbner_mark_rows launch on `ids` would do
+int kbner_embed_ln_bwd_mark(const bf16_t* dy, const bf16_t* h0, const float* mean, const float* rstd, const float* gamma,
+                            const int* ids, const int* pos_ids, float* dgamma, float* dbeta, float* dword, float* dpos,
+                            float* dtype0, float* ws, unsigned char* row_flags, int M, int H, uint32_t drop_seed, uint32_t drop_thresh,
+                            void* stream) {
+  return embed_ln_bwd_impl(dy, h0, mean, rstd, gamma, ids, pos_ids, dgamma, dbeta, dword, dpos, dtype0, ws, M, H, drop_seed, drop_thresh,
+                           row_flags, stream);
 }
 
 }  // extern "C"

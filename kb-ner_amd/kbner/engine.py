@@ -562,7 +562,7 @@ class Tagger:
         if defer:
             ln_blocks = ops.ln_bwd_blocks(Mp)
             if ac.defer_ln_ws is None:
-                ac.defer_ln_ws = torch.empty((2 * L, ln_blocks * 3 * H), dtype=F32, device=self.device)
+                ac.defer_ln_ws = torch.empty((2 * L + 1, ln_blocks * 3 * H), dtype=F32, device=self.device)
                 ac.colsum_ws_all = torch.empty((L, 2 * (Mp // 128), F_), dtype=F32, device=self.device)
             defer_ln = ac.defer_ln_ws
         for l in range(L - 1, -1, -1):
@@ -637,14 +637,16 @@ class Tagger:
         a.wgrad_stale = False   # every GEMM-weight gradient has been written by this pass
         # small batches: the column-sum reductions of the pass (2 L LayerNorm partials -> gamma / beta / bias gradients, L FFN-up bias
         # workspaces) in two launches instead of 3 L
+        # (the embedding LayerNorm's kernel also sets the optimizer's row flags of the rows it writes, and its partial sums join the batch)
+        ops.embed_ln_bwd(dx, ac.h0, ac.emb_mean, ac.emb_rstd, a.param("emb.ln.g"), ids, pos_ids, a.grad("emb.ln.g"),
+                         a.grad("emb.ln.b"), a.grad("emb.word"), a.grad("emb.pos"), a.grad("emb.type")[0], drop=d_emb,
+                         row_flags=a.emb_flags, defer_ws=defer_ln[2 * L] if defer else None)
+        if defer:
+            ln_items.append((defer_ln[2 * L], a.grad("emb.ln.g"), a.grad("emb.ln.b"), a.grad("emb.type")[0], ln_blocks))
         for k in range(0, len(ln_items), 64):
             ops.ln_colreduce_batched(ln_items[k:k + 64], H)
         for k in range(0, len(cs_items), 64):
             ops.colsum_rows_f32_batched(cs_items[k:k + 64], F_)
-        ops.embed_ln_bwd(dx, ac.h0, ac.emb_mean, ac.emb_rstd, a.param("emb.ln.g"), ids, pos_ids, a.grad("emb.ln.g"),
-                         a.grad("emb.ln.b"), a.grad("emb.word"), a.grad("emb.pos"), a.grad("emb.type")[0], drop=d_emb)
-        if a.emb_flags is not None:
-            ops.mark_rows(ids, a.emb_flags)
 
     def _wgrads(self, pairs, Mp):
         a = self.arena
@@ -727,8 +729,12 @@ class Tagger:
         return l2_val
 
     def _sentence_weights(self, weights, B):
-        if weights is None:
-            return torch.full((B,), 1.0 / B, dtype=F32, device=self.device)
+        if weights is None:   # (read-only constants: one tensor per batch size, not one fill launch per micro-batch)
+            cache = self.__dict__.setdefault("_mean_weights", {})
+            w = cache.get(B)
+            if w is None:
+                w = cache[B] = torch.full((B,), 1.0 / B, dtype=F32, device=self.device)
+            return w
         w = torch.as_tensor(weights, dtype=F32, device=self.device).contiguous()
         if w.numel() != B:
             raise ValueError("weights must hold one value per sentence")
@@ -753,7 +759,15 @@ class Tagger:
         logz, gold, alpha = ops.crf_nll_fwd(em, trans, batch["ctags"], batch["clens"], self.start, self.stop)
         ops.wdiff_sum(logz, gold, w, loss)
         if backward:
-            dl = w * loss_scale
+            if weights is None:    # the constant 1 / B weights: their scaled copy is a constant per (B, loss_scale) too
+                cache = self.__dict__.setdefault("_mean_weights_scaled", {})
+                dl = cache.get((B, float(loss_scale)))
+                if dl is None:
+                    if len(cache) > 64:
+                        cache.clear()
+                    dl = cache[(B, float(loss_scale))] = w * loss_scale
+            else:
+                dl = w * loss_scale
             demit = ops.crf_nll_bwd(em, trans, batch["ctags"], batch["clens"], alpha, logz, dl, self.start, self.stop,
                                     a.grad("transitions"))
             self._backprop_emissions(demit, pooled, crow_idx, B, nc, R, S, grad_ready)

@@ -50,6 +50,7 @@ SIGNATURES = {
     "kbner_ln_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, c_int, P, U32, U32, P]),
     "kbner_embed_ln_fwd": (c_int, [P, P, P, P, P, P, P, c_float, P, P, P, P, c_int, c_int, U32, U32, P]),
     "kbner_embed_ln_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, U32, U32, P]),
+    "kbner_embed_ln_bwd_mark": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, U32, U32, P]),
     "kbner_dropout_mask": (c_int, [P, c_int, c_int, c_int, U32, U32, P]),
     "kbner_gemm_bf16": (c_int, [c_int, P, c_int, P, c_int, c_int, c_int, c_int, P, c_int, P, c_int, P, P, c_int, P, c_int,
                                 P, c_int, c_int, c_int, c_float, U32, U32, P]),

@@ -407,10 +407,20 @@ def embed_ln_fwd(ids, pos_ids, word, pos, type0, gamma, beta, eps, h0, y, mean, 
            ptr(y), ptr(mean), ptr(rstd), M, H, drop[0], drop[1], stream_ptr())
 
 
-def embed_ln_bwd(dy, h0, mean, rstd, gamma, ids, pos_ids, dgamma, dbeta, dword, dpos, dtype0, drop=NO_DROP):
+def embed_ln_bwd(dy, h0, mean, rstd, gamma, ids, pos_ids, dgamma, dbeta, dword, dpos, dtype0, drop=NO_DROP, row_flags=None, defer_ws=None):
+    """row_flags (u8 per row of dword): set to LIVE | TOUCHED by the kernel for every row it adds a gradient to (instead of a mark_rows
+    launch); defer_ws: the partial column sums stay there for ln_colreduce_batched (dgamma / dbeta / dtype0 are not touched)."""
     M, H = ids.numel(), dword.shape[1]
-    L.call("kbner_embed_ln_bwd", ptr(dy), ptr(h0), ptr(mean), ptr(rstd), ptr(gamma), ptr(ids), ptr(pos_ids), ptr(dgamma),
-           ptr(dbeta), ptr(dword), ptr(dpos), ptr(dtype0), ptr(ln_ws(H, dy.device)), M, H, drop[0], drop[1], stream_ptr())
+    if row_flags is not None:
+        _chk(row_flags, torch.uint8, "row_flags")
+    if row_flags is None and defer_ws is None:
+        L.call("kbner_embed_ln_bwd", ptr(dy), ptr(h0), ptr(mean), ptr(rstd), ptr(gamma), ptr(ids), ptr(pos_ids), ptr(dgamma),
+               ptr(dbeta), ptr(dword), ptr(dpos), ptr(dtype0), ptr(ln_ws(H, dy.device)), M, H, drop[0], drop[1], stream_ptr())
+        return
+    deferred = defer_ws is not None
+    L.call("kbner_embed_ln_bwd_mark", ptr(dy), ptr(h0), ptr(mean), ptr(rstd), ptr(gamma), ptr(ids), ptr(pos_ids),
+           None if deferred else ptr(dgamma), None if deferred else ptr(dbeta), ptr(dword), ptr(dpos), None if deferred else ptr(dtype0),
+           ptr(defer_ws if deferred else ln_ws(H, dy.device)), ptr(row_flags), M, H, drop[0], drop[1], stream_ptr())
 
 
 # ---------------------------------------------------------------- GEMM
