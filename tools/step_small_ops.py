@@ -23,8 +23,8 @@ with profile(activities=[ProfilerActivity.CPU], with_stack=True, record_shapes=T
 import collections
 agg = collections.Counter()
 for ev in prof.events():
-    if ev.name.startswith("aten::") and ev.name in ("aten::fill_", "aten::zero_", "aten::copy_", "aten::mul", "aten::full", "aten::zeros", "aten::zeros_like",
-                                                     "aten::where", "aten::add_", "aten::_to_copy", "aten::empty_like", "aten::index_put_", "aten::select"):
+    if ev.name.startswith("aten::") and ev.name not in ("aten::select", "aten::as_strided", "aten::view", "aten::empty", "aten::slice", "aten::empty_strided",
+                                                         "aten::reshape", "aten::_unsafe_view", "aten::unsqueeze", "aten::expand", "aten::item", "aten::_local_scalar_dense"):
         st = [f for f in (ev.stack or []) if "kb-ner_amd" in f or "bench" in f]
         agg[(ev.name, tuple(s.split("kb-ner_amd/")[-1] for s in st[:2]), str(ev.input_shapes)[:60])] += 1
 for (n, st, shp), c in sorted(agg.items(), key=lambda kv: -kv[1])[:40]:
