@@ -124,10 +124,11 @@ struct RowState {
   float4 p[4], m[4], v[4];
 };
 
+// (m * b1 + (1 - b1) * 0 and v * b2 + (1 - b2) * 0 * 0 of the eager kernel, without the terms that are zero: the same values -- at
+//  most the sign of a zero differs, which no later operation of the update can turn into a different number)
 __device__ __forceinline__ void adam_zero_grad_step(float& p, float& m, float& v, float step, float b1, float b2, float eps) {
-  const float gk = 0.0f;
-  m = m * b1 + (1.0f - b1) * gk;
-  v = v * b2 + (1.0f - b2) * gk * gk;
+  m = m * b1;
+  v = v * b2;
   p -= step * (m / (sqrtf(v) + eps));
 }
 
