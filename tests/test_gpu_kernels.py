@@ -909,6 +909,55 @@ def test_lazy_embedding_rows_equal_eager():
         assert torch.equal(getattr(ta.arena, name), getattr(tb.arena, name)), ("second optimizer", name)
 
 
+def test_lazy_rows_under_the_captured_inference_graph():
+    """Forward-only passes of one shape are replayed from a HIP graph after their third call (Tagger.encoder_forward); with
+    FusedAdamW.lazy_rows the capture contains the catch-up launch of the looked-up rows, which reads the optimizer's clock from
+    device memory -- replays between optimizer steps must see the rows as up to date as an eager twin's.  Six rounds of (training
+    step, two forward-only passes on a batch of rarely visited ids): equal losses every time, before and after the capture."""
+    import torch
+    from kbner import batch as kb
+    from kbner import engine
+    T, start, stop, x_idx = 29, 27, 28, 9
+    cfg = engine.EncoderConfig(vocab_size=4000, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                               max_position_embeddings=130, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    tgs, opts = [], []
+    for lazy in (False, True):
+        tg = engine.Tagger(cfg, T, start, stop, device="cuda")
+        tg.init_random(seed=23)
+        opt = engine.FusedAdamW(tg.arena, lr=2e-3, lr_rate=10.0, t_total=40, warmup=2, max_norm=0.5)
+        opt.lazy_rows = lazy
+        tgs.append(tg)
+        opts.append(opt)
+    ev = kb.to_device(kb.synthetic_batch(3, 128, vocab=4000, T=T, x_idx=x_idx, start=start, stop=stop, seed=77), "cuda")
+    # every id of the evaluation batch becomes live first (one training step on it), then is left alone by the training batches
+    for tg, opt in zip(tgs, opts):
+        tg.forward_loss(ev, backward=True)
+    tgs[1].arena.g.copy_(tgs[0].arena.g)
+    for opt in opts:
+        opt.step()
+    graphs = []
+    for rnd in range(6):
+        mb = kb.to_device(kb.synthetic_batch(3, 128, vocab=300, T=T, x_idx=x_idx, start=start, stop=stop, seed=600 + rnd), "cuda")
+        for tg in tgs:
+            tg.train(True)
+            tg.forward_loss(mb, backward=True)
+        tgs[1].arena.g.copy_(tgs[0].arena.g)
+        for opt in opts:
+            opt.step()
+        for rep in range(2):
+            ems = []
+            for tg in tgs:
+                tg.train(False)
+                ems.append(tg.forward_features(ev).clone())      # encoder_forward(need_grad=False): eager twice, then captured
+            assert torch.equal(ems[0], ems[1]), (rnd, rep, float((ems[0] - ems[1]).abs().max()))
+        graphs.append(tgs[1].acts(3, 128).infer_graph["graph"] if tgs[1].acts(3, 128).infer_graph else None)
+    assert any(g not in (None, False) for g in graphs), "the forward-only pass was captured"   # (else this test checks nothing new)
+    opts[1].materialize()
+    torch.cuda.synchronize()
+    for name in ("p", "m", "v"):
+        assert torch.equal(getattr(tgs[0].arena, name), getattr(tgs[1].arena, name)), name
+
+
 def test_lazy_rows_checkpoint_resume():
     """A checkpoint taken from a LAZY optimizer (state_dict() + the encoder's hf_state_dict(): both materialize the table first) and
     loaded into a fresh tagger + lazy optimizer continues exactly like the uninterrupted run: the restored rows are all current,
