@@ -457,8 +457,11 @@ def _student_from(d, arrs, prefix):
     return cp, student
 
 
-def test_training_trajectory_vs_reference_run(g12):
-    """ModelFinetuner.train on the HIP engine from the reference run's initial head / transitions, same YAML, no dropout, no
+@pytest.mark.parametrize("lazy_rows", [True, "always"])
+def test_training_trajectory_vs_reference_run(g12, lazy_rows):
+    """(lazy_rows "always": the same run with FusedAdamW.lazy_rows forced on -- the tiny vocabulary would keep the eager row update --
+    and the small-batch routes of round 6 as the trainer picks them: the reference's trajectory must come out either way.)
+    ModelFinetuner.train on the HIP engine from the reference run's initial head / transitions, same YAML, no dropout, no
     shuffling: per-micro-batch losses, epoch losses (the reference's loss/accum convention), dev scores (percent) and the final
     transitions against what the reference's own ModelFinetuner.train produced (tests/golden/e2e_train.*).
     Tolerances: bf16 GEMMs/attention vs the reference's fp32 (Adam at lr*lr_rate = 0.1 on the transitions amplifies rounding
@@ -476,7 +479,9 @@ def test_training_trajectory_vs_reference_run(g12):
 
     student.forward_backward = spy
     trainer = ModelFinetuner(student, None, cp.corpus, config=cp.config, **cp.config["ModelFinetuner"])
+    trainer.lazy_embedding_rows = lazy_rows
     out = trainer.train(cp.get_target_path, fuse_accumulation=False, **cp.config["train"])
+    assert bool(trainer.optimizer.lazy_rows) == (lazy_rows == "always")
     mine = [float(x) for x in steps]
     ref = e2e["step_losses"]
     assert len(mine) == len(ref)
