@@ -545,8 +545,11 @@ def test_evaluate_with_reference_weights_vs_reference_lines(g12, part):
 
 
 # ------------------------------------------------------------------ checkpoint / resume
-def test_checkpoint_resume_equals_uninterrupted(g12, tmp_path):
-    """4 epochs straight == 2 epochs + checkpoint.pt + a NEW process-like restart from Model.load_checkpoint for 2 more
+@pytest.mark.parametrize("lazy_rows", [True, "always"])
+def test_checkpoint_resume_equals_uninterrupted(g12, tmp_path, lazy_rows):
+    """(lazy_rows "always": with lazy embedding rows forced on -- the checkpoint then holds a MATERIALIZED table and the restart
+    restarts the lazy clock from it.)
+    4 epochs straight == 2 epochs + checkpoint.pt + a NEW process-like restart from Model.load_checkpoint for 2 more
     (nn.py:69-139, finetune_trainer.py:1261-1277, trainer.py:582): Adam moments, step count (LR decay position), batch order and
     dropout streams all continue.  Atomics in the embedding backward make runs differ by rounding only."""
     import copy
@@ -560,8 +563,9 @@ def test_checkpoint_resume_equals_uninterrupted(g12, tmp_path):
         cfg.update(max_epochs=4, checkpoint=True, shuffle=True)
         student.use_word_dropout = student.engine.word_dropout = 0.1     # dropout streams are part of what must continue
         student.engine.seed_dropout(123)
-        base = tmp_path / ("straight" if epochs_then is None else "resumed")
+        base = tmp_path / (("straight" if epochs_then is None else "resumed") + str(lazy_rows))
         tr = ModelFinetuner(student, None, cp.corpus, config=cp.config, **cp.config["ModelFinetuner"])
+        tr.lazy_embedding_rows = lazy_rows
         if epochs_then is None:
             out = tr.train(base, **cfg)
             return out["train_loss_history"], torch.load(base / "final-model.pt", weights_only=False)
@@ -584,7 +588,9 @@ def test_checkpoint_resume_equals_uninterrupted(g12, tmp_path):
         ck = FastSequenceTagger.load_checkpoint(base / "checkpoint.pt")
         assert ck["epoch"] == epochs_then and ck["optimizer_state_dict"]["t"] > 0
         tr2 = ModelFinetuner.load_from_checkpoint(ck, cp.corpus, config=cp.config, **cp.config["ModelFinetuner"])
+        tr2.lazy_embedding_rows = lazy_rows
         out2 = tr2.train(base, **cfg)
+        assert bool(tr2.optimizer.lazy_rows) == (lazy_rows == "always")
         hist += out2["train_loss_history"]
         return hist, torch.load(base / "final-model.pt", weights_only=False)
 
