@@ -988,6 +988,18 @@ def test_train_py_distill_mode_command_line(tmp_path):
     assert "Distilling" not in out and "Testing using best model" in out
 
 
+def test_multiview_and_kd_trainers_with_lazy_rows(tmp_path, monkeypatch):
+    """The multi-view run (two encoder passes per step: the context view looks its own sub-tokens up) and the teacher-student run,
+    both pinned to the reference's own trainer, once more with FusedAdamW.lazy_rows forced on for every ModelFinetuner: same
+    assertions against the same goldens."""
+    from flair.trainers import ModelFinetuner
+    monkeypatch.setattr(ModelFinetuner, "lazy_embedding_rows", "always", raising=False)
+    (tmp_path / "mv").mkdir()
+    (tmp_path / "kd").mkdir()
+    test_multiview_training_vs_reference_run(tmp_path / "mv")
+    test_kd_training_vs_reference_run(tmp_path / "kd", "posterior_crf_att")
+
+
 @pytest.mark.parametrize("flags", [dict(distill_exact=True, distill_posterior=False), dict(calculate_l2_loss=True),
                                    dict(calculate_l2_loss=True, l2_loss_only=True)])
 def test_multiview_other_branches_train(tmp_path, flags):
